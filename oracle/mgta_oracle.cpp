@@ -1,0 +1,1004 @@
+// mgta_oracle.cpp — CPU ORACLE.   *** TEST INFRASTRUCTURE, NOT PRODUCT CODE ***
+//
+// Plain C++17 restatement of the MegaGTA hot path (read -> SdBG edges -> succinct graph navigation
+// -> profile-HMM A*), written for clarity, not speed.  Each block cites the reference file:line
+// whose behaviour it follows (paths relative to /root/reference/src).  Pinned against golden
+// vectors generated from the compiled reference (tests/golden/, tests/test_oracle_golden.py).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+#include "mgta_oracle.h"
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+constexpr int kBuckets = ORC_NUM_BUCKETS;
+constexpr int kMaxMulti = 65535;    // definitions.h:33
+constexpr int kMulti2Sp = 255;      // definitions.h:37
+constexpr int kMaxMulti2 = 254;     // definitions.h:36
+constexpr int kDollar = 4;          // kSentinelValue, cx1_read2sdbg.h:72
+
+// =================================================================================================
+// 1. logical SdBG edge stream
+// =================================================================================================
+struct Stream {
+    int k = 0, words_per_tip = 0;
+    int64_t n_items_sorted = 0;
+    std::vector<int64_t> bucket_items = std::vector<int64_t>(kBuckets, 0);
+    std::vector<uint16_t> records, large;
+    std::vector<uint32_t> tips;
+};
+
+struct BucketOut {
+    std::vector<uint16_t> records, large;
+    std::vector<uint32_t> tips;
+};
+
+inline int base_at(const uint32_t *packed, uint64_t pos) {   // sequence_package.h:126-129
+    return (packed[pos >> 4] >> (30 - 2 * (pos & 15))) & 3;
+}
+
+// Key of one sort item: `nchars` characters (k or k-1), 2 bits each, left aligned, zero padded;
+// low 4 bits of the last word = (is_full_k<<3)|prev   [cx1_read2sdbg_s2.cpp:586-677, 639-641]
+template <int W>
+inline std::array<uint32_t, W> make_key(const uint8_t *chars, int nchars, int k, int prev) {
+    std::array<uint32_t, W> key{};
+    for (int j = 0; j < nchars; ++j) key[j >> 4] |= uint32_t(chars[j]) << (30 - 2 * (j & 15));
+    key[W - 1] |= uint32_t(nchars == k) << 3;
+    key[W - 1] |= uint32_t(prev);
+    return key;
+}
+
+template <int W>
+inline bool same_km1(const std::array<uint32_t, W> &a, const std::array<uint32_t, W> &b, int k) {
+    // IsDiffKMinusOneMer, cx1_read2sdbg_s2.cpp:54-75
+    int full = (k - 1) / 16, rem = (k - 1) % 16;
+    for (int i = 0; i < full; ++i)
+        if (a[i] != b[i]) return false;
+    if (rem > 0 && (a[full] >> (16 - rem) * 2) != (b[full] >> (16 - rem) * 2)) return false;
+    return true;
+}
+
+template <int W>
+inline int key_a(const std::array<uint32_t, W> &it, int k) {   // Extract_a, s2.cpp:83-94
+    if ((it[W - 1] >> 3) & 1) return (it[(k - 1) / 16] >> (15 - (k - 1) % 16) * 2) & 3;
+    return kDollar;
+}
+template <int W>
+inline int key_b(const std::array<uint32_t, W> &it) { return it[W - 1] & 7; }   // Extract_b, s2.cpp:96-98
+
+// output_(), cx1_read2sdbg_s2.cpp:742-835 + SdbgWriter::write, sdbg_multi_io.h:83-112
+template <int W>
+void emit_bucket(const std::array<uint32_t, W> *it, int64_t n, int k, int words_per_tip, BucketOut &out) {
+    int64_t start = 0;
+    while (start < n) {
+        int64_t end = start + 1;
+        while (end < n && same_km1<W>(it[start], it[end], k)) ++end;
+        int has_solid_a = 0, has_solid_b = 0, outputed_b = 0;
+        int64_t last_a[4] = {-1, -1, -1, -1};
+        for (int64_t i = start; i < end; ++i) {
+            int a = key_a<W>(it[i], k), b = key_b<W>(it[i]);
+            if (a != kDollar && b != kDollar) { has_solid_a |= 1 << a; has_solid_b |= 1 << b; }
+            if (a != kDollar && (b != kDollar || !(has_solid_a & (1 << a)))) last_a[a] = i;
+        }
+        for (int64_t i = start, j; i < end; i = j) {
+            int a = key_a<W>(it[i], k), b = key_b<W>(it[i]);
+            j = i + 1;
+            while (j < end && key_a<W>(it[j], k) == a && key_b<W>(it[j]) == b) ++j;
+            int count = (int)std::min<int64_t>(j - i, kMaxMulti);
+            int is_dollar = 0;
+            if (a == kDollar) {
+                if (has_solid_b & (1 << b)) continue;
+                is_dollar = 1;
+            }
+            if (b == kDollar) {
+                if (has_solid_a & (1 << a)) continue;
+            }
+            int w = (b == kDollar) ? 0 : ((outputed_b & (1 << b)) ? b + 5 : b + 1);
+            int last = (a == kDollar) ? 0 : (last_a[a] == j - 1 ? 1 : 0);
+            outputed_b |= 1 << b;
+            out.records.push_back(uint16_t(w | (last << 4) | (is_dollar << 5) | (std::min(count, kMulti2Sp) << 8)));
+            if (count > kMaxMulti2) out.large.push_back(uint16_t(count));
+            if (is_dollar)
+                for (int t = 0; t < words_per_tip; ++t) out.tips.push_back(it[i][t]);
+        }
+        start = end;
+    }
+}
+
+// Enumerate the sort items of one read (stage 2, every position solid).
+// s2_lv0_calc_bucket_size / s2_lv1_fill_offset / s2_lv2_extract_substr_, cx1_read2sdbg_s2.cpp:252-315,475-677
+template <int W, class F>
+inline void for_each_item(const uint8_t *r, int len, int k, F &&f) {
+    if (len < k + 1) return;                                     // s2.cpp:262-264
+    std::vector<uint8_t> rc(k + 1);
+    for (int p = 0; p + k < len; ++p) {
+        const uint8_t *e = r + p;                                // edge = (k+1)-mer
+        for (int i = 0; i <= k; ++i) rc[i] = 3 - e[k - i];
+        bool pal = std::equal(e, e + k + 1, rc.begin());         // s2.cpp:278
+        bool first = (p == 0), last = (p + k == len - 1);
+        if (first) {                                             // left $   (s2.cpp:531-540)
+            f(make_key<W>(e, k, k, kDollar));
+            if (!pal) f(make_key<W>(rc.data() + 2, k - 1, k, rc[1]));
+        }
+        f(make_key<W>(e + 1, k, k, e[0]));                       // solid    (s2.cpp:543-550)
+        if (!pal) f(make_key<W>(rc.data() + 1, k, k, rc[0]));
+        if (last) {                                              // right $  (s2.cpp:553-562)
+            f(make_key<W>(e + 2, k - 1, k, e[1]));
+            if (!pal) f(make_key<W>(rc.data(), k, k, kDollar));
+        }
+    }
+}
+
+template <int W>
+Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, int k, int n_threads) {
+    using Key = std::array<uint32_t, W>;
+    auto *s = new Stream;
+    s->k = k;
+    s->words_per_tip = (2 * k + 31) / 32;                        // sdbg_multi_io.h:63
+    std::vector<int64_t> cnt(kBuckets + 1, 0);
+    int maxlen = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) maxlen = std::max<int>(maxlen, int(start_idx[r + 1] - start_idx[r]));
+    std::vector<uint8_t> buf(maxlen + 1);
+    auto decode = [&](uint64_t r) {
+        int len = int(start_idx[r + 1] - start_idx[r]);
+        for (int i = 0; i < len; ++i) buf[i] = (uint8_t)base_at(packed, start_idx[r] + i);
+        return len;
+    };
+    // pass 1: bucket sizes (bucket = first 8 characters of the key, s2.cpp:832 `key[0] >> 16`)
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        int len = decode(r);
+        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { ++cnt[(key[0] >> 16) + 1]; });
+    }
+    for (int b = 0; b < kBuckets; ++b) cnt[b + 1] += cnt[b];
+    int64_t total = cnt[kBuckets];
+    s->n_items_sorted = total;
+    std::vector<Key> items((size_t)total);
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    // pass 2: materialise the keys bucket by bucket
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        int len = decode(r);
+        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { items[(size_t)fill[key[0] >> 16]++] = key; });
+    }
+    // per bucket: sort ascending as W big-endian words (lv2_cpu_sort.h:87-150) and emit
+    std::vector<BucketOut> outs(kBuckets);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int b = 0; b < kBuckets; ++b) {
+        int64_t lo = cnt[b], hi = cnt[b + 1];
+        if (lo == hi) continue;
+        std::sort(items.begin() + lo, items.begin() + hi);
+        emit_bucket<W>(items.data() + lo, hi - lo, k, s->words_per_tip, outs[b]);
+    }
+    for (int b = 0; b < kBuckets; ++b) {
+        s->bucket_items[b] = (int64_t)outs[b].records.size();
+        s->records.insert(s->records.end(), outs[b].records.begin(), outs[b].records.end());
+        s->large.insert(s->large.end(), outs[b].large.begin(), outs[b].large.end());
+        s->tips.insert(s->tips.end(), outs[b].tips.begin(), outs[b].tips.end());
+    }
+    return s;
+}
+
+// =================================================================================================
+// 2. succinct de Bruijn graph
+// =================================================================================================
+struct Graph {
+    int64_t size = 0;
+    int k = 0, words_per_tip = 0;
+    int64_t f[6] = {0, 0, 0, 0, 0, 0};
+    int64_t rank_f[6] = {0, 0, 0, 0, 0, 0};
+    int64_t num_tips = 0;
+    std::vector<uint64_t> w, last, tip, invalid, multi1;
+    std::vector<uint32_t> tip_labels;
+    // simple sampled rank directories (layout is ours; only the ANSWERS follow rank_and_select.h)
+    std::vector<int64_t> last_cum;            // ones before 64-bit word i
+    std::vector<int64_t> tip_cum;
+    std::vector<int64_t> w_cum[9];            // occurrences of c before 64-bit word i (16 chars)
+    int64_t w_total[9] = {0};
+    int64_t last_total = 0;
+
+    int W(int64_t x) const { return (w[x >> 4] >> ((x & 15) * 4)) & 15; }                 // succinct_dbg.h:88
+    bool bit(const std::vector<uint64_t> &v, int64_t x) const { return (v[x >> 6] >> (x & 63)) & 1; }
+    bool is_last(int64_t x) const { return bit(last, x); }
+    bool is_tip(int64_t x) const { return bit(tip, x); }
+    bool last_or_tip(int64_t x) const { return ((last[x >> 6] | tip[x >> 6]) >> (x & 63)) & 1; }   // .h:101
+    bool valid(int64_t x) const { return !bit(invalid, x); }
+    bool is_multi1(int64_t x) const { return bit(multi1, x); }
+    int out_label(int64_t x) const { int c = W(x); return c > 4 ? c - 4 : c; }              // .h:92-95
+};
+
+inline int count_sym(uint64_t word, int c) {     // number of 4-bit fields equal to c
+    int n = 0;
+    for (int i = 0; i < 16; ++i) n += int(((word >> (4 * i)) & 15) == (uint64_t)c);
+    return n;
+}
+
+int64_t rank_bits(const std::vector<uint64_t> &v, const std::vector<int64_t> &cum, int64_t total, int64_t size, int64_t pos) {
+    // number of ones in [0..pos]; pos<0 -> 0; pos>=size-1 -> total   (rank_and_select.h:492-495)
+    if (pos < 0) return 0;
+    if (pos >= size - 1) return total;
+    int64_t wi = pos >> 6;
+    int bits = int(pos & 63) + 1;
+    uint64_t mask = bits == 64 ? ~0ULL : ((1ULL << bits) - 1);
+    return cum[wi] + __builtin_popcountll(v[wi] & mask);
+}
+
+int64_t select_bits(const std::vector<uint64_t> &v, const std::vector<int64_t> &cum, int64_t total, int64_t size, int64_t r) {
+    // position of the r-th (0-based) one; `size` if r >= total; -1 if r < 0  (rank_and_select.h:560-568)
+    if (r >= total) return size;
+    if (r < 0) return -1;
+    // last word whose cum <= r
+    int64_t lo = 0, hi = (int64_t)v.size() - 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) >> 1;
+        if (cum[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    uint64_t word = v[lo];
+    int64_t rem = r - cum[lo];
+    for (int64_t i = 0; i < rem; ++i) word &= word - 1;
+    return lo * 64 + __builtin_ctzll(word);
+}
+
+int64_t g_rank_last(const Graph &g, int64_t pos) { return rank_bits(g.last, g.last_cum, g.last_total, g.size, pos); }
+int64_t g_select_last(const Graph &g, int64_t r) { return select_bits(g.last, g.last_cum, g.last_total, g.size, r); }
+
+int64_t g_rank_w(const Graph &g, int c, int64_t pos) {   // rank_and_select.h:153-157
+    if (pos < 0) return 0;
+    if (pos >= g.size - 1) return g.w_total[c];
+    int64_t wi = pos >> 4;
+    int n = int(pos & 15) + 1;
+    int64_t r = g.w_cum[c][wi];
+    uint64_t word = g.w[wi];
+    for (int i = 0; i < n; ++i) r += int(((word >> (4 * i)) & 15) == (uint64_t)c);
+    return r;
+}
+
+int64_t g_select_w(const Graph &g, int c, int64_t r) {   // rank_and_select.h:220-227
+    if (r >= g.w_total[c]) return g.size;
+    if (r < 0) return -1;
+    const auto &cum = g.w_cum[c];
+    int64_t lo = 0, hi = (int64_t)g.w.size() - 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi + 1) >> 1;
+        if (cum[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    int64_t rem = r - cum[lo];
+    uint64_t word = g.w[lo];
+    for (int i = 0; i < 16; ++i)
+        if (((word >> (4 * i)) & 15) == (uint64_t)c) {
+            if (rem == 0) return lo * 16 + i;
+            --rem;
+        }
+    return g.size;
+}
+
+int node_last_char(const Graph &g, int64_t x) {   // GetNodeLastChar, succinct_dbg.h:109-115
+    for (int i = 1;; ++i)
+        if (g.f[i] > x) return i - 1;
+}
+
+int64_t g_forward(const Graph &g, int64_t e) {    // succinct_dbg.h:155-164
+    int a = g.out_label(e);
+    int64_t count_a = g_rank_w(g, a, e);
+    return g_select_last(g, g.rank_f[a] + count_a - 1);
+}
+
+int64_t g_backward(const Graph &g, int64_t e) {   // succinct_dbg.h:166-170
+    int a = node_last_char(g, e);
+    int64_t count_a = g_rank_last(g, e - 1) - g.rank_f[a];
+    return g_select_w(g, a, count_a);
+}
+
+int g_outgoing(const Graph &g, int64_t e, int64_t *out) {   // succinct_dbg.cpp:78-97
+    if (!g.valid(e)) return -1;
+    int od = 0;
+    int64_t nx = g_forward(g, e);
+    do {
+        if (g.valid(nx)) out[od++] = nx;
+        --nx;
+    } while (nx >= 0 && !g.last_or_tip(nx));
+    return od;
+}
+
+int g_incoming(const Graph &g, int64_t e, int64_t *in) {    // succinct_dbg.cpp:99-127
+    if (!g.valid(e)) return -1;
+    int64_t first = g_backward(g, e);
+    int c = g.W(first);
+    int ones = g.last_or_tip(first);
+    int id = g.valid(first);
+    if (id > 0) in[0] = first;
+    for (int64_t y = first + 1; ones < 5 && y < g.size; ++y) {
+        ones += g.last_or_tip(y);
+        int cur = g.W(y);
+        if (cur == c) break;
+        if (cur == c + 4 && g.valid(y)) in[id++] = y;
+    }
+    return id;
+}
+
+inline int tip_char(const Graph &g, int64_t tip_rank, int j) {
+    const uint32_t *t = g.tip_labels.data() + (size_t)g.words_per_tip * tip_rank;
+    return (t[j >> 4] >> (15 - (j & 15)) * 2) & 3;
+}
+
+int g_label(const Graph &g, int64_t e, uint8_t *seq) {      // succinct_dbg.cpp:503-528
+    int64_t x = e;
+    for (int i = g.k - 1; i >= 0; --i) {
+        if (g.is_tip(x)) {
+            int64_t tr = rank_bits(g.tip, g.tip_cum, g.num_tips, g.size, x) - 1;
+            for (int j = 0; j <= i; ++j) seq[i - j] = uint8_t(tip_char(g, tr, j) + 1);
+            break;
+        }
+        x = g_backward(g, x);
+        int c = g.W(x);
+        seq[i] = uint8_t(c > 4 ? c - 4 : c);
+    }
+    return g.k;
+}
+
+int64_t g_index_node(const Graph &g, const uint8_t *seq) {  // IndexBinarySearch, succinct_dbg.cpp:427-501
+    int k = g.k;
+    int64_t l = g.f[seq[k - 1]], r = g.f[seq[k - 1] + 1] - 1;
+    while (l <= r) {
+        int cmp = 0;
+        int64_t mid = (l + r) / 2, y = mid;
+        for (int i = k - 1; i >= 0; --i) {
+            if (g.is_tip(y)) {
+                int64_t tr = rank_bits(g.tip, g.tip_cum, g.num_tips, g.size, y) - 1;
+                for (int j = 0; j < i; ++j) {
+                    int c = tip_char(g, tr, j) + 1;
+                    if (c < seq[i - j]) { cmp = -1; break; }
+                    if (c > seq[i - j]) { cmp = 1; break; }
+                }
+                if (cmp == 0) {
+                    if (g.is_tip(mid)) cmp = -1;                       // :455-457 (a tip never matches)
+                    else {
+                        int c = tip_char(g, tr, i) + 1;
+                        if (c < seq[0]) cmp = -1;
+                        else if (c > seq[0]) cmp = 1;
+                    }
+                }
+                break;
+            }
+            y = g_backward(g, y);
+            int c = g.W(y);
+            if (c < seq[i]) { cmp = -1; break; }
+            if (c > seq[i]) { cmp = 1; break; }
+        }
+        if (cmp == 0) {                                                // GetLastIndex = rs_last_.Succ(mid)
+            int64_t p = mid;
+            while (p < g.size && !g.is_last(p)) ++p;
+            return p;
+        }
+        if (cmp > 0) r = mid - 1; else l = mid + 1;
+    }
+    return -1;
+}
+
+int64_t g_index_edge(const Graph &g, const uint8_t *seq) {  // IndexBinarySearchEdge, succinct_dbg.cpp:530-549
+    int64_t node = g_index_node(g, seq);
+    if (node == -1) return -1;
+    do {
+        int lab = g.W(node);
+        if (lab == seq[g.k] || lab - 4 == seq[g.k]) return node;
+        --node;
+    } while (node >= 0 && !g.last_or_tip(node));
+    return -1;
+}
+
+Graph *graph_from_stream(const Stream &s) {                   // LoadFromMultiFile(prefix,false), succinct_dbg.cpp:595-723
+    auto *g = new Graph;
+    g->k = s.k;
+    g->words_per_tip = s.words_per_tip;
+    int64_t n = (int64_t)s.records.size();
+    g->size = n;
+    // f_: sdbg_multi_io.h:254-268
+    g->f[0] = -1; g->f[1] = 0;
+    int64_t acc = 0;
+    for (int b = 0; b < kBuckets; ++b) { acc += s.bucket_items[b]; g->f[b / (kBuckets / 4) + 2] = acc; }
+    size_t nw4 = (size_t)((n + 15) / 16), nw1 = (size_t)((n + 63) / 64);
+    g->w.assign(nw4 + 1, 0); g->last.assign(nw1 + 1, 0); g->tip.assign(nw1 + 1, 0); g->multi1.assign(nw1 + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        uint16_t it = s.records[(size_t)i];
+        g->w[i >> 4] |= uint64_t(it & 15) << ((i & 15) * 4);
+        g->last[i >> 6] |= uint64_t((it >> 4) & 1) << (i & 63);
+        g->tip[i >> 6] |= uint64_t((it >> 5) & 1) << (i & 63);
+        g->multi1[i >> 6] |= uint64_t((it >> 8) <= 1) << (i & 63);         // :680
+    }
+    g->tip_labels = s.tips;
+    g->num_tips = s.words_per_tip ? (int64_t)s.tips.size() / s.words_per_tip : 0;
+    g->invalid = g->tip;                                                     // :717
+    for (int64_t i = 0; i < n; ++i)
+        if (g->W(i) == 0) g->invalid[i >> 6] |= 1ULL << (i & 63);           // init(), succinct_dbg.h:81-85
+    // rank directories
+    g->last_cum.assign(g->last.size() + 1, 0); g->tip_cum.assign(g->tip.size() + 1, 0);
+    for (size_t i = 0; i < g->last.size(); ++i) {
+        g->last_cum[i + 1] = g->last_cum[i] + __builtin_popcountll(g->last[i]);
+        g->tip_cum[i + 1] = g->tip_cum[i] + __builtin_popcountll(g->tip[i]);
+    }
+    g->last_total = g->last_cum[g->last.size()];
+    for (int c = 0; c < 9; ++c) {
+        g->w_cum[c].assign(g->w.size() + 1, 0);
+        for (size_t i = 0; i < g->w.size(); ++i) {
+            int cnt = count_sym(g->w[i], c);
+            if (c == 0) {   // padding fields beyond `size` read as 0: do not count them
+                int64_t base = (int64_t)i * 16;
+                if (base + 16 > n) cnt -= int(std::min<int64_t>(16, base + 16 - std::max<int64_t>(n, base)));
+            }
+            g->w_cum[c][i + 1] = g->w_cum[c][i] + cnt;
+        }
+        g->w_total[c] = g->w_cum[c][g->w.size()];
+    }
+    for (int i = 0; i < 6; ++i) g->rank_f[i] = g_rank_last(*g, g->f[i] - 1);   // succinct_dbg.h:74-76
+    return g;
+}
+
+// =================================================================================================
+// 3. profile HMM (HMMER3 text) + A* heuristic
+// =================================================================================================
+constexpr double NEG_INF = -std::numeric_limits<double>::infinity();
+enum { MM = 0, MI = 1, MD = 2, IM = 3, II = 4, DM = 5, DD = 6 };   // profile_hmm.h:25
+
+struct Hmm {
+    int M = 0, A = 0;
+    std::vector<double> msc, isc, tsc, maxm, h, compo;
+    int alpha[127];
+    double m(int k, int j) const { return k == 0 ? NEG_INF : msc[(size_t)k * A + j]; }   // profile_hmm.h:58-64
+    double t(int k, int tr) const { return tsc[(size_t)tr * (M + 1) + k]; }
+    double hc(int st, int k) const { return h[(size_t)st * (M + 1) + k]; }
+};
+
+double parse_p(const std::string &tok) { return tok == "*" ? 0.0 : std::exp(-1 * std::stod(tok)); }  // hmmer3b_parser.h:111-116
+
+double heuristic_from(const Hmm &hm, char pre, int state_no) {    // computeCostInternal, most_probable_path.h:48-118
+    double h = 0;
+    for (int i = state_no + 1; i <= hm.M; i++) {
+        double mt, it, dt;
+        switch (pre) {
+        case 'm': mt = hm.t(i - 1, MM); it = hm.t(i - 1, MI); dt = hm.t(i - 1, MD); break;
+        case 'd': mt = hm.t(i - 1, DM); it = NEG_INF; dt = hm.t(i - 1, DD); break;
+        default:  mt = hm.t(i - 1, IM); it = hm.t(i - 1, II); dt = NEG_INF; break;
+        }
+        double best_m = NEG_INF, best_i = NEG_INF;
+        for (int j = 0; j < hm.A; ++j) {
+            best_m = std::max(best_m, hm.m(i, j));
+            best_i = std::max(best_i, hm.isc[(size_t)i * hm.A + j]);
+        }
+        mt += best_m - hm.maxm[i];
+        dt -= hm.maxm[i];
+        it += best_i;
+        it = NEG_INF;                                               // :100 (insert branch disabled)
+        if (it > mt && it > dt) { h += it; pre = 'i'; i--; }
+        else if (dt > mt && dt > it) { h += dt; pre = 'd'; }
+        else { h += mt; pre = 'm'; }
+    }
+    return h;
+}
+
+Hmm *parse_hmm(const char *path) {                                   // Parser::readHMM, hmmer3b_parser.h:19-177
+    std::ifstream f(path);
+    if (!f.is_open()) return nullptr;
+    auto *hm = new Hmm;
+    std::fill(hm->alpha, hm->alpha + 127, -1);
+    std::string line, w1, w2;
+    std::getline(f, line);                                            // version line
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        w1.clear(); w2.clear();
+        iss >> w1 >> w2;
+        if (w1 == "LENG") hm->M = std::stoi(w2);
+        else if (w1 == "HMM") {                                       // parseAlpha, :179-201
+            std::istringstream a(line);
+            std::string tok;
+            a >> tok;
+            int count = 0;
+            while (a >> tok) {
+                hm->alpha[toupper(tok[0])] = count;
+                hm->alpha[tolower(tok[0])] = count;
+                ++count;
+            }
+            hm->A = count;
+            break;
+        }
+    }
+    std::getline(f, line);                                            // transition labels
+    std::getline(f, line);                                            // COMPO
+    {
+        std::istringstream iss(line);
+        std::string tag, tok;
+        iss >> tag;
+        if (tag == "COMPO")
+            for (int j = 0; j < hm->A; ++j) { iss >> tok; hm->compo.push_back(std::exp(-1 * std::stod(tok))); }
+    }
+    int M = hm->M, A = hm->A;
+    hm->msc.assign((size_t)(M + 1) * A, 0.0);
+    hm->isc.assign((size_t)(M + 1) * A, 0.0);
+    hm->tsc.assign((size_t)7 * (M + 1), 0.0);
+    hm->maxm.assign(M + 1, NEG_INF);
+    for (int i = 0; i <= M; ++i) {
+        std::string tok;
+        if (i > 0) {
+            std::getline(f, line);
+            std::istringstream iss(line);
+            iss >> tok;                                               // node number
+            for (int j = 0; j < A; ++j) {
+                iss >> tok;
+                double v = std::log(parse_p(tok) / hm->compo[j]);     // normalized, :122-124
+                hm->msc[(size_t)i * A + j] = v;
+                if (v > hm->maxm[i]) hm->maxm[i] = v;                 // profile_hmm.h:72-78
+            }
+        }
+        std::getline(f, line);                                        // insert emissions: 0 when normalized (:145-147)
+        std::getline(f, line);                                        // transitions
+        std::istringstream iss(line);
+        for (int t = 0; t < 7; ++t) { iss >> tok; hm->tsc[(size_t)t * (M + 1) + i] = std::log(parse_p(tok)); }
+    }
+    for (int j = 0; j < A; ++j) hm->isc[(size_t)M * A + j] = NEG_INF; // :170-172
+    hm->h.assign((size_t)3 * (M + 1), 0.0);
+    for (int i = 0; i <= M; ++i) {
+        hm->h[i] = heuristic_from(*hm, 'm', i);
+        hm->h[(size_t)(M + 1) + i] = heuristic_from(*hm, 'i', i);
+        hm->h[(size_t)2 * (M + 1) + i] = heuristic_from(*hm, 'd', i);
+    }
+    return hm;
+}
+
+// =================================================================================================
+// 4. HMM-guided A*
+// =================================================================================================
+const char kCodon[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";   // codon.h:9-106
+
+inline char codon_fwd(int c1, int c2, int c3) { return kCodon[c1 * 16 + c2 * 4 + c3]; }
+inline char codon_rc(int c1, int c2, int c3) { return kCodon[(3 - c3) * 16 + (3 - c2) * 4 + (3 - c1)]; }  // codon.h:108-209
+
+struct Node {                               // AStarNode, a_star_node.h:9-33
+    Node *from = nullptr;
+    int nucl_emission = 0;
+    double score = 0, real_score = 0, max_score = 0;
+    int state_no = 0;
+    char state = 'm';
+    int fval = 0, indels = 0, length = 0, negative_count = 0;
+    int64_t node_id = -1;
+};
+
+inline int srank(char s) { return s == 'm' ? 3 : s == 'd' ? 2 : s == 'i' ? 1 : 0; }
+inline bool node_less(const Node &a, const Node &b) {   // AStarNode::operator<, a_star_node.h:34-82
+    if (a.fval != b.fval) return a.fval < b.fval;
+    if (a.state_no != b.state_no) return a.state_no > b.state_no;
+    return srank(a.state) < srank(b.state);
+}
+struct PtrLess { bool operator()(const Node *a, const Node *b) const { return node_less(*a, *b); } };
+
+struct Key {
+    int64_t node_id; int state_no; char state;
+    bool operator==(const Key &o) const { return node_id == o.node_id && state_no == o.state_no && state == o.state; }
+};
+struct KeyHash {
+    size_t operator()(const Key &k) const {
+        uint64_t h = (uint64_t)k.node_id * 0x9E3779B97F4A7C15ULL ^ ((uint64_t)k.state_no << 8) ^ (uint64_t)k.state;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+        return (size_t)h;
+    }
+};
+inline Key key_of(const Node &n) { return Key{n.node_id, n.state_no, n.state}; }
+
+inline int to_fval(double x) {     // (int) cast of a double; x86 cvttsd2si yields INT_MIN when out of range / NaN
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return std::numeric_limits<int>::min();
+    return (int)x;
+}
+
+using Cache = std::unordered_map<Key, Key, KeyHash>;   // term_nodes: parent key -> child key, first insert wins
+
+struct Searcher {
+    const Graph *g;
+    const Hmm *hm[2];     // 0 = forward model, 1 = reverse model
+    int prune;
+    double low_cov_penalty;                                 // -log(low_cov_pen), node_enumerator.h:42
+    double exit_prob[3000];                                 // hmm_graph_search.h:48-52
+    Cache cache[2];
+    std::vector<Node *> pool;
+    Node *alloc() { pool.push_back(new Node); return pool.back(); }
+    void release() { for (Node *n : pool) delete n; pool.clear(); }
+};
+
+// NodeEnumerator::enumerateNodes, node_enumerator.h:65-246
+void enumerate(const Searcher &S, const Hmm &hm, Node &curr, bool forward, const Key *child, std::vector<Node> &ret) {
+    ret.clear();
+    int next_state = curr.state_no + 1;
+    double mt, it, dt;
+    switch (curr.state) {
+    case 'm': mt = hm.t(curr.state_no, MM); it = hm.t(curr.state_no, MI); dt = hm.t(curr.state_no, MD); break;
+    case 'd': mt = hm.t(curr.state_no, DM); it = NEG_INF; dt = hm.t(curr.state_no, DD); break;
+    default:  mt = hm.t(curr.state_no, IM); it = hm.t(curr.state_no, II); dt = NEG_INF; break;
+    }
+    double max_match = hm.maxm[next_state];
+    if (curr.node_id == -1) return;
+    const Graph &g = *S.g;
+    int64_t n1[4], n2[4], n3[4];
+    std::vector<int64_t> packed;
+    int od1 = g_outgoing(g, curr.node_id, n1);
+    for (int i = 0; i < od1; ++i) {
+        int od2 = g_outgoing(g, n1[i], n2);
+        for (int j = 0; j < od2; ++j) {
+            int od3 = g_outgoing(g, n2[j], n3);
+            for (int k = 0; k < od3; ++k) {
+                int64_t p = (n3[k] << 16) | ((g.out_label(n1[i]) - 1) << 6) | ((g.out_label(n2[j]) - 1) << 3) |
+                            (g.out_label(n3[k]) - 1);
+                p |= int64_t(g.is_multi1(n1[i]) && g.is_multi1(n2[j]) && g.is_multi1(n3[k])) << 9;
+                packed.push_back(p);        // the low-coverage-sibling flag (bit 10) is set after the push: never used (:119-125)
+            }
+        }
+    }
+    for (int64_t p : packed) {
+        int c1 = (p >> 6) & 7, c2 = (p >> 3) & 7, c3 = p & 7;
+        char em = forward ? codon_fwd(c1, c2, c3) : codon_rc(c1, c2, c3);
+        if (em == '*') continue;
+        if (child && child->node_id != (p >> 16)) continue;
+        double pen = (p & (1 << 9)) ? S.low_cov_penalty : 0;
+        int aa = hm.alpha[(int)em];
+        Node nx;
+        nx.from = &curr; nx.state_no = next_state; nx.state = 'm';
+        double e = mt + hm.msc[(size_t)next_state * hm.A + aa];
+        nx.real_score = curr.real_score + e - pen;
+        if (nx.real_score >= curr.max_score) { nx.max_score = nx.real_score; nx.negative_count = 0; }
+        else { nx.max_score = curr.max_score; nx.negative_count = curr.negative_count + 1; }
+        nx.nucl_emission = int(p & 511);
+        double self = e - pen - max_match;
+        nx.length = curr.length + 1;
+        nx.score = curr.score + self;
+        nx.fval = to_fval(10000 * (nx.score + 2.0 * hm.hc(0, next_state)));
+        nx.indels = curr.indels;
+        nx.node_id = p >> 16;
+        ret.push_back(nx);
+        if (child && *child == key_of(nx)) return;
+        if (curr.state != 'd') {
+            Node ni;
+            ni.from = &curr; ni.state_no = curr.state_no; ni.state = 'i';
+            double ei = it + hm.isc[(size_t)next_state * hm.A + aa];
+            ni.real_score = curr.real_score + ei - pen;
+            ni.max_score = curr.max_score;
+            ni.negative_count = curr.negative_count + 1;
+            ni.nucl_emission = int(p & 511);
+            ni.length = curr.length + 1;
+            ni.score = curr.score + (ei - pen);
+            ni.fval = to_fval(10000 * (ni.score + 2.0 * hm.hc(1, curr.state_no)));
+            ni.indels = curr.indels + 1;
+            ni.node_id = p >> 16;
+            ret.push_back(ni);
+            if (child && *child == key_of(ni)) return;
+        }
+    }
+    if (curr.state != 'i') {
+        Node nd;
+        nd.from = &curr; nd.state_no = next_state; nd.state = 'd';
+        nd.real_score = curr.real_score + dt;
+        nd.max_score = curr.max_score;
+        nd.negative_count = curr.negative_count + 1;
+        nd.nucl_emission = (4 << 6) | (4 << 3) | 4;
+        nd.length = curr.length;
+        nd.score = curr.score + (dt - max_match);
+        nd.fval = to_fval(10000 * (nd.score + 2.0 * hm.hc(2, next_state)));
+        nd.indels = curr.indels + 1;
+        nd.node_id = curr.node_id;
+        ret.push_back(nd);
+    }
+}
+
+struct AstarOut { bool ok = false; Node goal; bool has_goal = false; int partial = 0; int64_t closed = 0, expanded = 0, opened = 0; };
+
+// getHighestScoreNode, hmm_graph_search.h:345-356.  Returns the pool node chosen.
+Node *highest_score(Node *inter) {
+    Node *best = inter;
+    for (Node *p = inter->from; p; p = p->from)
+        if (p->real_score > best->real_score) best = p;
+    return best;
+}
+
+// astarSearch (core loop), hmm_graph_search.h:191-343
+Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache, AstarOut &out) {
+    out = AstarOut();
+    if (start->state_no >= hm.M) { out.ok = true; return start; }           // :193-197
+    static const double log2v = std::log(2);
+    std::priority_queue<Node *, std::vector<Node *>, PtrLess> open;
+    std::unordered_set<Key, KeyHash> closed;
+    std::unordered_map<Key, Node *, KeyHash> open_hash;
+    std::vector<Node> kids;
+    auto cached_child = [&](const Node &n) -> const Key * {
+        auto it = cache.find(key_of(n));
+        return it == cache.end() ? nullptr : &it->second;
+    };
+    enumerate(S, hm, *start, forward, cached_child(*start), kids);         // :212-233: no pruning / dedup here
+    if (start->node_id != -1) out.expanded++;
+    for (Node &nx : kids) { Node *p = S.alloc(); *p = nx; open.push(p); }
+    out.opened = 1;
+    if (open.empty()) { out.ok = false; return nullptr; }                  // :235-237
+    Node *inter = start;
+    auto better = [&](const Node &a, const Node &b) {
+        return (a.real_score + S.exit_prob[a.length]) / log2v > (b.real_score + S.exit_prob[b.length]) / log2v;
+    };
+    while (!open.empty()) {
+        Node *curr = open.top();
+        open.pop();
+        if (closed.count(key_of(*curr))) continue;                         // :254
+        if (curr->state_no >= hm.M) {                                      // :259-270
+            if (better(*curr, *inter)) inter = curr;
+            out.ok = true;
+            return highest_score(inter);
+        }
+        closed.insert(key_of(*curr));
+        out.closed++;
+        if (better(*curr, *inter)) inter = curr;                           // :274-277
+        enumerate(S, hm, *curr, forward, cached_child(*curr), kids);
+        out.expanded++;
+        for (Node &nx : kids) {
+            bool open_node = false;
+            bool admissible = S.prune > 0 ? ((nx.length < 5 || nx.negative_count <= S.prune) && nx.real_score > 0.0) : true;  // :292-293
+            if (admissible) {
+                auto got = open_hash.find(key_of(nx));
+                if (got != open_hash.end()) { if (node_less(*got->second, nx)) open_node = true; }   // :299-302
+                else open_node = true;
+            }
+            if (open_node) {
+                Node *p = S.alloc();
+                *p = nx;
+                open_hash[key_of(nx)] = p;                                 // :331
+                out.opened++;
+                open.push(p);
+            }
+        }
+    }
+    out.partial = 1;                                                       // :339
+    out.ok = true;
+    return highest_score(inter);
+}
+
+// partialResultFromGoal, hmm_graph_search.h:83-110
+std::string path_string(Node *goal, Cache &cache) {
+    std::string s;
+    for (Node *p = goal; p && p->from; p = p->from) {
+        if (p->state != 'd')
+            for (int i = 0; i < 3; ++i) s.push_back("acgt-"[(p->nucl_emission >> (3 * i)) & 7]);
+        cache.emplace(key_of(*p->from), key_of(*p));                        // insert keeps the first (hash_table_st.h:309-331)
+    }
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+inline char comp(char c) {   // hmm_graph_search.h:362-389
+    switch (c) {
+    case 'a': case 'A': return 't';
+    case 'c': case 'C': return 'g';
+    case 'g': case 'G': return 'c';
+    case 't': case 'T': return 'a';
+    case 'n': case 'N': return 'n';
+    default: return '-';
+    }
+}
+std::string revcomp(std::string s) {
+    std::reverse(s.begin(), s.end());
+    for (auto &c : s) c = comp(c);
+    return s;
+}
+inline int dna_sym(char c) {  // dna_map, hmm_graph_search.h:54-58  (N -> 3 i.e. G)
+    switch (c) {
+    case 'A': case 'a': return 1;
+    case 'C': case 'c': return 2;
+    case 'G': case 'g': case 'N': case 'n': return 3;
+    case 'T': case 't': return 4;
+    default: return -1;
+    }
+}
+
+// astarSearch (start-node set-up), hmm_graph_search.h:132-189
+Node *astar_from_kmer(Searcher &S, int dir, int starting_state, const std::string &kmer, AstarOut &out) {
+    const Hmm &hm = *S.hm[dir];
+    bool forward = dir == 0;
+    int k = S.g->k;
+    // protein of the k-mer (libseq translation == standard table), reversed for the left search
+    std::string prot;
+    for (size_t i = 0; i + 2 < kmer.size() && i / 3 < kmer.size() / 3; i += 3)
+        prot.push_back(codon_fwd(dna_sym(kmer[i]) - 1, dna_sym(kmer[i + 1]) - 1, dna_sym(kmer[i + 2]) - 1));
+    if (!forward) std::reverse(prot.begin(), prot.end());
+    std::string word = forward ? kmer : revcomp(kmer);
+    std::vector<uint8_t> seq(k + 1);
+    for (int i = 0; i < k + 1; ++i) seq[i] = (uint8_t)dna_sym(word[i]);
+    Node *st = S.alloc();
+    st->from = nullptr;
+    st->state_no = starting_state + int(kmer.size() / 3);
+    st->state = 'm';
+    st->length = int(kmer.size() / 3);
+    st->fval = 0;
+    double sc = 0, rs = 0;                                                   // scoreStart / realScoreStart, :112-130
+    for (int i = 1; i <= (int)prot.size(); ++i) {
+        int aa = hm.alpha[(int)prot[i - 1]];
+        sc += hm.msc[(size_t)(starting_state + i) * hm.A + aa] + hm.t(starting_state + i - 1, MM) - hm.maxm[starting_state + i];
+        rs += hm.msc[(size_t)(starting_state + i) * hm.A + aa] + hm.t(starting_state + i - 1, MM);
+    }
+    st->score = sc;
+    st->real_score = rs;
+    st->node_id = g_index_edge(*S.g, seq.data());
+    return astar(S, hm, st, forward, S.cache[dir], out);
+}
+
+void fill_result(orc_astar_result *r, const AstarOut &o, const Node *goal) {
+    if (!r) return;
+    std::memset(r, 0, sizeof(*r));
+    r->ok = o.ok; r->partial = o.partial;
+    r->n_closed = o.closed; r->n_expanded = o.expanded; r->n_opened = o.opened;
+    r->state = '-'; r->state_no = -1; r->node_id = -1;
+    if (goal) {
+        r->fval = goal->fval; r->length = goal->length; r->state_no = goal->state_no; r->state = goal->state;
+        r->node_id = goal->node_id; r->real_score = goal->real_score; r->score = goal->score;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+struct orc_stream : Stream {};
+struct orc_graph : Graph {};
+struct orc_hmm : Hmm {};
+struct orc_searcher : Searcher {};
+
+extern "C" {
+
+orc_stream *orc_sdbg_build(const uint32_t *packed, uint64_t n_words, const uint64_t *start_idx, uint64_t n_reads, int k,
+                           int n_threads) {
+    (void)n_words;
+    if (k < 9 || k > 127) return nullptr;
+    int W = (2 * k + 4 + 31) / 32;                                 // words_per_substring, s2.cpp:331
+    Stream *s = nullptr;
+    switch (W) {
+    case 1: s = build_stream<1>(packed, start_idx, n_reads, k, n_threads); break;
+    case 2: s = build_stream<2>(packed, start_idx, n_reads, k, n_threads); break;
+    case 3: s = build_stream<3>(packed, start_idx, n_reads, k, n_threads); break;
+    case 4: s = build_stream<4>(packed, start_idx, n_reads, k, n_threads); break;
+    case 5: s = build_stream<5>(packed, start_idx, n_reads, k, n_threads); break;
+    case 6: s = build_stream<6>(packed, start_idx, n_reads, k, n_threads); break;
+    case 7: s = build_stream<7>(packed, start_idx, n_reads, k, n_threads); break;
+    case 8: s = build_stream<8>(packed, start_idx, n_reads, k, n_threads); break;
+    default: s = build_stream<9>(packed, start_idx, n_reads, k, n_threads); break;
+    }
+    return static_cast<orc_stream *>(s);
+}
+
+orc_stream *orc_sdbg_read(const char *prefix) {                    // SdbgReader, sdbg_multi_io.h:240-382
+    std::string p(prefix);
+    FILE *info = fopen((p + ".sdbg_info").c_str(), "r");
+    if (!info) return nullptr;
+    auto *s = new orc_stream;
+    int nb = 0, nf = 0;
+    long long total = 0, ntips = 0, nlarge = 0;
+    bool ok = fscanf(info, "k %d\n", &s->k) == 1 && fscanf(info, "words_per_tip_label %d\n", &s->words_per_tip) == 1 &&
+              fscanf(info, "num_buckets %d\n", &nb) == 1 && fscanf(info, "num_threads %d\n", &nf) == 1 &&
+              fscanf(info, "total_size %lld\n", &total) == 1 && fscanf(info, "num_tips %lld\n", &ntips) == 1 &&
+              fscanf(info, "large_multi %lld\n", &nlarge) == 1 && nb == kBuckets;
+    if (!ok) { fclose(info); delete s; return nullptr; }
+    struct Rec { int tid; long long off, items, tips, large; };
+    std::vector<Rec> recs(nb);
+    for (int b = 0; b < nb; ++b) {
+        int dummy;
+        if (fscanf(info, "%d %d %lld %lld %lld %lld\n", &dummy, &recs[b].tid, &recs[b].off, &recs[b].items, &recs[b].tips,
+                   &recs[b].large) != 6) { fclose(info); delete s; return nullptr; }
+    }
+    fclose(info);
+    std::vector<std::vector<unsigned char>> files(nf);
+    for (int t = 0; t < nf; ++t) {
+        std::ifstream f(p + ".sdbg." + std::to_string(t), std::ios::binary);
+        if (!f.is_open()) { delete s; return nullptr; }
+        files[t].assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    for (int b = 0; b < nb; ++b) {
+        s->bucket_items[b] = recs[b].items;
+        if (recs[b].tid < 0) continue;
+        const unsigned char *ptr = files[recs[b].tid].data() + recs[b].off;
+        for (long long i = 0; i < recs[b].items; ++i) {
+            uint16_t it;
+            memcpy(&it, ptr, 2); ptr += 2;
+            s->records.push_back(it);
+            if ((it >> 8) == kMulti2Sp) { uint16_t m; memcpy(&m, ptr, 2); ptr += 2; s->large.push_back(m); }   // :367-371
+            if ((it >> 5) & 1) {
+                for (int t = 0; t < s->words_per_tip; ++t) { uint32_t w; memcpy(&w, ptr, 4); ptr += 4; s->tips.push_back(w); }
+            }
+        }
+    }
+    if ((long long)s->records.size() != total) { delete s; return nullptr; }
+    return s;
+}
+
+void orc_stream_free(orc_stream *s) { delete s; }
+int orc_stream_k(const orc_stream *s) { return s->k; }
+int orc_stream_words_per_tip(const orc_stream *s) { return s->words_per_tip; }
+int64_t orc_stream_num_edges(const orc_stream *s) { return (int64_t)s->records.size(); }
+int64_t orc_stream_num_tips(const orc_stream *s) { return s->words_per_tip ? (int64_t)s->tips.size() / s->words_per_tip : 0; }
+int64_t orc_stream_num_large(const orc_stream *s) { return (int64_t)s->large.size(); }
+int64_t orc_stream_num_items_sorted(const orc_stream *s) { return s->n_items_sorted; }
+const int64_t *orc_stream_bucket_items(const orc_stream *s) { return s->bucket_items.data(); }
+const uint16_t *orc_stream_records(const orc_stream *s) { return s->records.data(); }
+const uint16_t *orc_stream_large(const orc_stream *s) { return s->large.data(); }
+const uint32_t *orc_stream_tips(const orc_stream *s) { return s->tips.data(); }
+
+orc_graph *orc_graph_from_stream(const orc_stream *s) { return static_cast<orc_graph *>(graph_from_stream(*s)); }
+void orc_graph_free(orc_graph *g) { delete g; }
+int64_t orc_graph_size(const orc_graph *g) { return g->size; }
+int orc_graph_k(const orc_graph *g) { return g->k; }
+const int64_t *orc_graph_f(const orc_graph *g) { return g->f; }
+const uint64_t *orc_graph_w(const orc_graph *g) { return g->w.data(); }
+const uint64_t *orc_graph_last(const orc_graph *g) { return g->last.data(); }
+const uint64_t *orc_graph_tip(const orc_graph *g) { return g->tip.data(); }
+const uint64_t *orc_graph_invalid(const orc_graph *g) { return g->invalid.data(); }
+const uint64_t *orc_graph_multi1(const orc_graph *g) { return g->multi1.data(); }
+const uint32_t *orc_graph_tip_labels(const orc_graph *g) { return g->tip_labels.data(); }
+int64_t orc_graph_num_tips(const orc_graph *g) { return g->num_tips; }
+int64_t orc_rank_last(const orc_graph *g, int64_t pos) { return g_rank_last(*g, pos); }
+int64_t orc_select_last(const orc_graph *g, int64_t r) { return g_select_last(*g, r); }
+int64_t orc_rank_w(const orc_graph *g, int c, int64_t pos) { return g_rank_w(*g, c, pos); }
+int64_t orc_select_w(const orc_graph *g, int c, int64_t r) { return g_select_w(*g, c, r); }
+int64_t orc_forward(const orc_graph *g, int64_t e) { return g_forward(*g, e); }
+int64_t orc_backward(const orc_graph *g, int64_t e) { return g_backward(*g, e); }
+int orc_outgoing(const orc_graph *g, int64_t e, int64_t out[4]) { return g_outgoing(*g, e, out); }
+int orc_incoming(const orc_graph *g, int64_t e, int64_t in[4]) { return g_incoming(*g, e, in); }
+int orc_label(const orc_graph *g, int64_t e, uint8_t *seq) { return g_label(*g, e, seq); }
+int64_t orc_index_edge(const orc_graph *g, const uint8_t *seq) { return g_index_edge(*g, seq); }
+
+orc_hmm *orc_hmm_parse(const char *path) { return static_cast<orc_hmm *>(parse_hmm(path)); }
+void orc_hmm_free(orc_hmm *h) { delete h; }
+int orc_hmm_M(const orc_hmm *h) { return h->M; }
+int orc_hmm_A(const orc_hmm *h) { return h->A; }
+const double *orc_hmm_msc(const orc_hmm *h) { return h->msc.data(); }
+const double *orc_hmm_isc(const orc_hmm *h) { return h->isc.data(); }
+const double *orc_hmm_tsc(const orc_hmm *h) { return h->tsc.data(); }
+const double *orc_hmm_maxm(const orc_hmm *h) { return h->maxm.data(); }
+const double *orc_hmm_h(const orc_hmm *h) { return h->h.data(); }
+const int *orc_hmm_alpha(const orc_hmm *h) { return h->alpha; }
+
+orc_searcher *orc_searcher_new(const orc_graph *g, const orc_hmm *fwd, const orc_hmm *rev, int prune_len, double low_cov_pen) {
+    auto *s = new orc_searcher;
+    s->g = g; s->hm[0] = fwd; s->hm[1] = rev;
+    s->prune = prune_len;
+    s->low_cov_penalty = -std::log(low_cov_pen);
+    for (int i = 0; i < 3000; ++i) s->exit_prob[i] = std::log(2.0 / (i + 2)) * 2;
+    return s;
+}
+void orc_searcher_free(orc_searcher *s) { s->release(); delete s; }
+void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); }
+
+int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, orc_astar_result *right, orc_astar_result *left,
+                        char *contig, int64_t cap) {
+    std::string kmer(kmer_c);
+    for (auto &c : kmer) c = (char)tolower(c);                              // search.cpp:156
+    if ((int)kmer.size() < s->g->k + 1) return -1;
+    AstarOut o1, o2;
+    Node *g1 = astar_from_kmer(*s, 0, start_state, kmer, o1);               // hmm_graph_search.h:67
+    std::string rs = g1 ? path_string(g1, s->cache[0]) : std::string();
+    fill_result(right, o1, g1);
+    int lstate = s->hm[1]->M - start_state - int(kmer.size() / 3);          // :73
+    Node *g2 = astar_from_kmer(*s, 1, lstate, kmer, o2);
+    std::string ls = g2 ? path_string(g2, s->cache[1]) : std::string();
+    fill_result(left, o2, g2);
+    s->release();
+    std::string out = revcomp(ls) + kmer + rs;                              // :77-79
+    if ((int64_t)out.size() + 1 > cap) return -2;
+    memcpy(contig, out.c_str(), out.size() + 1);
+    return (int64_t)out.size();
+}
+
+}  // extern "C"

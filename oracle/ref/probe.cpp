@@ -185,11 +185,14 @@ static int cmd_astar(int argc, char **argv) {
         AStarNode *g1 = s.pool_->construct(), *g2 = s.pool_->construct();
         std::string right, left;
         printf("seed %d %s %d", idx, kmer.c_str(), start_state);
+        // astarSearch clears `closed` itself (hmm_graph_search.h:202) except on its early return
+        // (:193-197); clearing here only keeps the printed count from going stale in that case.
+        s.closed.clear();
         bool ok1 = s.astarSearch(fwd, start_state, kmer, dbg, true, fe, *g1, *tn);
-        size_t closed1 = s.closed.size(); (void)closed1;
         s.partialResultFromGoal(*g1, true, right, *tn);
         print_goal("R", *g1, s, right, ok1);
         int lstate = rev.modelLength() - start_state - (int)kmer.size() / 3;
+        s.closed.clear();
         bool ok2 = s.astarSearch(rev, lstate, kmer, dbg, false, re, *g2, *tnr);
         s.partialResultFromGoal(*g2, false, left, *tnr);
         print_goal("L", *g2, s, left, ok2);
@@ -202,7 +205,27 @@ static int cmd_astar(int argc, char **argv) {
     return 0;
 }
 
+static int cmd_codon() {
+    // codon.h:5-209: forward and reverse-complement codon tables, index c1,c2,c3 with A0 C1 G2 T3
+    printf("fwd ");
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) putchar(Codon::codonTable[a][b][c]);
+    printf("\nrc ");
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) putchar(Codon::rc_codonTable[a][b][c]);
+    printf("\n");
+    // libseq translation used for the start k-mer (hmm_graph_search.h:137-148)
+    printf("libseq ");
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int c = 0; c < 4; ++c) {
+        std::string cod; cod += "ACGT"[a]; cod += "ACGT"[b]; cod += "ACGT"[c];
+        seq::NTSequence nts = seq::NTSequence("", "", cod);
+        seq::AASequence aa = seq::AASequence::translate(nts.begin(), nts.begin() + 3);
+        printf("%s", aa.asString().c_str());
+    }
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "codon") return cmd_codon();
     if (argc < 3) { fprintf(stderr, "usage: probe hmm|graph|index|astar ...\n"); return 2; }
     std::string c = argv[1];
     if (c == "hmm") return cmd_hmm(argc, argv);

@@ -1,0 +1,84 @@
+"""Shared helpers for the parity tests (golden-file parsing)."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+
+def gz_lines(path):
+    with gzip.open(path, "rt") as f:
+        return f.read().splitlines()
+
+
+def load_streams(path):
+    return json.load(open(path))
+
+
+def fnv1a(arr: np.ndarray) -> str:
+    h = 1469598103934665603
+    for b in arr.tobytes():
+        h ^= b
+        h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def parse_probe_graph(lines):
+    hdr = {l.split()[0]: l.split()[1:] for l in lines if not l.startswith("q ")}
+    qs = []
+    for l in lines:
+        if not l.startswith("q "):
+            continue
+        t = l.split()
+        q = dict(e=int(t[1]), w=int(t[3]), last=int(t[5]), tip=int(t[7]), valid=int(t[9]), multi1=int(t[11]), od=int(t[13]))
+        od = max(q["od"], 0)
+        q["out"] = [int(x) for x in t[14:14 + od]]
+        p = 14 + od
+        assert t[p] == "rl"
+        q["rank_last"] = int(t[p + 1])
+        q["rank_w"] = [int(x) for x in t[p + 2:p + 11]]
+        assert t[p + 11] == "sl"
+        q["select_last"] = int(t[p + 12])
+        if len(t) > p + 13:
+            assert t[p + 13] == "fwd"
+            q["fwd"] = int(t[p + 14])
+            q["label"] = t[p + 16]
+            idn = int(t[p + 18])
+            q["id"] = idn
+            q["in"] = [int(x) for x in t[p + 19:p + 19 + idn]]
+        qs.append(q)
+    return hdr, qs
+
+
+def parse_probe_hmm(lines):
+    out = dict(msc={}, isc={}, tsc={}, maxm={}, h={})
+    for l in lines:
+        t = l.split()
+        if t[0] == "M":
+            out["M"] = int(t[1])
+        elif t[0] == "A":
+            out["A"] = int(t[1])
+        elif t[0] == "alpha":
+            out["alpha"] = [int(x) for x in t[1:]]
+        elif t[0] in ("msc", "isc", "tsc", "h"):
+            out[t[0]][int(t[1])] = np.array([float.fromhex(x) for x in t[2:]])
+        elif t[0] == "maxm":
+            out["maxm"][int(t[1])] = float.fromhex(t[2])
+    return out
+
+
+def parse_probe_astar(lines):
+    """-> list of dict(idx, kmer, start_state, R=dict, L=dict, contig)"""
+    res = []
+    for l in lines:
+        t = l.split()
+        iR, iL, ic = t.index("R"), t.index("L"), t.index("contig")
+
+        def side(tt):
+            d = dict(zip(tt[0::2], tt[1::2]))
+            return dict(ok=int(d["ok"]), real=float.fromhex(d["real"]), score=float.fromhex(d["score"]), fval=int(d["fval"]),
+                        length=int(d["len"]), state_no=int(d["state_no"]), state=d["state"], node=int(d["node"]),
+                        closed=int(d["closed"]), seq="" if d["seq"] == "." else d["seq"])
+        res.append(dict(idx=int(t[1]), kmer=t[2], start_state=int(t[3]), R=side(t[iR + 1:iL]), L=side(t[iL + 1:ic]),
+                        contig=t[ic + 1]))
+    return res
