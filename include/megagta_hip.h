@@ -1,0 +1,152 @@
+/* megagta_hip.h — C ABI of libmegagta_hip.so: the MI355X (gfx950) implementation of MegaGTA's
+ * HMM-guided succinct-de-Bruijn-graph assembly hot path.
+ *
+ * This is the in-process successor of the reference's dead GPU plug-point
+ *     lv2_gpu_sort(uint32_t *lv2_substrings, uint32_t *permutation, int words_per_substring,
+ *                  int64_t lv2_num_items, void *key1, void *key2, void *val1, void *val2)
+ *     alloc_gpu_buffers(...) / free_gpu_buffers(...)
+ * (call sites cx1_read2sdbg_s1.cpp:308,619-620,945 and cx1_read2sdbg_s2.cpp:391,697-698,926; the
+ * functions themselves exist nowhere in the reference tree).  Instead of sorting one lv2 batch per
+ * call, the whole read -> SdBG-edge pipeline, the graph and the A* search live on the device.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns 0 on success and a
+ * negative MGTA_E* code on failure (mgta_last_error() gives the message of the calling thread's
+ * last failure); no exceptions cross the boundary; one mgta_ctx per GPU (thread-compatible).
+ * There is NO CPU fallback: without a usable HIP device every entry point fails.
+ */
+#ifndef MEGAGTA_HIP_H_
+#define MEGAGTA_HIP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGTA_OK 0
+#define MGTA_EINVAL (-1)      /* bad argument */
+#define MGTA_EHIP (-2)        /* HIP runtime error / no device */
+#define MGTA_ENOMEM (-3)      /* device memory exhausted */
+#define MGTA_EUNSUPPORTED (-4)/* feature of the reference not built yet (fails loudly, never silently) */
+#define MGTA_ESINK (-5)       /* caller's sink returned non-zero */
+#define MGTA_EOVERFLOW (-6)   /* per-search arena exhausted after all retries */
+
+#define MGTA_NUM_BUCKETS 65536 /* kNumBuckets, cx1_read2sdbg.h:64 (8-character key prefix) */
+
+typedef struct mgta_ctx mgta_ctx;
+typedef struct mgta_reads mgta_reads;
+typedef struct mgta_sdbg mgta_sdbg;
+typedef struct mgta_hmm mgta_hmm;
+
+const char *mgta_last_error(void);
+const char *mgta_version(void);
+
+mgta_ctx *mgta_ctx_create(int device_id);            /* NULL on failure (see mgta_last_error) */
+void mgta_ctx_destroy(mgta_ctx *);
+/* memory the build may use on the device; 0 = 90 % of what is free (cf. --host_mem/--mem_flag, build_graph.cpp:40-47) */
+int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * SdBG construction  (replaces CX1::run() with the s2 plug-ins: cx1.h:443-623,
+ * s2_lv0_calc_bucket_size / s2_lv1_fill_offset / s2_lv2_extract_substr_ / lv2_cpu_radix_sort_st /
+ * output_: cx1_read2sdbg_s2.cpp:252-315,475-677,742-835; lv2_cpu_sort.h:133-150)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* One call per bucket range [bucket_begin,bucket_end), ranges ascending and disjoint: the logical
+ * edge stream in bucket order, exactly the arguments SdbgWriter::write receives
+ * (sdbg_multi_io.h:83-112).  recs[i] = w | last<<4 | tip<<5 | min(mult,255)<<8; `large` holds the
+ * full 16-bit multiplicities of the records with mult > 254, `tips` words_per_tip words per tip
+ * record, both in stream order.  Buffers are host memory owned by the library, valid during the call. */
+typedef int (*mgta_edge_sink)(void *user, int32_t bucket_begin, int32_t bucket_end,
+                              const int64_t *bucket_counts /* [bucket_end-bucket_begin][3]: records, large, tips */,
+                              const uint16_t *recs, int64_t n_recs, const uint16_t *large, int64_t n_large,
+                              const uint32_t *tips, int64_t n_tip_words);
+
+typedef struct mgta_build_stats {
+    int32_t k, words_per_key, words_per_tip, n_passes;
+    int64_t n_reads, n_kmers;        /* n_kmers = sum max(0,len-k): (k+1)-mer occurrences fed to stage 2 */
+    int64_t n_items;                 /* sort items generated */
+    int64_t n_edges, n_tips, n_large;
+    int64_t n_sort_launches;         /* launches of the dominant kernel (radix scatter) */
+    double ms_total;                 /* device time, reads resident -> last record in device memory */
+    double ms_count, ms_gen, ms_sort, ms_emit, ms_d2h;
+    double ms_sort_scatter;          /* summed duration of the radix scatter launches (HIP events) */
+    uint64_t bytes_peak;             /* device bytes allocated at the peak */
+} mgta_build_stats;
+
+/* a1: packed reads as `buildgraph` holds them — every read REVERSED (cx1_read2sdbg_s1.cpp:97,117),
+ * 2 bits/base, base j of word at bits 30-2j (sequence_package.h:126-129), reads concatenated;
+ * start_idx[n_reads+1] in bases (sequence_package.h:44).  Copies host -> device. */
+int mgta_reads_upload(mgta_ctx *, const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx,
+                      uint64_t n_reads, mgta_reads **out);
+/* adopt buffers that already live on this device (e.g. torch tensors); not freed by mgta_reads_free */
+int mgta_reads_adopt_device(mgta_ctx *, const uint32_t *d_packed_seq, uint64_t n_words,
+                            const uint64_t *d_start_idx, uint64_t n_reads, mgta_reads **out);
+void mgta_reads_free(mgta_reads *);
+
+/* a2-a6: reads resident -> edge stream.  min_count must be 1 (reference `-m 1`: every position solid);
+ * min_count > 1 / need_mercy (stage 1, cx1_read2sdbg_s1.cpp) returns MGTA_EUNSUPPORTED.
+ * n_short_reads: reads [n_short_reads, n_reads) are assist sequences (always solid, s2.cpp:276).
+ * sink may be NULL (records stay on the device, e.g. for timing). */
+int mgta_sdbg_build_resident(mgta_ctx *, const mgta_reads *, uint64_t n_short_reads, int k, int min_count,
+                             int need_mercy, mgta_edge_sink sink, void *user, mgta_build_stats *stats);
+/* convenience: upload + build + free */
+int mgta_sdbg_build(mgta_ctx *, const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx,
+                    uint64_t n_reads, uint64_t n_short_reads, int k, int min_count, int need_mercy,
+                    mgta_edge_sink sink, void *user, mgta_build_stats *stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * Succinct de Bruijn graph on the device (replaces SuccinctDBG::LoadFromMultiFile/init and the
+ * rank/select indexes: succinct_dbg.cpp:595-723, succinct_dbg.h:62-86, rank_and_select.h)
+ * ------------------------------------------------------------------------------------------------ */
+/* From the logical edge stream (all buckets): recs[size], bucket_items[65536], tip labels. */
+int mgta_sdbg_load(mgta_ctx *, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items,
+                   const uint32_t *tips, int64_t n_tip_words, int words_per_tip, mgta_sdbg **out);
+void mgta_sdbg_free(mgta_sdbg *);
+int64_t mgta_sdbg_size(const mgta_sdbg *);
+/* batched navigation (test hook + building block of the search): for each edge id the valid
+ * outgoing edges in the reference's order (descending id) [succinct_dbg.cpp:78-97];
+ * outdeg[i] = -1 for an invalid edge.  out4 = n x 4 int64 (unused slots -1). Host pointers. */
+int mgta_sdbg_outgoing(mgta_sdbg *, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg);
+/* batched IndexBinarySearchEdge over (k+1)-symbol strings (symbols 1..4) [succinct_dbg.cpp:427-549]. */
+int mgta_sdbg_index_edges(mgta_sdbg *, const uint8_t *seqs /* n x (k+1) */, int64_t n, int64_t *edge_ids);
+
+/* ------------------------------------------------------------------------------------------------
+ * Profile HMM tables (parsed on the host exactly like Parser::readHMM, hmmer3b_parser.h:19-177;
+ * heuristic like MostProbablePath, most_probable_path.h:48-118)
+ * ------------------------------------------------------------------------------------------------ */
+int mgta_hmm_load(mgta_ctx *, int M, int A, const double *msc /* [(M+1)*A] */, const double *tsc /* [7*(M+1)] */,
+                  const double *max_match /* [M+1] */, const double *h /* [3*(M+1)] */,
+                  const int32_t *alpha /* [127] residue letter -> column */, mgta_hmm **out);
+void mgta_hmm_free(mgta_hmm *);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched HMM-guided A* (replaces the OMP seed loop of search(): search.cpp:184-189,
+ * HMMGraphSearch::search/astarSearch: hmm_graph_search.h:60-343, NodeEnumerator::enumerateNodes:
+ * node_enumerator.h:65-246)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mgta_astar_side {
+    int32_t ok, fval, length, state_no, state, partial;
+    int64_t node_id, n_closed, n_expanded, n_opened;
+    double real_score, score;
+} mgta_astar_side;
+
+typedef struct mgta_astar_stats {
+    int64_t n_seeds, n_expansions, n_opened, n_retries;
+    double ms_total, ms_kernel;
+} mgta_astar_stats;
+
+/* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */
+typedef int (*mgta_contig_sink)(void *user, int64_t seed_index, const char *left, int64_t left_len,
+                                const char *right, int64_t right_len, const mgta_astar_side *right_side,
+                                const mgta_astar_side *left_side);
+
+/* kmers: n x (k+1) characters ACGT (any case), start_state[i] = model position - 1 (search.cpp:157).
+ * cache_mode 0 = cold (every seed independent, embarrassingly parallel);
+ * cache_mode 1 = warm, seeds processed sequentially sharing the term_nodes caches like `search ... 1`. */
+int mgta_astar_batch(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
+                     const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
+                     int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGAGTA_HIP_H_ */

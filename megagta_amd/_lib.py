@@ -1,0 +1,96 @@
+"""ctypes loader of libmegagta_hip.so (the C ABI of include/megagta_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no device is usable every call fails
+loudly (MegaGtaError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmegagta_hip.so")
+
+
+class MegaGtaError(RuntimeError):
+    pass
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("k", C.c_int32), ("words_per_key", C.c_int32), ("words_per_tip", C.c_int32), ("n_passes", C.c_int32),
+                ("n_reads", C.c_int64), ("n_kmers", C.c_int64), ("n_items", C.c_int64), ("n_edges", C.c_int64),
+                ("n_tips", C.c_int64), ("n_large", C.c_int64), ("n_sort_launches", C.c_int64), ("ms_total", C.c_double),
+                ("ms_count", C.c_double), ("ms_gen", C.c_double), ("ms_sort", C.c_double), ("ms_emit", C.c_double),
+                ("ms_d2h", C.c_double), ("ms_sort_scatter", C.c_double), ("bytes_peak", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class AstarSide(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("fval", C.c_int32), ("length", C.c_int32), ("state_no", C.c_int32), ("state", C.c_int32),
+                ("partial", C.c_int32), ("node_id", C.c_int64), ("n_closed", C.c_int64), ("n_expanded", C.c_int64),
+                ("n_opened", C.c_int64), ("real_score", C.c_double), ("score", C.c_double)]
+
+
+class AstarStats(C.Structure):
+    _fields_ = [("n_seeds", C.c_int64), ("n_expansions", C.c_int64), ("n_opened", C.c_int64), ("n_retries", C.c_int64),
+                ("ms_total", C.c_double), ("ms_kernel", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EDGE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint16), C.c_int64,
+                        C.POINTER(C.c_uint16), C.c_int64, C.POINTER(C.c_uint32), C.c_int64)
+CONTIG_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                          C.POINTER(AstarSide), C.POINTER(AstarSide))
+
+# every symbol include/megagta_hip.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = {
+    "mgta_last_error": (C.c_char_p, []),
+    "mgta_version": (C.c_char_p, []),
+    "mgta_ctx_create": (C.c_void_p, [C.c_int]),
+    "mgta_ctx_destroy": (None, [C.c_void_p]),
+    "mgta_ctx_set_mem_limit": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "mgta_reads_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mgta_reads_adopt_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mgta_reads_free": (None, [C.c_void_p]),
+    "mgta_sdbg_build_resident": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, EDGE_SINK, C.c_void_p,
+                                          C.POINTER(BuildStats)]),
+    "mgta_sdbg_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                 C.c_int, EDGE_SINK, C.c_void_p, C.POINTER(BuildStats)]),
+    "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                C.POINTER(C.c_void_p)]),
+    "mgta_sdbg_free": (None, [C.c_void_p]),
+    "mgta_sdbg_size": (C.c_int64, [C.c_void_p]),
+    "mgta_sdbg_outgoing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mgta_sdbg_index_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mgta_hmm_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_void_p)]),
+    "mgta_hmm_free": (None, [C.c_void_p]),
+    "mgta_astar_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                  C.c_int, CONTIG_SINK, C.c_void_p, C.POINTER(AstarStats)]),
+}
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MegaGtaError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C megagta_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise MegaGtaError(f"{what} failed ({rc}): {load().mgta_last_error().decode()}")

@@ -1,0 +1,219 @@
+"""Python host side above the C ABI: mirrors the reference's `buildgraph` / `search` operator
+surface (same inputs, same outputs, same error behaviour) on top of libmegagta_hip.so.
+
+  Context.build_sdbg(...)      <->  `megagta buildgraph`  (build_graph.cpp:33-135)
+  write_sdbg(prefix, stream)   <->  SdbgWriter            (sdbg_multi_io.h:34-199)
+  read_sdbg(prefix)            <->  SdbgReader            (sdbg_multi_io.h:201-417)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import MegaGtaError, check
+
+NUM_BUCKETS = 65536
+
+
+@dataclass
+class EdgeStream:
+    """Logical SdBG edge stream in bucket order (what SdbgWriter::write receives)."""
+    k: int
+    words_per_tip: int
+    bucket_items: np.ndarray                 # int64 [65536] records per bucket
+    records: np.ndarray                      # uint16 [num_edges]
+    large: np.ndarray                        # uint16 [num_large]
+    tips: np.ndarray                         # uint32 [num_tips * words_per_tip]
+    bucket_large: np.ndarray = None          # int64 [65536]
+    bucket_tips: np.ndarray = None           # int64 [65536]
+    stats: dict = field(default_factory=dict)
+
+    def md5(self) -> str:
+        h = hashlib.md5()
+        h.update(np.int32(self.k).tobytes())
+        h.update(self.bucket_items.astype("<i8").tobytes())
+        h.update(self.records.astype("<u2").tobytes())
+        h.update(self.large.astype("<u2").tobytes())
+        h.update(self.tips.astype("<u4").tobytes())
+        return h.hexdigest()
+
+
+class Context:
+    """One per GPU (mgta_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self.h = self._L.mgta_ctx_create(device)
+        if not self.h:
+            raise MegaGtaError("mgta_ctx_create failed: " + self._L.mgta_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.mgta_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_mem_limit(self, nbytes: int):
+        check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
+
+    # ---- SdBG build ---------------------------------------------------------------------------
+    def upload_reads(self, packed: np.ndarray, start_idx: np.ndarray) -> "Reads":
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        start_idx = np.ascontiguousarray(start_idx, dtype=np.uint64)
+        out = C.c_void_p()
+        check(self._L.mgta_reads_upload(self.h, packed.ctypes.data, packed.size, start_idx.ctypes.data, start_idx.size - 1,
+                                        C.byref(out)), "mgta_reads_upload")
+        return Reads(self, out, start_idx.size - 1)
+
+    def adopt_reads(self, d_packed_ptr: int, n_words: int, d_start_ptr: int, n_reads: int, keepalive=None) -> "Reads":
+        out = C.c_void_p()
+        check(self._L.mgta_reads_adopt_device(self.h, d_packed_ptr, n_words, d_start_ptr, n_reads, C.byref(out)),
+              "mgta_reads_adopt_device")
+        r = Reads(self, out, n_reads)
+        r._keep = keepalive
+        return r
+
+    def build_sdbg(self, reads: "Reads", k: int, min_count: int = 1, need_mercy: bool = False, collect: bool = True,
+                   n_short_reads: int | None = None) -> EdgeStream:
+        """Reads resident on the device -> edge stream (collect=False keeps it on the device: timing runs)."""
+        wpt = (2 * k + 31) // 32
+        recs, large, tips = [], [], []
+        counts = np.zeros((NUM_BUCKETS, 3), dtype=np.int64)
+
+        def sink(user, b0, b1, bc, r, nr, lg, nl, tp, ntw):
+            nb = b1 - b0
+            counts[b0:b1] = np.ctypeslib.as_array(bc, shape=(nb * 3,)).reshape(nb, 3)
+            recs.append(np.ctypeslib.as_array(r, shape=(nr,)).copy() if nr else np.zeros(0, np.uint16))
+            large.append(np.ctypeslib.as_array(lg, shape=(nl,)).copy() if nl else np.zeros(0, np.uint16))
+            tips.append(np.ctypeslib.as_array(tp, shape=(ntw,)).copy() if ntw else np.zeros(0, np.uint32))
+            return 0
+
+        cb = _lib.EDGE_SINK(sink) if collect else C.cast(None, _lib.EDGE_SINK)
+        st = _lib.BuildStats()
+        ns = reads.n_reads if n_short_reads is None else n_short_reads
+        check(self._L.mgta_sdbg_build_resident(self.h, reads.h, ns, k, min_count, int(need_mercy), cb, None, C.byref(st)),
+              "mgta_sdbg_build_resident")
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        return EdgeStream(k=k, words_per_tip=wpt, bucket_items=counts[:, 0].copy(), records=cat(recs, np.uint16),
+                          large=cat(large, np.uint16), tips=cat(tips, np.uint32), bucket_large=counts[:, 1].copy(),
+                          bucket_tips=counts[:, 2].copy(), stats=st.as_dict())
+
+
+class Reads:
+    def __init__(self, ctx: Context, handle, n_reads: int):
+        self.ctx, self.h, self.n_reads = ctx, handle, n_reads
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx._L.mgta_reads_free(self.h)
+            self.h = None
+
+    __del__ = free
+
+
+# ------------------------------------------------------------------------------------------------
+# .sdbg.N / .sdbg_info files
+# ------------------------------------------------------------------------------------------------
+def write_sdbg(prefix: str, s: EdgeStream, num_files: int = 1) -> None:
+    """SdbgWriter layout (sdbg_multi_io.h:83-187): per record uint16, then uint16 full multiplicity if
+    mult > 254, then words_per_tip uint32 if tip; text index with one line per bucket
+    `bucket file byte_offset num_items num_tips num_large_mul` (file = -1 for an empty bucket).
+    Buckets are dealt to `num_files` files as contiguous ranges of roughly equal record count."""
+    n = s.records.size
+    rec = s.records
+    is_large = (rec >> 8) == 255
+    is_tip = ((rec >> 5) & 1).astype(bool)
+    sz = 2 + 2 * is_large.astype(np.int64) + 4 * s.words_per_tip * is_tip.astype(np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(sz, out=off[1:])
+    buf = np.zeros(int(off[-1]), dtype=np.uint8)
+    pos = off[:-1]
+
+    def put16(at, vals):
+        v = vals.astype("<u2").view(np.uint8).reshape(-1, 2)
+        buf[at] = v[:, 0]
+        buf[at + 1] = v[:, 1]
+
+    put16(pos, rec)
+    if is_large.any():
+        put16(pos[is_large] + 2, s.large)
+    if is_tip.any():
+        tp = pos[is_tip] + 2 + 2 * is_large[is_tip].astype(np.int64)
+        tb = s.tips.astype("<u4").view(np.uint8).reshape(-1, 4 * s.words_per_tip)
+        for j in range(4 * s.words_per_tip):
+            buf[tp + j] = tb[:, j]
+    bstart = np.zeros(NUM_BUCKETS + 1, dtype=np.int64)
+    np.cumsum(s.bucket_items, out=bstart[1:])
+    cuts = [0]
+    for f in range(1, num_files):
+        cuts.append(max(cuts[-1], int(np.searchsorted(bstart, n * f // num_files, side="left"))))
+    cuts.append(NUM_BUCKETS)
+    large_cum = np.concatenate([[0], np.cumsum(is_large)])
+    tip_cum = np.concatenate([[0], np.cumsum(is_tip)])
+    lines = [f"k {s.k}\n", f"words_per_tip_label {s.words_per_tip}\n", f"num_buckets {NUM_BUCKETS}\n", f"num_threads {num_files}\n",
+             f"total_size {n}\n", f"num_tips {int(is_tip.sum())}\n", f"large_multi {int(is_large.sum())}\n"]
+    file_of = np.zeros(NUM_BUCKETS, dtype=np.int64)
+    for f in range(num_files):
+        b0, b1 = cuts[f], cuts[f + 1]
+        file_of[b0:b1] = f
+        buf[off[bstart[b0]]:off[bstart[b1]]].tofile(f"{prefix}.sdbg.{f}")
+    for b in range(NUM_BUCKETS):
+        i0, i1 = bstart[b], bstart[b + 1]
+        if i1 == i0:
+            lines.append(f"{b} -1 0 0 0 0\n")
+        else:
+            f = file_of[b]
+            lines.append(f"{b} {f} {off[i0] - off[bstart[cuts[f]]]} {i1 - i0} {tip_cum[i1] - tip_cum[i0]} "
+                         f"{large_cum[i1] - large_cum[i0]}\n")
+    with open(prefix + ".sdbg_info", "w") as fh:
+        fh.writelines(lines)
+
+
+def read_sdbg(prefix: str) -> EdgeStream:
+    """SdbgReader (sdbg_multi_io.h:240-382): files -> logical stream in bucket order."""
+    with open(prefix + ".sdbg_info") as fh:
+        hdr = {}
+        for key in ("k", "words_per_tip_label", "num_buckets", "num_threads", "total_size", "num_tips", "large_multi"):
+            name, val = fh.readline().split()
+            if name != key:
+                raise ValueError(f"{prefix}.sdbg_info: expected '{key}', got '{name}'")
+            hdr[key] = int(val)
+        rows = np.loadtxt(fh, dtype=np.int64).reshape(-1, 6)
+    if hdr["num_buckets"] != NUM_BUCKETS or rows.shape[0] != NUM_BUCKETS:
+        raise ValueError("unexpected bucket count")
+    wpt = hdr["words_per_tip_label"]
+    files = [np.fromfile(f"{prefix}.sdbg.{t}", dtype=np.uint8) for t in range(hdr["num_threads"])]
+    recs, large, tips = [], [], []
+    for b in range(NUM_BUCKETS):
+        _, tid, offb, items, ntips, nlarge = rows[b]
+        if tid < 0 or items == 0:
+            continue
+        nbytes = items * 2 + nlarge * 2 + ntips * 4 * wpt
+        chunk = files[tid][offb:offb + nbytes]
+        if ntips == 0 and nlarge == 0:
+            recs.append(chunk.view("<u2"))
+            continue
+        p, r, lg, tp = 0, [], [], []
+        for _ in range(items):
+            it = int(chunk[p]) | (int(chunk[p + 1]) << 8)
+            p += 2
+            r.append(it)
+            if (it >> 8) == 255:
+                lg.append(int(chunk[p]) | (int(chunk[p + 1]) << 8))
+                p += 2
+            if (it >> 5) & 1:
+                tp.append(chunk[p:p + 4 * wpt].view("<u4").copy())
+                p += 4 * wpt
+        recs.append(np.array(r, dtype=np.uint16))
+        large.append(np.array(lg, dtype=np.uint16))
+        if tp:
+            tips.append(np.concatenate(tp))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return EdgeStream(k=hdr["k"], words_per_tip=wpt, bucket_items=rows[:, 3].copy(), records=cat(recs, np.uint16),
+                      large=cat(large, np.uint16), tips=cat(tips, np.uint32), bucket_large=rows[:, 5].copy(),
+                      bucket_tips=rows[:, 4].copy())

@@ -1,0 +1,76 @@
+// common.hpp — shared host-side plumbing of libmegagta_hip.so (context, error reporting, device buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/megagta_hip.h"
+
+namespace mgta {
+
+void set_error(const char *fmt, ...);
+
+struct HipError {
+    int code;
+};
+
+#define MGTA_HIP_CHECK(expr)                                                                        \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            ::mgta::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw ::mgta::HipError{e_ == hipErrorOutOfMemory ? MGTA_ENOMEM : MGTA_EHIP};           \
+        }                                                                                           \
+    } while (0)
+
+// RAII device allocation; tracks the context's running / peak byte count.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    uint64_t *live = nullptr, *peak = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept { *this = std::move(o); }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; live = o.live; peak = o.peak; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n, uint64_t *live_ = nullptr, uint64_t *peak_ = nullptr) {
+        release();
+        if (n == 0) n = 16;
+        MGTA_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n; live = live_; peak = peak_;
+        if (live) { *live += n; if (peak && *live > *peak) *peak = *live; }
+    }
+    void release() {
+        if (p) { (void)hipFree(p); if (live) *live -= bytes; }
+        p = nullptr; bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace mgta
+
+struct mgta_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t mem_limit = 0;       // 0 = auto
+    uint64_t live_bytes = 0, peak_bytes = 0;
+    int num_cus = 256;
+    hipDeviceProp_t prop;
+};
+
+struct mgta_reads {
+    mgta_ctx *ctx = nullptr;
+    const uint32_t *d_packed = nullptr;   // padded with >= 16 zero words past n_words
+    const uint64_t *d_start = nullptr;    // [n_reads+1]
+    uint64_t n_words = 0, n_reads = 0;
+    mgta::DevBuf own_packed, own_start;   // empty when adopted
+};

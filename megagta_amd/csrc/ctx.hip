@@ -1,0 +1,53 @@
+// ctx.hip — context life-cycle and error reporting of libmegagta_hip.so
+#include "common.hpp"
+
+namespace mgta {
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace mgta
+
+extern "C" {
+
+const char *mgta_last_error(void) { return mgta::g_err; }
+const char *mgta_version(void) { return "megagta_amd 0.1 (gfx950)"; }
+
+mgta_ctx *mgta_ctx_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        mgta::set_error("no HIP device available (%s): libmegagta_hip has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) { mgta::set_error("device %d out of range (%d devices)", device_id, n); return nullptr; }
+    auto *ctx = new mgta_ctx;
+    ctx->device = device_id;
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(device_id));
+        MGTA_HIP_CHECK(hipGetDeviceProperties(&ctx->prop, device_id));
+        ctx->num_cus = ctx->prop.multiProcessorCount;
+        MGTA_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    } catch (const mgta::HipError &) {
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void mgta_ctx_destroy(mgta_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+int mgta_ctx_set_mem_limit(mgta_ctx *ctx, uint64_t bytes) {
+    if (!ctx) return MGTA_EINVAL;
+    ctx->mem_limit = bytes;
+    return MGTA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,883 @@
+// sdbg_build.hip — reads -> succinct-de-Bruijn-graph edge stream on gfx950 (MI355X).
+//
+// Replaces, behind the C ABI of include/megagta_hip.h, the reference's CX1 stage-2 pipeline
+//   s2_lv0_calc_bucket_size   cx1_read2sdbg_s2.cpp:252-315   (bucket census)
+//   s2_lv1_fill_offset        cx1_read2sdbg_s2.cpp:475-584   (per-bucket item lists)
+//   s2_lv2_extract_substr_    cx1_read2sdbg_s2.cpp:586-677   (key extraction, CopySubstring[RC] packed_reads.h:44-176)
+//   lv2_cpu_radix_sort_st     lv2_cpu_sort.h:133-150         (ascending lexicographic sort of the W-word keys)
+//   output_ + SdbgWriter::write  cx1_read2sdbg_s2.cpp:742-835, sdbg_multi_io.h:83-112 (edge records)
+// with a device-resident design (no differential offset lists, no per-bucket CPU threads):
+//
+//   pass over a bucket range [b_lo,b_hi) that fits the memory budget (the analogue of CX1's lv1 loop)
+//     1. item_scan<count>   one wave per read chunk, one lane per (k+1)-mer position: funnel-shift the
+//                           edge out of the 2-bit read array, reverse-complement it in registers, count
+//                           the <= 6 sort items of the position that fall into the bucket range
+//     2. prefix sum of the per-workgroup counts
+//     3. item_scan<write>   same scan, keys written (array-of-structs, W words) with wave-aggregated offsets
+//     4. LSD radix sort of the keys, 8-bit digits, zero bits skipped: digit census per tile, row scan,
+//        stable LDS-staged scatter (wave-level match ranking, coalesced run writes)
+//     5. edge emission: run heads -> sub-group descriptors (a, b, group-head) -> per sub-group decision
+//        (W, last, tip, multiplicity, $-suppression) -> order-preserving compaction of records, large
+//        multiplicities and tip labels + per-bucket boundaries
+//
+// Everything is integer / byte work bound by HBM traffic; no MFMA.  Parity: bit-exact edge stream vs
+// the oracle (tests/test_sdbg_build_gpu.py).
+#include <algorithm>
+#include <cstdlib>
+#include <memory>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "scan.hpp"
+
+namespace mgta {
+
+constexpr int kDollar = 4;   // kSentinelValue, cx1_read2sdbg.h:72
+
+template <int W>
+struct Key {
+    uint32_t w[W];
+};
+
+// ---------------------------------------------------------------------------------------------
+// multi-word helpers on big-endian 2-bit strings (x[0] holds the first 16 characters)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void shl_bits(uint32_t (&x)[W], int s) {   // 0 <= s <= 32
+    if (s == 0) return;
+    if (s == 32) {
+#pragma unroll
+        for (int j = 0; j < W - 1; ++j) x[j] = x[j + 1];
+        x[W - 1] = 0;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) x[j] = (x[j] << s) | (j + 1 < W ? (x[j + 1] >> (32 - s)) : 0u);
+}
+
+template <int W>
+__device__ __forceinline__ void keep_chars(uint32_t (&x)[W], int n) {   // keep the first n characters
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        int lo = j * 16;
+        if (n <= lo) x[j] = 0;
+        else if (n < lo + 16) x[j] &= ~0u << (32 - 2 * (n - lo));
+    }
+}
+
+// key = characters [from, from+n) of `e` (n = k or k-1), zero padded, flags in the low 4 bits of the
+// last word: (n == k) << 3 | prev     [cx1_read2sdbg_s2.cpp:613-671]
+template <int W>
+__device__ __forceinline__ Key<W> make_key(const uint32_t (&e)[W], int from, int n, int k, int prev) {
+    uint32_t t[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) t[j] = e[j];
+    shl_bits<W>(t, 2 * from);
+    keep_chars<W>(t, n);
+    t[W - 1] |= (uint32_t)(n == k) << 3;
+    t[W - 1] |= (uint32_t)prev;
+    Key<W> key;
+#pragma unroll
+    for (int j = 0; j < W; ++j) key.w[j] = t[j];
+    return key;
+}
+
+__device__ __forceinline__ uint32_t rev_chars(uint32_t x) {   // reverse the 16 characters of a word
+    x = __brev(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1./3. read scan
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 256;            // 4 waves
+constexpr int kReadsPerBlock = 64;
+
+struct ScanArgs {
+    const uint32_t *packed;
+    uint64_t n_words;
+    const uint64_t *start;
+    uint64_t n_reads;
+    int k;
+    uint32_t b_lo, b_hi;                   // bucket range [b_lo, b_hi)
+    uint32_t *block_count;                 // count mode: items per workgroup
+    const uint64_t *block_base;            // write mode
+    void *out;                             // Key<W>*
+    unsigned long long *n_kmers;           // count mode, sum over reads of max(0, len - k)
+};
+
+template <int W, bool WRITE>
+__global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
+    __shared__ uint32_t s_cursor;
+    __shared__ uint32_t s_wave_cnt[kScanBlock / 64];
+    const int k = a.k;
+    const int lane = lane_id(), wv = wave_id();
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
+    uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
+    Key<W> *out = reinterpret_cast<Key<W> *>(a.out);
+    uint64_t base = WRITE ? a.block_base[blockIdx.x] : 0;
+    uint32_t my_count = 0;
+    unsigned long long kmers = 0;
+    const int pad_bits = 2 * (16 * W - (k + 1));   // 2..32
+
+    for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
+        uint64_t s0 = a.start[r];
+        int len = (int)(a.start[r + 1] - s0);
+        if (len < k + 1) continue;                                     // s2.cpp:262-264
+        int npos = len - k;
+        if (lane == 0) kmers += (unsigned long long)npos;
+        for (int c0 = 0; c0 < npos; c0 += 64) {
+            int p = c0 + lane;
+            bool active = p < npos;
+            Key<W> items[6];
+            int cnt = 0;
+            if (active) {
+                // edge = characters [p, p+k] of the read
+                uint64_t q = s0 + (uint64_t)p;
+                uint64_t wi = q >> 4;
+                int sh = (int)(q & 15) * 2;
+                uint32_t raw[W + 1];
+#pragma unroll
+                for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
+                uint32_t e[W], rc[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) e[j] = sh ? ((raw[j] << sh) | (raw[j + 1] >> (32 - sh))) : raw[j];
+                keep_chars<W>(e, k + 1);
+                // reverse complement (MegahitKmer::ReverseComplement, megahit_kmer.h:115-174)
+#pragma unroll
+                for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
+                shl_bits<W>(rc, pad_bits);
+                bool pal = true;                                       // s2.cpp:278
+#pragma unroll
+                for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
+                int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+                auto push = [&](const Key<W> &key) {
+                    uint32_t b = key.w[0] >> 16;                       // bucket = first 8 characters (s2.cpp:832)
+                    if (b >= a.b_lo && b < a.b_hi) items[cnt++] = key;
+                };
+                if (p == 0) {                                          // left $  (s2.cpp:531-540)
+                    push(make_key<W>(e, 0, k, k, kDollar));
+                    if (!pal) push(make_key<W>(rc, 2, k - 1, k, r1c));
+                }
+                push(make_key<W>(e, 1, k, k, e0));                     // solid   (s2.cpp:543-550)
+                if (!pal) push(make_key<W>(rc, 1, k, k, r0c));
+                if (p == npos - 1) {                                   // right $ (s2.cpp:553-562)
+                    push(make_key<W>(e, 2, k - 1, k, e1));
+                    if (!pal) push(make_key<W>(rc, 0, k, k, kDollar));
+                }
+            }
+            if (!WRITE) {
+                my_count += (uint32_t)cnt;
+            } else {
+                uint32_t inc = wave_incl_scan((uint32_t)cnt);
+                uint32_t tot = __shfl(inc, 63, 64);
+                uint32_t wbase = 0;
+                if (lane == 0 && tot) wbase = atomicAdd(&s_cursor, tot);
+                wbase = __shfl(wbase, 0, 64);
+                uint64_t dst = base + wbase + (inc - (uint32_t)cnt);
+                for (int i = 0; i < cnt; ++i) out[dst + i] = items[i];
+            }
+        }
+    }
+    if (!WRITE) {
+        my_count = wave_sum(my_count);
+        if (lane == 0) s_wave_cnt[wv] = my_count;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < kScanBlock / 64; ++w) t += s_wave_cnt[w];
+            a.block_count[blockIdx.x] = t;
+        }
+        if (lane == 0 && kmers && a.n_kmers) atomicAdd(a.n_kmers, kmers);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. LSD radix sort (8-bit digits)
+// ---------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 512;                    // 8 waves
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kItemsPerThread = 8;
+constexpr int kSubTile = kSortThreads * kItemsPerThread;   // 4096 keys staged in LDS at a time
+constexpr int kSubTilesPerBlock = 8;
+constexpr int kBlockTile = kSubTile * kSubTilesPerBlock;   // 32768 keys per workgroup
+constexpr int kWaveChunk = kSubTile / kSortWaves;          // 512 consecutive keys per wave
+
+struct Digit {
+    int pos;     // bit position counted from the least significant bit of the whole key
+    int bits;    // <= 8
+};
+
+template <int W>
+__device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
+    int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
+    uint32_t v = key.w[wi] >> off;
+    if (off + d.bits > 32 && wi > 0) v |= key.w[wi - 1] << (32 - off);
+    return v & ((1u << d.bits) - 1u);
+}
+
+// census: hist[digit * n_tiles + tile]
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W> *keys, uint64_t n, Digit d, uint64_t n_tiles,
+                                                                     uint64_t *hist) {
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    uint64_t base = (uint64_t)blockIdx.x * kBlockTile;
+    int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
+    bool straddle = off + d.bits > 32 && wi > 0;
+    uint32_t mask = (1u << d.bits) - 1u;
+    for (int i = 0; i < kBlockTile / kSortThreads; ++i) {
+        uint64_t idx = base + (uint64_t)i * kSortThreads + threadIdx.x;
+        if (idx < n) {
+            uint32_t v = keys[idx].w[wi] >> off;
+            if (straddle) v |= keys[idx].w[wi - 1] << (32 - off);
+            atomicAdd(&h[v & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
+}
+
+// one workgroup per digit value: exclusive scan of its row of tile counts, in place; row total -> totals[digit]
+__global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uint64_t n_tiles, uint64_t *totals) {
+    __shared__ uint64_t scratch[1024 / 64 + 1];
+    __shared__ uint64_t carry_s;
+    uint64_t *row = hist + (uint64_t)blockIdx.x * n_tiles;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t b = 0; b < n_tiles; b += 1024) {
+        uint64_t idx = b + threadIdx.x;
+        uint64_t x = idx < n_tiles ? row[idx] : 0, tot;
+        uint64_t ex = block_excl_scan64<1024>(x, scratch, &tot);
+        uint64_t carry = carry_s;
+        if (idx < n_tiles) row[idx] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// stable scatter of one 32768-key tile by the current digit
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
+                                                                      uint64_t n_tiles, const uint64_t *rowoff,
+                                                                      const uint64_t *totals) {
+    __shared__ Key<W> s_keys[kSubTile];
+    __shared__ uint32_t s_whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile
+    __shared__ uint32_t s_start[256];               // first position of each digit value inside the sorted sub-tile
+    __shared__ uint32_t s_total[256];
+    __shared__ uint64_t s_gbase[256];               // global destination of the next key of each digit value
+    __shared__ uint32_t s_scratch[kSortThreads / 64 + 1];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const uint64_t ltmask = lanemask_lt();
+
+    // global base of every digit value for this tile = scan(totals)[digit] + rowoff[digit][tile]
+    {
+        __shared__ uint64_t s64[kSortThreads / 64 + 1];
+        uint64_t t = tid < 256 ? totals[tid] : 0;
+        uint64_t ex = block_excl_scan64<kSortThreads>(t, s64, nullptr);
+        if (tid < 256) s_gbase[tid] = ex + rowoff[(uint64_t)tid * n_tiles + blockIdx.x];
+    }
+    volatile uint32_t *whist = &s_whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
+    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
+    __syncthreads();
+
+    const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
+    for (int st = 0; st < kSubTilesPerBlock; ++st) {
+        uint64_t sub_base = tile_base + (uint64_t)st * kSubTile;
+        if (sub_base >= n) break;
+        uint32_t n_valid = (uint32_t)((n - sub_base) < (uint64_t)kSubTile ? (n - sub_base) : (uint64_t)kSubTile);
+
+        // phase 1: load (wave w owns keys [w*512, w*512+512) of the sub-tile, 64 at a time) + rank inside the wave chunk
+        Key<W> key[kItemsPerThread];
+        uint32_t dr[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
+#pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
+            bool valid = j < n_valid;
+            uint32_t dg = 0;
+            if (valid) {
+                key[it] = in[sub_base + j];
+                dg = get_digit<W>(key[it], d);
+            }
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                uint64_t bal = __ballot((dg >> b) & 1u);
+                peers &= ((dg >> b) & 1u) ? bal : ~bal;
+            }
+            uint32_t rank = (uint32_t)__popcll(peers & ltmask);
+            uint32_t cnt = (uint32_t)__popcll(peers);
+            uint32_t prev = 0;
+            if (valid) {
+                prev = whist[wv * 256 + dg];
+                if (rank == cnt - 1) whist[wv * 256 + dg] = prev + cnt;   // highest peer lane publishes the new count
+            }
+            dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
+        }
+        __syncthreads();
+        // phase 2: per digit value: wave bases + sub-tile totals, then exclusive scan over the 256 values
+        uint32_t tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) {
+                uint32_t c = s_whist[w][tid];
+                s_whist[w][tid] = tot;
+                tot += c;
+            }
+            s_total[tid] = tot;
+        }
+        uint32_t ex = block_excl_scan<kSortThreads>(tot, s_scratch, nullptr);
+        if (tid < 256) s_start[tid] = ex;
+        __syncthreads();
+        // phase 3: place the keys in sorted order in LDS
+#pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            if (dr[it] >> 31) {
+                uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
+                s_keys[s_start[dg] + s_whist[wv][dg] + rk] = key[it];
+            }
+        }
+        __syncthreads();
+        // phase 4: stream the sorted sub-tile out; consecutive threads hit consecutive addresses inside a run
+#pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+            if (j < n_valid) {
+                Key<W> kk = s_keys[j];
+                uint32_t dg = get_digit<W>(kk, d);
+                out[s_gbase[dg] + (j - s_start[dg])] = kk;
+            }
+        }
+        __syncthreads();
+        // phase 5: advance the global bases, clear the wave counters
+        if (tid < 256) s_gbase[tid] += s_total[tid];
+        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. edge emission
+// ---------------------------------------------------------------------------------------------
+constexpr int kEmitThreads = 256;
+constexpr int kEmitPerThread = 16;
+constexpr int kEmitTile = kEmitThreads * kEmitPerThread;   // 4096 sorted keys per workgroup
+
+template <int W>
+__device__ __forceinline__ bool keys_equal(const Key<W> &x, const Key<W> &y) {
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < W; ++j) eq = eq && (x.w[j] == y.w[j]);
+    return eq;
+}
+template <int W>
+__device__ __forceinline__ bool same_km1(const Key<W> &x, const Key<W> &y, int k) {   // IsDiffKMinusOneMer, s2.cpp:54-75
+    int full = (k - 1) >> 4, rem = (k - 1) & 15;
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        if (j < full) eq = eq && (x.w[j] == y.w[j]);
+        else if (j == full && rem > 0) eq = eq && ((x.w[j] >> (16 - rem) * 2) == (y.w[j] >> (16 - rem) * 2));
+    }
+    return eq;
+}
+template <int W>
+__device__ __forceinline__ int key_a(const Key<W> &x, int k) {   // Extract_a, s2.cpp:83-94
+    if ((x.w[W - 1] >> 3) & 1u) {
+        int wi = (k - 1) >> 4, ci = (k - 1) & 15;
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) if (j == wi) word = x.w[j];
+        return (word >> (15 - ci) * 2) & 3;
+    }
+    return kDollar;
+}
+template <int W>
+__device__ __forceinline__ int key_b(const Key<W> &x) { return x.w[W - 1] & 7u; }   // Extract_b, s2.cpp:96-98
+
+// E1: number of run heads (distinct keys) per tile
+template <int W>
+__global__ __launch_bounds__(kEmitThreads) void emit_mark_kernel(const Key<W> *keys, uint64_t n, uint32_t *tile_heads) {
+    __shared__ uint32_t s_cnt[kEmitThreads / 64];
+    uint64_t base = (uint64_t)blockIdx.x * kEmitTile;
+    uint32_t c = 0;
+    for (int it = 0; it < kEmitPerThread; ++it) {
+        uint64_t idx = base + (uint64_t)it * kEmitThreads + threadIdx.x;
+        bool head = false;
+        if (idx < n) head = idx == 0 || !keys_equal<W>(keys[idx], keys[idx - 1]);
+        c += (uint32_t)__popcll(__ballot(head));
+    }
+    if (lane_id() == 0) s_cnt[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kEmitThreads / 64; ++w) t += s_cnt[w];
+        tile_heads[blockIdx.x] = t;
+    }
+}
+
+// E2: write one descriptor per run: start index + (a | b<<3 | group_head<<6)
+template <int W>
+__global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, const uint64_t *tile_base,
+                                                                     uint64_t *sub_start, uint8_t *sub_info) {
+    __shared__ uint32_t s_cnt[kEmitPerThread * (kEmitThreads / 64)];
+    __shared__ uint32_t s_scr[kEmitThreads / 64 + 1];
+    uint64_t base = (uint64_t)blockIdx.x * kEmitTile;
+    const int lane = lane_id(), wv = wave_id();
+    uint32_t headbits = 0;
+    uint32_t rank_in_wave[kEmitPerThread];
+    uint8_t info[kEmitPerThread];
+#pragma unroll
+    for (int it = 0; it < kEmitPerThread; ++it) {
+        uint64_t idx = base + (uint64_t)it * kEmitThreads + threadIdx.x;
+        bool head = false;
+        info[it] = 0;
+        if (idx < n) {
+            Key<W> cur = keys[idx];
+            bool ghead = true;
+            if (idx == 0) head = true;
+            else {
+                Key<W> prv = keys[idx - 1];
+                head = !keys_equal<W>(cur, prv);
+                ghead = !same_km1<W>(cur, prv, k);
+            }
+            info[it] = (uint8_t)(key_a<W>(cur, k) | (key_b<W>(cur) << 3) | ((int)ghead << 6));
+        }
+        uint64_t bal = __ballot(head);
+        rank_in_wave[it] = (uint32_t)__popcll(bal & lanemask_lt());
+        headbits |= (uint32_t)head << it;
+        if (lane == 0) s_cnt[it * (kEmitThreads / 64) + wv] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    // exclusive scan of the 64 (iteration, wave) counts: order of keys = iteration-major, wave, lane
+    uint32_t v = threadIdx.x < kEmitPerThread * (kEmitThreads / 64) ? s_cnt[threadIdx.x] : 0;
+    uint32_t ex = block_excl_scan<kEmitThreads>(v, s_scr, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kEmitPerThread * (kEmitThreads / 64)) s_cnt[threadIdx.x] = ex;
+    __syncthreads();
+    uint64_t tb = tile_base[blockIdx.x];
+#pragma unroll
+    for (int it = 0; it < kEmitPerThread; ++it) {
+        if ((headbits >> it) & 1u) {
+            uint64_t idx = base + (uint64_t)it * kEmitThreads + threadIdx.x;
+            uint64_t s = tb + s_cnt[it * (kEmitThreads / 64) + wv] + rank_in_wave[it];
+            sub_start[s] = idx;
+            sub_info[s] = info[it];
+        }
+    }
+}
+
+// E3: decide every run (sub-group): the rules of output_(), cx1_read2sdbg_s2.cpp:763-834.
+// rec = w | last<<4 | tip<<5 | min(mult,255)<<8, or 0xFFFF when the run is suppressed.
+constexpr int kDecideThreads = 256;
+constexpr int kDecidePerThread = 4;
+constexpr int kDecideTile = kDecideThreads * kDecidePerThread;   // 1024 runs per workgroup, thread owns 4 consecutive
+
+__device__ __forceinline__ bool run_suppressed(int a, int b, int has_a, int has_b) {
+    return (a == kDollar && ((has_b >> b) & 1)) || (b == kDollar && ((has_a >> a) & 1));
+}
+
+__global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(const uint64_t *sub_start, const uint8_t *sub_info, uint64_t m,
+                                                                      uint64_t n_items, uint16_t *rec, uint32_t *cnt_e,
+                                                                      uint32_t *cnt_l, uint32_t *cnt_t) {
+    __shared__ uint32_t s_e[kDecideThreads / 64], s_l[kDecideThreads / 64], s_t[kDecideThreads / 64];
+    uint64_t s0 = (uint64_t)blockIdx.x * kDecideTile + (uint64_t)threadIdx.x * kDecidePerThread;
+    uint32_t ne = 0, nl = 0, nt = 0;
+    for (int q = 0; q < kDecidePerThread; ++q) {
+        uint64_t s = s0 + q;
+        if (s >= m) break;
+        int inf = sub_info[s];
+        int a = inf & 7, b = (inf >> 3) & 7;
+        // group extent [gs, ge): at most 24 runs share a (k-1)-mer
+        uint64_t gs = s;
+        while (!(sub_info[gs] & 64)) --gs;
+        uint64_t ge = s + 1;
+        while (ge < m && !(sub_info[ge] & 64)) ++ge;
+        int has_a = 0, has_b = 0;
+        for (uint64_t x = gs; x < ge; ++x) {
+            int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+            if (xa != kDollar && xb != kDollar) { has_a |= 1 << xa; has_b |= 1 << xb; }
+        }
+        uint16_t r = 0xFFFF;
+        if (!run_suppressed(a, b, has_a, has_b)) {
+            bool seen_b = false;                                   // outputed_b, s2.cpp:822-824
+            for (uint64_t x = gs; x < s; ++x) {
+                int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+                if (xb == b && !run_suppressed(xa, xb, has_a, has_b)) seen_b = true;
+            }
+            int w = (b == kDollar) ? 0 : (seen_b ? b + 5 : b + 1);
+            int last = 0;
+            if (a != kDollar) {                                    // last_a[], s2.cpp:776-779,823
+                bool later = false;
+                for (uint64_t x = s + 1; x < ge; ++x) {
+                    int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+                    if (xa == a && (xb != kDollar || !((has_a >> a) & 1))) later = true;
+                }
+                last = later ? 0 : 1;
+            }
+            uint64_t end = (s + 1 < m) ? sub_start[s + 1] : n_items;
+            uint64_t run = end - sub_start[s];
+            uint32_t count = run > 65535 ? 65535u : (uint32_t)run;  // kMaxMulti_t
+            int tip = a == kDollar;
+            r = (uint16_t)(w | (last << 4) | (tip << 5) | ((count > 255 ? 255u : count) << 8));
+            ne++;
+            nl += count > 254;                                      // kMaxMulti2_t, sdbg_multi_io.h:99
+            nt += tip;
+        }
+        rec[s] = r;
+    }
+    ne = wave_sum(ne); nl = wave_sum(nl); nt = wave_sum(nt);
+    if (lane_id() == 0) { s_e[wave_id()] = ne; s_l[wave_id()] = nl; s_t[wave_id()] = nt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t e = 0, l = 0, t = 0;
+        for (int w = 0; w < kDecideThreads / 64; ++w) { e += s_e[w]; l += s_l[w]; t += s_t[w]; }
+        cnt_e[blockIdx.x] = e; cnt_l[blockIdx.x] = l; cnt_t[blockIdx.x] = t;
+    }
+}
+
+// E5: order-preserving compaction into the output stream + per-bucket boundaries
+template <int W>
+__global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W> *keys, const uint64_t *sub_start, const uint16_t *rec,
+                                                                     uint64_t m, uint64_t n_items, const uint64_t *base_e,
+                                                                     const uint64_t *base_l, const uint64_t *base_t, int words_per_tip,
+                                                                     uint32_t b_lo, uint16_t *out_rec, uint16_t *out_large,
+                                                                     uint32_t *out_tips, int64_t *bucket_first /* [nb][3] */) {
+    __shared__ uint64_t s_scr[kDecideThreads / 64 + 1];
+    uint64_t s0 = (uint64_t)blockIdx.x * kDecideTile + (uint64_t)threadIdx.x * kDecidePerThread;
+    uint16_t r[kDecidePerThread];
+    uint64_t packed = 0;   // emitted | large << 20 | tips << 40
+    uint32_t cnts[kDecidePerThread];
+    for (int q = 0; q < kDecidePerThread; ++q) {
+        uint64_t s = s0 + q;
+        r[q] = 0xFFFF; cnts[q] = 0;
+        if (s < m) {
+            r[q] = rec[s];
+            if (r[q] != 0xFFFF) {
+                uint64_t end = (s + 1 < m) ? sub_start[s + 1] : n_items;
+                uint64_t run = end - sub_start[s];
+                cnts[q] = run > 65535 ? 65535u : (uint32_t)run;
+                packed += 1ull + ((uint64_t)(cnts[q] > 254) << 20) + ((uint64_t)((r[q] >> 5) & 1) << 40);
+            }
+        }
+    }
+    uint64_t ex = block_excl_scan64<kDecideThreads>(packed, s_scr, nullptr);
+    uint64_t ie = base_e[blockIdx.x] + (ex & 0xFFFFF), il = base_l[blockIdx.x] + ((ex >> 20) & 0xFFFFF),
+             it = base_t[blockIdx.x] + (ex >> 40);
+    for (int q = 0; q < kDecidePerThread; ++q) {
+        uint64_t s = s0 + q;
+        if (s >= m) break;
+        uint64_t first_item = sub_start[s];
+        uint32_t bucket = keys[first_item].w[0] >> 16;
+        bool boundary = s == 0;
+        if (s > 0) boundary = (keys[sub_start[s - 1]].w[0] >> 16) != bucket;
+        if (boundary) {                                            // number of records/large/tips before this bucket
+            int64_t *bf = bucket_first + (uint64_t)(bucket - b_lo) * 3;
+            bf[0] = (int64_t)ie; bf[1] = (int64_t)il; bf[2] = (int64_t)it;
+        }
+        if (r[q] != 0xFFFF) {
+            out_rec[ie++] = r[q];
+            if (cnts[q] > 254) out_large[il++] = (uint16_t)cnts[q];
+            if ((r[q] >> 5) & 1) {
+                for (int j = 0; j < words_per_tip; ++j) out_tips[it * words_per_tip + j] = keys[first_item].w[j];   // s2.cpp:826-830
+                it++;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+struct Timer {
+    hipEvent_t a, b;
+    hipStream_t st;
+    explicit Timer(hipStream_t s) : st(s) { MGTA_HIP_CHECK(hipEventCreate(&a)); MGTA_HIP_CHECK(hipEventCreate(&b)); }
+    ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    void start() { MGTA_HIP_CHECK(hipEventRecord(a, st)); }
+    double stop() {   // milliseconds, synchronises
+        MGTA_HIP_CHECK(hipEventRecord(b, st));
+        MGTA_HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        MGTA_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+};
+
+static std::vector<Digit> digit_plan(int k, int W) {
+    // key bits from the LSB: [0,4) flags, [4,4+pad) always zero, [4+pad, 32W) characters
+    std::vector<Digit> plan;
+    int pad = 32 * W - 2 * k - 4;
+    plan.push_back(Digit{0, 4});
+    for (int pos = 4 + pad; pos < 32 * W; pos += 8) plan.push_back(Digit{pos, std::min(8, 32 * W - pos)});
+    return plan;
+}
+
+template <int W>
+static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, mgta_edge_sink sink, void *user, mgta_build_stats *st) {
+    hipStream_t stream = ctx->stream;
+    MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+    const int words_per_tip = (2 * k + 31) / 32;                       // sdbg_multi_io.h:63
+    const uint64_t n_reads = rd->n_reads;
+    const uint64_t n_blocks = (n_reads + kReadsPerBlock - 1) / kReadsPerBlock;
+    if (n_blocks > 0x7FFFFFFFull) { set_error("too many reads for one launch"); return MGTA_EINVAL; }
+    mgta_build_stats S;
+    memset(&S, 0, sizeof(S));
+    S.k = k; S.words_per_key = W; S.words_per_tip = words_per_tip; S.n_reads = (int64_t)n_reads;
+    ctx->peak_bytes = ctx->live_bytes;
+
+    size_t free_b = 0, total_b = 0;
+    MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = ctx->mem_limit ? std::min<uint64_t>(ctx->mem_limit, free_b) : (uint64_t)(free_b * 0.9);
+
+    Timer t_all(stream), t_ph(stream), t_k(stream);
+    DevBuf d_block_count, d_block_base, d_scan_tmp, d_total, d_kmers;
+    d_block_count.alloc(std::max<uint64_t>(1, n_blocks) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+    d_block_base.alloc(std::max<uint64_t>(1, n_blocks) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+    d_scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(n_blocks, 1u << 22)) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+    d_total.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+    d_kmers.alloc(8, &ctx->live_bytes, &ctx->peak_bytes);
+    MGTA_HIP_CHECK(hipMemsetAsync(d_kmers.p, 0, 8, stream));
+
+    ScanArgs sa;
+    sa.packed = rd->d_packed; sa.n_words = rd->n_words; sa.start = rd->d_start; sa.n_reads = n_reads; sa.k = k;
+    sa.block_count = d_block_count.as<uint32_t>(); sa.block_base = d_block_base.as<uint64_t>(); sa.out = nullptr;
+    sa.n_kmers = d_kmers.as<unsigned long long>();
+
+    t_all.start();
+    const std::vector<Digit> plan = digit_plan(k, W);
+    int n_pass = 1;
+    uint32_t b_lo = 0;
+    bool first_pass = true;
+    std::vector<int64_t> h_first;
+    std::vector<uint16_t> h_rec, h_large;
+    std::vector<uint32_t> h_tips;
+    std::vector<int64_t> h_items;
+
+    while (b_lo < MGTA_NUM_BUCKETS) {
+        uint32_t width = (MGTA_NUM_BUCKETS + n_pass - 1) / n_pass;
+        uint32_t b_hi = std::min<uint32_t>(MGTA_NUM_BUCKETS, b_lo + width);
+        // ---- 1. count
+        t_ph.start();
+        sa.b_lo = b_lo; sa.b_hi = b_hi;
+        if (first_pass) MGTA_HIP_CHECK(hipMemsetAsync(d_kmers.p, 0, 8, stream));
+        else sa.n_kmers = nullptr;
+        if (n_blocks) hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+        exclusive_scan_u32(stream, d_block_count.as<uint32_t>(), n_blocks, d_block_base.as<uint64_t>(), d_scan_tmp.as<uint64_t>(),
+                           d_total.as<uint64_t>());
+        uint64_t n_items = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total.p, 8, hipMemcpyDeviceToHost, stream));
+        S.ms_count += t_ph.stop();
+        if (first_pass) {
+            unsigned long long km = 0;
+            MGTA_HIP_CHECK(hipMemcpy(&km, d_kmers.p, 8, hipMemcpyDeviceToHost));
+            S.n_kmers = (int64_t)km;
+        }
+        // does the pass fit?  two key buffers + emit scratch inside the second one
+        uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
+        uint64_t need = 2 * n_items * sizeof(Key<W>) + n_tiles * 256 * 8 + (64u << 20);
+        if (need > budget - std::min<uint64_t>(budget, ctx->live_bytes) && width > 1) {
+            n_pass *= 2;                                              // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
+            continue;
+        }
+        first_pass = false;
+        S.n_items += (int64_t)n_items;
+        S.n_passes++;
+        const uint32_t nb = b_hi - b_lo;
+        h_items.assign(nb * 3, 0);
+        uint64_t n_edges = 0, n_large = 0, n_tips = 0;
+        if (n_items > 0) {
+            DevBuf d_a, d_b, d_hist, d_totals;
+            d_a.alloc(n_items * sizeof(Key<W>), &ctx->live_bytes, &ctx->peak_bytes);
+            d_b.alloc(std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12), &ctx->live_bytes, &ctx->peak_bytes);
+            d_hist.alloc(n_tiles * 256 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            d_totals.alloc(256 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            // ---- 3. write keys
+            t_ph.start();
+            sa.out = d_a.p;
+            hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+            S.ms_gen += t_ph.stop();
+            // ---- 4. LSD radix sort
+            t_ph.start();
+            Key<W> *src = d_a.as<Key<W>>(), *dst = d_b.as<Key<W>>();
+            for (const Digit &dg : plan) {
+                hipLaunchKernelGGL((radix_census_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, n_items, dg,
+                                   n_tiles, d_hist.as<uint64_t>());
+                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist.as<uint64_t>(), n_tiles,
+                                   d_totals.as<uint64_t>());
+                MGTA_HIP_CHECK(hipEventRecord(t_k.a, stream));
+                hipLaunchKernelGGL((radix_scatter_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, dst, n_items,
+                                   dg, n_tiles, d_hist.as<uint64_t>(), d_totals.as<uint64_t>());
+                MGTA_HIP_CHECK(hipEventRecord(t_k.b, stream));
+                MGTA_HIP_CHECK(hipEventSynchronize(t_k.b));
+                float ms = 0;
+                MGTA_HIP_CHECK(hipEventElapsedTime(&ms, t_k.a, t_k.b));
+                S.ms_sort_scatter += ms;
+                S.n_sort_launches++;
+                std::swap(src, dst);
+            }
+            S.ms_sort += t_ph.stop();
+            d_hist.release();
+            // ---- 5. emit.  `src` holds the sorted keys; the other buffer is scratch.
+            t_ph.start();
+            const Key<W> *sorted = src;
+            char *scratch = reinterpret_cast<char *>(dst);
+            uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
+            DevBuf d_tile_heads, d_tile_base;
+            d_tile_heads.alloc(e_tiles * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tile_base.alloc(e_tiles * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            hipLaunchKernelGGL((emit_mark_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items,
+                               d_tile_heads.as<uint32_t>());
+            exclusive_scan_u32(stream, d_tile_heads.as<uint32_t>(), e_tiles, d_tile_base.as<uint64_t>(), d_scan_tmp.as<uint64_t>(),
+                               d_total.as<uint64_t>());
+            uint64_t m = 0;
+            MGTA_HIP_CHECK(hipMemcpyAsync(&m, d_total.p, 8, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            // scratch layout (<= 12 bytes per run <= 12 bytes per key): sub_start u64 | rec u16 | info u8
+            uint64_t *sub_start = reinterpret_cast<uint64_t *>(scratch);
+            uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + m * 8);
+            uint8_t *info = reinterpret_cast<uint8_t *>(scratch + m * 10);
+            hipLaunchKernelGGL((emit_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k,
+                               d_tile_base.as<uint64_t>(), sub_start, info);
+            uint64_t d_tiles = (m + kDecideTile - 1) / kDecideTile;
+            DevBuf d_cnt, d_base, d_tot3, d_first;
+            d_cnt.alloc(d_tiles * 4 * 3, &ctx->live_bytes, &ctx->peak_bytes);
+            d_base.alloc(d_tiles * 8 * 3, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tot3.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+            d_first.alloc((uint64_t)nb * 3 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_first.p, 0xFF, (uint64_t)nb * 3 * 8, stream));
+            uint32_t *ce = d_cnt.as<uint32_t>(), *cl = ce + d_tiles, *ct = cl + d_tiles;
+            uint64_t *be = d_base.as<uint64_t>(), *bl = be + d_tiles, *bt = bl + d_tiles;
+            hipLaunchKernelGGL(emit_decide_kernel, dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sub_start, info, m, n_items,
+                               rec, ce, cl, ct);
+            exclusive_scan_u32(stream, ce, d_tiles, be, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>());
+            exclusive_scan_u32(stream, cl, d_tiles, bl, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>() + 1);
+            exclusive_scan_u32(stream, ct, d_tiles, bt, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>() + 2);
+            uint64_t tot3[3];
+            MGTA_HIP_CHECK(hipMemcpyAsync(tot3, d_tot3.p, 24, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            n_edges = tot3[0]; n_large = tot3[1]; n_tips = tot3[2];
+            DevBuf d_out_rec, d_out_large, d_out_tips;
+            d_out_rec.alloc(n_edges * 2, &ctx->live_bytes, &ctx->peak_bytes);
+            d_out_large.alloc(n_large * 2, &ctx->live_bytes, &ctx->peak_bytes);
+            d_out_tips.alloc(n_tips * words_per_tip * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            hipLaunchKernelGGL((emit_write_kernel<W>), dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sorted, sub_start, rec, m,
+                               n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec.as<uint16_t>(), d_out_large.as<uint16_t>(),
+                               d_out_tips.as<uint32_t>(), d_first.as<int64_t>());
+            S.ms_emit += t_ph.stop();
+            // ---- device -> host
+            if (sink) {
+                t_ph.start();
+                h_rec.resize(n_edges); h_large.resize(n_large); h_tips.resize(n_tips * words_per_tip);
+                h_first.resize((size_t)nb * 3);
+                if (n_edges) MGTA_HIP_CHECK(hipMemcpyAsync(h_rec.data(), d_out_rec.p, n_edges * 2, hipMemcpyDeviceToHost, stream));
+                if (n_large) MGTA_HIP_CHECK(hipMemcpyAsync(h_large.data(), d_out_large.p, n_large * 2, hipMemcpyDeviceToHost, stream));
+                if (n_tips) MGTA_HIP_CHECK(hipMemcpyAsync(h_tips.data(), d_out_tips.p, n_tips * words_per_tip * 4, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipMemcpyAsync(h_first.data(), d_first.p, (size_t)nb * 3 * 8, hipMemcpyDeviceToHost, stream));
+                S.ms_d2h += t_ph.stop();
+                // bucket boundaries -> counts; untouched entries (-1) are empty buckets
+                int64_t nxt[3] = {(int64_t)n_edges, (int64_t)n_large, (int64_t)n_tips};
+                for (int64_t b = (int64_t)nb - 1; b >= 0; --b)
+                    for (int c = 0; c < 3; ++c) {
+                        int64_t f = h_first[(size_t)b * 3 + c];
+                        if (f < 0) f = nxt[c];
+                        h_items[(size_t)b * 3 + c] = nxt[c] - f;
+                        nxt[c] = f;
+                    }
+            }
+        } else {
+            h_rec.clear(); h_large.clear(); h_tips.clear();
+        }
+        S.n_edges += (int64_t)n_edges; S.n_large += (int64_t)n_large; S.n_tips += (int64_t)n_tips;
+        if (sink) {
+            int rc = sink(user, (int32_t)b_lo, (int32_t)b_hi, h_items.data(), h_rec.data(), (int64_t)n_edges, h_large.data(),
+                          (int64_t)n_large, h_tips.data(), (int64_t)(n_tips * words_per_tip));
+            if (rc != 0) { set_error("edge sink returned %d", rc); return MGTA_ESINK; }
+        }
+        b_lo = b_hi;
+    }
+    S.ms_total = t_all.stop();
+    S.bytes_peak = ctx->peak_bytes;
+    if (st) *st = S;
+    return MGTA_OK;
+}
+
+}  // namespace mgta
+
+using namespace mgta;
+
+extern "C" {
+
+int mgta_reads_upload(mgta_ctx *ctx, const uint32_t *packed, uint64_t n_words, const uint64_t *start_idx, uint64_t n_reads,
+                      mgta_reads **out) {
+    if (!ctx || !packed || !start_idx || !out) { set_error("mgta_reads_upload: null argument"); return MGTA_EINVAL; }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        auto r = std::make_unique<mgta_reads>();
+        r->ctx = ctx; r->n_words = n_words; r->n_reads = n_reads;
+        r->own_packed.alloc((n_words + 16) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+        r->own_start.alloc((n_reads + 1) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+        MGTA_HIP_CHECK(hipMemsetAsync((char *)r->own_packed.p + n_words * 4, 0, 64, ctx->stream));
+        MGTA_HIP_CHECK(hipMemcpyAsync(r->own_packed.p, packed, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+        MGTA_HIP_CHECK(hipMemcpyAsync(r->own_start.p, start_idx, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        r->d_packed = r->own_packed.as<uint32_t>();
+        r->d_start = r->own_start.as<uint64_t>();
+        *out = r.release();
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_reads_adopt_device(mgta_ctx *ctx, const uint32_t *d_packed, uint64_t n_words, const uint64_t *d_start, uint64_t n_reads,
+                            mgta_reads **out) {
+    if (!ctx || !d_packed || !d_start || !out) { set_error("mgta_reads_adopt_device: null argument"); return MGTA_EINVAL; }
+    auto *r = new mgta_reads;
+    r->ctx = ctx; r->d_packed = d_packed; r->d_start = d_start; r->n_words = n_words; r->n_reads = n_reads;
+    *out = r;
+    return MGTA_OK;
+}
+
+void mgta_reads_free(mgta_reads *r) { delete r; }
+
+int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short_reads, int k, int min_count, int need_mercy,
+                             mgta_edge_sink sink, void *user, mgta_build_stats *stats) {
+    (void)n_short_reads;   // with min_count == 1 every position of every sequence is solid (s2.cpp:276)
+    if (!ctx || !rd) { set_error("mgta_sdbg_build: null argument"); return MGTA_EINVAL; }
+    if (k < 9 || k > 127) { set_error("k=%d out of range [9,127] (kMaxK, definitions.h:56)", k); return MGTA_EINVAL; }
+    if (min_count != 1 || need_mercy) {
+        set_error("min_count=%d need_mercy=%d: stage 1 (solid-edge counting, cx1_read2sdbg_s1.cpp) is not built yet", min_count, need_mercy);
+        return MGTA_EUNSUPPORTED;
+    }
+    try {
+        int W = (2 * k + 4 + 31) / 32;                                 // words_per_substring, s2.cpp:331
+        switch (W) {
+        case 1: return build_impl<1>(ctx, rd, k, sink, user, stats);
+        case 2: return build_impl<2>(ctx, rd, k, sink, user, stats);
+        case 3: return build_impl<3>(ctx, rd, k, sink, user, stats);
+        case 4: return build_impl<4>(ctx, rd, k, sink, user, stats);
+        case 5: return build_impl<5>(ctx, rd, k, sink, user, stats);
+        case 6: return build_impl<6>(ctx, rd, k, sink, user, stats);
+        case 7: return build_impl<7>(ctx, rd, k, sink, user, stats);
+        case 8: return build_impl<8>(ctx, rd, k, sink, user, stats);
+        default: return build_impl<9>(ctx, rd, k, sink, user, stats);
+        }
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_build(mgta_ctx *ctx, const uint32_t *packed, uint64_t n_words, const uint64_t *start_idx, uint64_t n_reads,
+                    uint64_t n_short_reads, int k, int min_count, int need_mercy, mgta_edge_sink sink, void *user,
+                    mgta_build_stats *stats) {
+    mgta_reads *rd = nullptr;
+    int rc = mgta_reads_upload(ctx, packed, n_words, start_idx, n_reads, &rd);
+    if (rc != MGTA_OK) return rc;
+    rc = mgta_sdbg_build_resident(ctx, rd, n_short_reads, k, min_count, need_mercy, sink, user, stats);
+    mgta_reads_free(rd);
+    return rc;
+}
+
+}  // extern "C"

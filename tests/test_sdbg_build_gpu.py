@@ -1,0 +1,127 @@
+"""Parity of the HIP SdBG build (through the C ABI) against the CPU oracle and the golden vectors.
+Bar: the logical edge stream is BIT-EXACT (records, large multiplicities, tip labels, bucket sizes)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from megagta_amd import readlib, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from megagta_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _same(gpu, orc):
+    assert gpu.k == orc.k and gpu.words_per_tip == orc.words_per_tip
+    assert np.array_equal(gpu.bucket_items, orc.bucket_items)
+    assert np.array_equal(gpu.records, orc.records)
+    assert np.array_equal(gpu.large, orc.large)
+    assert np.array_equal(gpu.tips, orc.tips)
+    assert gpu.md5() == orc.md5()
+
+
+@pytest.mark.parametrize("k", [29, 35, 44])
+def test_toy_vs_oracle_and_golden(ctx, oracle, golden_dir, k):
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    g = ctx.build_sdbg(rd, k)
+    o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    _same(g, o)
+    fx = H.load_streams(os.path.join(golden_dir, "toy", "sdbg_streams.json"))[str(k)]
+    assert g.md5() == fx["md5"]                           # == the reference's buildgraph output
+    assert g.stats["n_items"] == o.n_items_sorted
+    assert g.stats["n_kmers"] == 6000 * (150 - k)
+    # bucket-level tip / large counts agree with a decode of the stream
+    assert g.bucket_tips.sum() == ((g.records >> 5) & 1).sum() and g.bucket_large.sum() == g.large.size
+
+
+@pytest.mark.parametrize("k", [21, 29, 31, 44, 47, 63])
+def test_ragged_edge_cases(ctx, golden_dir, k):
+    """ragged lengths, reads shorter than k+1, N->G, palindromic (k+1)-mers, multiplicity > 254, W = 2..5 words"""
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "ragged", "reads.lib"))
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    fx = H.load_streams(os.path.join(golden_dir, "ragged", "sdbg_streams.json"))[str(k)]
+    assert g.md5() == fx["md5"]
+    assert [int(x) for x in g.records[:256]] == fx["head_records"]
+
+
+@pytest.mark.parametrize("k", [15, 30, 46, 79, 95, 127])
+def test_key_width_sweep(ctx, oracle, k):
+    """every key width W = 2..9 incl. the widths where 2k+4 fills the last word exactly (k = 30, 46)"""
+    rng = np.random.default_rng(k)
+    genome = rng.integers(0, 4, 4000).astype(np.uint8)
+    reads = []
+    for _ in range(300):
+        L = int(rng.integers(k - 3, 260))
+        p = int(rng.integers(0, 4000 - L))
+        r = genome[p:p + L].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    _same(g, o)
+
+
+def test_empty_and_degenerate(ctx, oracle):
+    # no read long enough -> empty stream, 65536 empty buckets
+    reads = [np.zeros(10, np.uint8), np.ones(30, np.uint8)]
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    assert g.records.size == 0 and g.bucket_items.sum() == 0 and g.stats["n_items"] == 0
+    # a single read of exactly k+1 bases; a homopolymer (palindromic for A/T only when rc == self: poly-A vs poly-T differ)
+    reads = [np.array([0, 1, 2, 3] * 8, np.uint8)[:30], np.zeros(64, np.uint8)]
+    packed, start = readlib.pack_for_build(reads)
+    _same(ctx.build_sdbg(ctx.upload_reads(packed, start), 29), oracle.Stream.build(packed, start, 29).edges())
+
+
+def test_multi_pass_bucket_ranges(ctx, oracle, golden_dir):
+    """a small memory limit forces several bucket-range passes (the analogue of CX1's lv1 loop, cx1.h:494)"""
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    c2 = api.Context(0)
+    c2.set_mem_limit(96 << 20)
+    g = c2.build_sdbg(c2.upload_reads(packed, start), 44)
+    assert g.stats["n_passes"] > 1
+    fx = H.load_streams(os.path.join(golden_dir, "toy", "sdbg_streams.json"))["44"]
+    assert g.md5() == fx["md5"]
+    c2.close()
+
+
+def test_larger_synthetic_properties(ctx, oracle):
+    """100k x 150 bp (BASELINE config 1 size): oracle parity + size-independent properties"""
+    mg = synth.make_metagenome(100_000, 150, (("rplB", 277),), seed=3)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    k = 29
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    o = oracle.Stream.build(packed, start, k, threads=8).edges()
+    _same(g, o)
+    # multiplicities of all records account for every sorted item that was not $-suppressed: upper bound
+    mult = (g.records >> 8).astype(np.int64)
+    assert mult.sum() <= g.stats["n_items"]
+    # `last` flags: one per distinct node with an outgoing a != $  => count(last) <= edges, > 0
+    assert 0 < ((g.records >> 4) & 1).sum() <= g.records.size
+    # W never exceeds 8; tips have last == 0
+    assert (g.records & 15).max() <= 8
+    tip = ((g.records >> 5) & 1).astype(bool)
+    assert (((g.records >> 4) & 1)[tip] == 0).all()
+
+
+def test_no_device_path_is_loud():
+    """min_count > 1 is not built yet: must fail loudly, never fall back"""
+    from megagta_amd import api
+    c = api.Context(0)
+    rd = c.upload_reads(np.zeros(4, np.uint32), np.array([0, 60], np.uint64))
+    with pytest.raises(api.MegaGtaError):
+        c.build_sdbg(rd, 29, min_count=2)
+    c.close()
