@@ -87,7 +87,8 @@ void mgta_reads_free(mgta_reads *);
  * n_short_reads: reads [n_short_reads, n_reads) are assist sequences (always solid, s2.cpp:276).
  * sink may be NULL (records stay on the device, e.g. for timing). */
 int mgta_sdbg_build_resident(mgta_ctx *, const mgta_reads *, uint64_t n_short_reads, int k, int min_count,
-                             int need_mercy, mgta_edge_sink sink, void *user, mgta_build_stats *stats);
+                             int need_mercy, int32_t bucket_begin, int32_t bucket_end /* this GPU's share of the 65536 buckets */,
+                             mgta_edge_sink sink, void *user, mgta_build_stats *stats);
 /* convenience: upload + build + free */
 int mgta_sdbg_build(mgta_ctx *, const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx,
                     uint64_t n_reads, uint64_t n_short_reads, int k, int min_count, int need_mercy,

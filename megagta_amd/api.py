@@ -79,7 +79,7 @@ class Context:
         return r
 
     def build_sdbg(self, reads: "Reads", k: int, min_count: int = 1, need_mercy: bool = False, collect: bool = True,
-                   n_short_reads: int | None = None) -> EdgeStream:
+                   n_short_reads: int | None = None, bucket_range: tuple[int, int] = (0, NUM_BUCKETS)) -> EdgeStream:
         """Reads resident on the device -> edge stream (collect=False keeps it on the device: timing runs)."""
         wpt = (2 * k + 31) // 32
         recs, large, tips = [], [], []
@@ -96,7 +96,8 @@ class Context:
         cb = _lib.EDGE_SINK(sink) if collect else C.cast(None, _lib.EDGE_SINK)
         st = _lib.BuildStats()
         ns = reads.n_reads if n_short_reads is None else n_short_reads
-        check(self._L.mgta_sdbg_build_resident(self.h, reads.h, ns, k, min_count, int(need_mercy), cb, None, C.byref(st)),
+        check(self._L.mgta_sdbg_build_resident(self.h, reads.h, ns, k, min_count, int(need_mercy), bucket_range[0], bucket_range[1],
+                                               cb, None, C.byref(st)),
               "mgta_sdbg_build_resident")
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
         return EdgeStream(k=k, words_per_tip=wpt, bucket_items=counts[:, 0].copy(), records=cat(recs, np.uint16),

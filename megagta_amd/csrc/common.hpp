@@ -65,6 +65,7 @@ struct mgta_ctx {
     uint64_t live_bytes = 0, peak_bytes = 0;
     int num_cus = 256;
     hipDeviceProp_t prop;
+    std::vector<mgta::DevBuf> pool;   // grow-only scratch kept between calls
 };
 
 struct mgta_reads {

@@ -618,8 +618,30 @@ static std::vector<Digit> digit_plan(int k, int W) {
     return plan;
 }
 
+// grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
+// hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
+enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_NUM };
+
+template <class T>
+static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
+    if ((int)ctx->pool.size() < S_NUM) ctx->pool.resize(S_NUM);
+    DevBuf &b = ctx->pool[slot];
+    if (b.bytes < bytes || !b.p) {
+        b.release();
+        b.alloc(bytes + bytes / 16, &ctx->live_bytes, &ctx->peak_bytes);
+    }
+    return b.as<T>();
+}
+static uint64_t pool_bytes(const mgta_ctx *ctx) {
+    uint64_t t = 0;
+    for (const DevBuf &b : ctx->pool) t += b.bytes;
+    return t;
+}
+
 template <int W>
-static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, mgta_edge_sink sink, void *user, mgta_build_stats *st) {
+static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucket_begin, uint32_t bucket_end, mgta_edge_sink sink,
+                      void *user, mgta_build_stats *st) {
     hipStream_t stream = ctx->stream;
     MGTA_HIP_CHECK(hipSetDevice(ctx->device));
     const int words_per_tip = (2 * k + 31) / 32;                       // sdbg_multi_io.h:63
@@ -633,55 +655,58 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, mgta_edge_sink
 
     size_t free_b = 0, total_b = 0;
     MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = ctx->mem_limit ? std::min<uint64_t>(ctx->mem_limit, free_b) : (uint64_t)(free_b * 0.9);
+    // what the build may hold: the explicit limit, else 90 % of (free + what our pool already holds)
+    uint64_t avail = (uint64_t)free_b + pool_bytes(ctx);
+    uint64_t budget = ctx->mem_limit ? std::min<uint64_t>(ctx->mem_limit, avail) : (uint64_t)(avail * 0.9);
 
-    Timer t_all(stream), t_ph(stream), t_k(stream);
-    DevBuf d_block_count, d_block_base, d_scan_tmp, d_total, d_kmers;
-    d_block_count.alloc(std::max<uint64_t>(1, n_blocks) * 4, &ctx->live_bytes, &ctx->peak_bytes);
-    d_block_base.alloc(std::max<uint64_t>(1, n_blocks) * 8, &ctx->live_bytes, &ctx->peak_bytes);
-    d_scan_tmp.alloc(scan_tmp_elems(std::max<uint64_t>(n_blocks, 1u << 22)) * 8, &ctx->live_bytes, &ctx->peak_bytes);
-    d_total.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-    d_kmers.alloc(8, &ctx->live_bytes, &ctx->peak_bytes);
-    MGTA_HIP_CHECK(hipMemsetAsync(d_kmers.p, 0, 8, stream));
+    Timer t_all(stream), t_ph(stream);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
+    uint32_t *d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
+    uint64_t *d_block_base = pool_get<uint64_t>(ctx, S_BLOCK_BASE, std::max<uint64_t>(1, n_blocks) * 8);
+    uint64_t *d_small = pool_get<uint64_t>(ctx, S_SMALL, 4096);       // [0] total, [1] kmers, [2..4] emit totals, [8..263] digit totals
+    uint64_t *d_total = d_small, *d_kmers = d_small + 1, *d_tot3 = d_small + 2, *d_totals = d_small + 8;
 
     ScanArgs sa;
     sa.packed = rd->d_packed; sa.n_words = rd->n_words; sa.start = rd->d_start; sa.n_reads = n_reads; sa.k = k;
-    sa.block_count = d_block_count.as<uint32_t>(); sa.block_base = d_block_base.as<uint64_t>(); sa.out = nullptr;
-    sa.n_kmers = d_kmers.as<unsigned long long>();
+    sa.block_count = d_block_count; sa.block_base = d_block_base; sa.out = nullptr;
+    sa.n_kmers = (unsigned long long *)d_kmers;
 
     t_all.start();
     const std::vector<Digit> plan = digit_plan(k, W);
     int n_pass = 1;
-    uint32_t b_lo = 0;
+    uint32_t b_lo = bucket_begin;
+    const uint32_t span = bucket_end - bucket_begin;
     bool first_pass = true;
     std::vector<int64_t> h_first;
     std::vector<uint16_t> h_rec, h_large;
     std::vector<uint32_t> h_tips;
     std::vector<int64_t> h_items;
 
-    while (b_lo < MGTA_NUM_BUCKETS) {
-        uint32_t width = (MGTA_NUM_BUCKETS + n_pass - 1) / n_pass;
-        uint32_t b_hi = std::min<uint32_t>(MGTA_NUM_BUCKETS, b_lo + width);
+    while (b_lo < bucket_end) {
+        uint32_t width = (span + n_pass - 1) / n_pass;
+        uint32_t b_hi = std::min<uint32_t>(bucket_end, b_lo + width);
         // ---- 1. count
         t_ph.start();
         sa.b_lo = b_lo; sa.b_hi = b_hi;
-        if (first_pass) MGTA_HIP_CHECK(hipMemsetAsync(d_kmers.p, 0, 8, stream));
+        if (first_pass) MGTA_HIP_CHECK(hipMemsetAsync(d_kmers, 0, 8, stream));
         else sa.n_kmers = nullptr;
+        uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
         if (n_blocks) hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
-        exclusive_scan_u32(stream, d_block_count.as<uint32_t>(), n_blocks, d_block_base.as<uint64_t>(), d_scan_tmp.as<uint64_t>(),
-                           d_total.as<uint64_t>());
+        exclusive_scan_u32(stream, d_block_count, n_blocks, d_block_base, d_scan_tmp, d_total);
         uint64_t n_items = 0;
-        MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total.p, 8, hipMemcpyDeviceToHost, stream));
+        MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, stream));
         S.ms_count += t_ph.stop();
         if (first_pass) {
             unsigned long long km = 0;
-            MGTA_HIP_CHECK(hipMemcpy(&km, d_kmers.p, 8, hipMemcpyDeviceToHost));
+            MGTA_HIP_CHECK(hipMemcpy(&km, d_kmers, 8, hipMemcpyDeviceToHost));
             S.n_kmers = (int64_t)km;
         }
-        // does the pass fit?  two key buffers + emit scratch inside the second one
+        // does the pass fit?  two key buffers (the second doubles as emit scratch) + census + outputs (estimate)
         uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
-        uint64_t need = 2 * n_items * sizeof(Key<W>) + n_tiles * 256 * 8 + (64u << 20);
-        if (need > budget - std::min<uint64_t>(budget, ctx->live_bytes) && width > 1) {
+        uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12);
+        uint64_t need = n_items * sizeof(Key<W>) + key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
+        uint64_t other = ctx->live_bytes - pool_bytes(ctx);
+        if (need + need / 8 > budget - std::min<uint64_t>(budget, other) && width > 1) {
             n_pass *= 2;                                              // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
             continue;
         }
@@ -689,96 +714,84 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, mgta_edge_sink
         S.n_items += (int64_t)n_items;
         S.n_passes++;
         const uint32_t nb = b_hi - b_lo;
-        h_items.assign(nb * 3, 0);
+        h_items.assign((size_t)nb * 3, 0);
         uint64_t n_edges = 0, n_large = 0, n_tips = 0;
         if (n_items > 0) {
-            DevBuf d_a, d_b, d_hist, d_totals;
-            d_a.alloc(n_items * sizeof(Key<W>), &ctx->live_bytes, &ctx->peak_bytes);
-            d_b.alloc(std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12), &ctx->live_bytes, &ctx->peak_bytes);
-            d_hist.alloc(n_tiles * 256 * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            d_totals.alloc(256 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            Key<W> *d_a = pool_get<Key<W>>(ctx, S_KEYS_A, n_items * sizeof(Key<W>));
+            Key<W> *d_b = pool_get<Key<W>>(ctx, S_KEYS_B, key_b);
+            uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, n_tiles * 256 * 8);
             // ---- 3. write keys
             t_ph.start();
-            sa.out = d_a.p;
+            sa.out = d_a;
             hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             S.ms_gen += t_ph.stop();
             // ---- 4. LSD radix sort
             t_ph.start();
-            Key<W> *src = d_a.as<Key<W>>(), *dst = d_b.as<Key<W>>();
+            Key<W> *src = d_a, *dst = d_b;
             for (const Digit &dg : plan) {
                 hipLaunchKernelGGL((radix_census_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, n_items, dg,
-                                   n_tiles, d_hist.as<uint64_t>());
-                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist.as<uint64_t>(), n_tiles,
-                                   d_totals.as<uint64_t>());
-                MGTA_HIP_CHECK(hipEventRecord(t_k.a, stream));
+                                   n_tiles, d_hist);
+                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, n_tiles, d_totals);
+                hipEvent_t e0, e1;
+                MGTA_HIP_CHECK(hipEventCreate(&e0));
+                MGTA_HIP_CHECK(hipEventCreate(&e1));
+                MGTA_HIP_CHECK(hipEventRecord(e0, stream));
                 hipLaunchKernelGGL((radix_scatter_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, dst, n_items,
-                                   dg, n_tiles, d_hist.as<uint64_t>(), d_totals.as<uint64_t>());
-                MGTA_HIP_CHECK(hipEventRecord(t_k.b, stream));
-                MGTA_HIP_CHECK(hipEventSynchronize(t_k.b));
-                float ms = 0;
-                MGTA_HIP_CHECK(hipEventElapsedTime(&ms, t_k.a, t_k.b));
-                S.ms_sort_scatter += ms;
+                                   dg, n_tiles, d_hist, d_totals);
+                MGTA_HIP_CHECK(hipEventRecord(e1, stream));
+                scatter_ev.emplace_back(e0, e1);
                 S.n_sort_launches++;
                 std::swap(src, dst);
             }
             S.ms_sort += t_ph.stop();
-            d_hist.release();
             // ---- 5. emit.  `src` holds the sorted keys; the other buffer is scratch.
             t_ph.start();
             const Key<W> *sorted = src;
             char *scratch = reinterpret_cast<char *>(dst);
             uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
-            DevBuf d_tile_heads, d_tile_base;
-            d_tile_heads.alloc(e_tiles * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tile_base.alloc(e_tiles * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            hipLaunchKernelGGL((emit_mark_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items,
-                               d_tile_heads.as<uint32_t>());
-            exclusive_scan_u32(stream, d_tile_heads.as<uint32_t>(), e_tiles, d_tile_base.as<uint64_t>(), d_scan_tmp.as<uint64_t>(),
-                               d_total.as<uint64_t>());
+            uint32_t *d_tile_heads = pool_get<uint32_t>(ctx, S_TILE_HEADS, e_tiles * 4);
+            uint64_t *d_tile_base = pool_get<uint64_t>(ctx, S_TILE_BASE, e_tiles * 8);
+            d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(std::max(n_blocks, e_tiles), n_items / kDecideTile + 1)) * 8);
+            hipLaunchKernelGGL((emit_mark_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, d_tile_heads);
+            exclusive_scan_u32(stream, d_tile_heads, e_tiles, d_tile_base, d_scan_tmp, d_total);
             uint64_t m = 0;
-            MGTA_HIP_CHECK(hipMemcpyAsync(&m, d_total.p, 8, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, stream));
             MGTA_HIP_CHECK(hipStreamSynchronize(stream));
             // scratch layout (<= 12 bytes per run <= 12 bytes per key): sub_start u64 | rec u16 | info u8
             uint64_t *sub_start = reinterpret_cast<uint64_t *>(scratch);
             uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + m * 8);
             uint8_t *info = reinterpret_cast<uint8_t *>(scratch + m * 10);
             hipLaunchKernelGGL((emit_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k,
-                               d_tile_base.as<uint64_t>(), sub_start, info);
+                               d_tile_base, sub_start, info);
             uint64_t d_tiles = (m + kDecideTile - 1) / kDecideTile;
-            DevBuf d_cnt, d_base, d_tot3, d_first;
-            d_cnt.alloc(d_tiles * 4 * 3, &ctx->live_bytes, &ctx->peak_bytes);
-            d_base.alloc(d_tiles * 8 * 3, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tot3.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-            d_first.alloc((uint64_t)nb * 3 * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_first.p, 0xFF, (uint64_t)nb * 3 * 8, stream));
-            uint32_t *ce = d_cnt.as<uint32_t>(), *cl = ce + d_tiles, *ct = cl + d_tiles;
-            uint64_t *be = d_base.as<uint64_t>(), *bl = be + d_tiles, *bt = bl + d_tiles;
+            uint32_t *ce = pool_get<uint32_t>(ctx, S_CNT, d_tiles * 4 * 3), *cl = ce + d_tiles, *ct = cl + d_tiles;
+            uint64_t *be = pool_get<uint64_t>(ctx, S_BASE, d_tiles * 8 * 3), *bl = be + d_tiles, *bt = bl + d_tiles;
+            int64_t *d_first = pool_get<int64_t>(ctx, S_FIRST, (uint64_t)MGTA_NUM_BUCKETS * 3 * 8);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_first, 0xFF, (uint64_t)nb * 3 * 8, stream));
             hipLaunchKernelGGL(emit_decide_kernel, dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sub_start, info, m, n_items,
                                rec, ce, cl, ct);
-            exclusive_scan_u32(stream, ce, d_tiles, be, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>());
-            exclusive_scan_u32(stream, cl, d_tiles, bl, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>() + 1);
-            exclusive_scan_u32(stream, ct, d_tiles, bt, d_scan_tmp.as<uint64_t>(), d_tot3.as<uint64_t>() + 2);
+            exclusive_scan_u32(stream, ce, d_tiles, be, d_scan_tmp, d_tot3);
+            exclusive_scan_u32(stream, cl, d_tiles, bl, d_scan_tmp, d_tot3 + 1);
+            exclusive_scan_u32(stream, ct, d_tiles, bt, d_scan_tmp, d_tot3 + 2);
             uint64_t tot3[3];
-            MGTA_HIP_CHECK(hipMemcpyAsync(tot3, d_tot3.p, 24, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipMemcpyAsync(tot3, d_tot3, 24, hipMemcpyDeviceToHost, stream));
             MGTA_HIP_CHECK(hipStreamSynchronize(stream));
             n_edges = tot3[0]; n_large = tot3[1]; n_tips = tot3[2];
-            DevBuf d_out_rec, d_out_large, d_out_tips;
-            d_out_rec.alloc(n_edges * 2, &ctx->live_bytes, &ctx->peak_bytes);
-            d_out_large.alloc(n_large * 2, &ctx->live_bytes, &ctx->peak_bytes);
-            d_out_tips.alloc(n_tips * words_per_tip * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            uint16_t *d_out_rec = pool_get<uint16_t>(ctx, S_OUT_REC, n_edges * 2);
+            uint16_t *d_out_large = pool_get<uint16_t>(ctx, S_OUT_LARGE, n_large * 2);
+            uint32_t *d_out_tips = pool_get<uint32_t>(ctx, S_OUT_TIPS, n_tips * words_per_tip * 4);
             hipLaunchKernelGGL((emit_write_kernel<W>), dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sorted, sub_start, rec, m,
-                               n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec.as<uint16_t>(), d_out_large.as<uint16_t>(),
-                               d_out_tips.as<uint32_t>(), d_first.as<int64_t>());
+                               n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec, d_out_large, d_out_tips, d_first);
             S.ms_emit += t_ph.stop();
             // ---- device -> host
             if (sink) {
                 t_ph.start();
                 h_rec.resize(n_edges); h_large.resize(n_large); h_tips.resize(n_tips * words_per_tip);
                 h_first.resize((size_t)nb * 3);
-                if (n_edges) MGTA_HIP_CHECK(hipMemcpyAsync(h_rec.data(), d_out_rec.p, n_edges * 2, hipMemcpyDeviceToHost, stream));
-                if (n_large) MGTA_HIP_CHECK(hipMemcpyAsync(h_large.data(), d_out_large.p, n_large * 2, hipMemcpyDeviceToHost, stream));
-                if (n_tips) MGTA_HIP_CHECK(hipMemcpyAsync(h_tips.data(), d_out_tips.p, n_tips * words_per_tip * 4, hipMemcpyDeviceToHost, stream));
-                MGTA_HIP_CHECK(hipMemcpyAsync(h_first.data(), d_first.p, (size_t)nb * 3 * 8, hipMemcpyDeviceToHost, stream));
+                if (n_edges) MGTA_HIP_CHECK(hipMemcpyAsync(h_rec.data(), d_out_rec, n_edges * 2, hipMemcpyDeviceToHost, stream));
+                if (n_large) MGTA_HIP_CHECK(hipMemcpyAsync(h_large.data(), d_out_large, n_large * 2, hipMemcpyDeviceToHost, stream));
+                if (n_tips) MGTA_HIP_CHECK(hipMemcpyAsync(h_tips.data(), d_out_tips, n_tips * words_per_tip * 4, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipMemcpyAsync(h_first.data(), d_first, (size_t)nb * 3 * 8, hipMemcpyDeviceToHost, stream));
                 S.ms_d2h += t_ph.stop();
                 // bucket boundaries -> counts; untouched entries (-1) are empty buckets
                 int64_t nxt[3] = {(int64_t)n_edges, (int64_t)n_large, (int64_t)n_tips};
@@ -802,6 +815,12 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, mgta_edge_sink
         b_lo = b_hi;
     }
     S.ms_total = t_all.stop();
+    for (auto &ev : scatter_ev) {
+        float ms = 0;
+        MGTA_HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        S.ms_sort_scatter += ms;
+        (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+    }
     S.bytes_peak = ctx->peak_bytes;
     if (st) *st = S;
     return MGTA_OK;
@@ -845,10 +864,14 @@ int mgta_reads_adopt_device(mgta_ctx *ctx, const uint32_t *d_packed, uint64_t n_
 void mgta_reads_free(mgta_reads *r) { delete r; }
 
 int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short_reads, int k, int min_count, int need_mercy,
-                             mgta_edge_sink sink, void *user, mgta_build_stats *stats) {
+                             int32_t bucket_begin, int32_t bucket_end, mgta_edge_sink sink, void *user, mgta_build_stats *stats) {
     (void)n_short_reads;   // with min_count == 1 every position of every sequence is solid (s2.cpp:276)
     if (!ctx || !rd) { set_error("mgta_sdbg_build: null argument"); return MGTA_EINVAL; }
     if (k < 9 || k > 127) { set_error("k=%d out of range [9,127] (kMaxK, definitions.h:56)", k); return MGTA_EINVAL; }
+    if (bucket_begin < 0 || bucket_end > MGTA_NUM_BUCKETS || bucket_begin >= bucket_end) {
+        set_error("bucket range [%d,%d) invalid", bucket_begin, bucket_end);
+        return MGTA_EINVAL;
+    }
     if (min_count != 1 || need_mercy) {
         set_error("min_count=%d need_mercy=%d: stage 1 (solid-edge counting, cx1_read2sdbg_s1.cpp) is not built yet", min_count, need_mercy);
         return MGTA_EUNSUPPORTED;
@@ -856,15 +879,15 @@ int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_sho
     try {
         int W = (2 * k + 4 + 31) / 32;                                 // words_per_substring, s2.cpp:331
         switch (W) {
-        case 1: return build_impl<1>(ctx, rd, k, sink, user, stats);
-        case 2: return build_impl<2>(ctx, rd, k, sink, user, stats);
-        case 3: return build_impl<3>(ctx, rd, k, sink, user, stats);
-        case 4: return build_impl<4>(ctx, rd, k, sink, user, stats);
-        case 5: return build_impl<5>(ctx, rd, k, sink, user, stats);
-        case 6: return build_impl<6>(ctx, rd, k, sink, user, stats);
-        case 7: return build_impl<7>(ctx, rd, k, sink, user, stats);
-        case 8: return build_impl<8>(ctx, rd, k, sink, user, stats);
-        default: return build_impl<9>(ctx, rd, k, sink, user, stats);
+        case 1: return build_impl<1>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 2: return build_impl<2>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 3: return build_impl<3>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 4: return build_impl<4>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 5: return build_impl<5>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 6: return build_impl<6>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 7: return build_impl<7>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 8: return build_impl<8>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        default: return build_impl<9>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
         }
     } catch (const HipError &e) { return e.code; }
 }
@@ -875,7 +898,7 @@ int mgta_sdbg_build(mgta_ctx *ctx, const uint32_t *packed, uint64_t n_words, con
     mgta_reads *rd = nullptr;
     int rc = mgta_reads_upload(ctx, packed, n_words, start_idx, n_reads, &rd);
     if (rc != MGTA_OK) return rc;
-    rc = mgta_sdbg_build_resident(ctx, rd, n_short_reads, k, min_count, need_mercy, sink, user, stats);
+    rc = mgta_sdbg_build_resident(ctx, rd, n_short_reads, k, min_count, need_mercy, 0, MGTA_NUM_BUCKETS, sink, user, stats);
     mgta_reads_free(rd);
     return rc;
 }

@@ -113,9 +113,15 @@ def pack_reads_for_build(reads: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
     (`buildgraph` loads the library with is_reverse=true: cx1_read2sdbg_s1.cpp:97,117).
     Returns (packed uint32 words, start_idx uint64[n+1] in bases)."""
     n, L = reads.shape
-    rev = reads[:, ::-1].reshape(-1)
     start = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
-    return pack_concat(rev), start
+    chunk = 1 << 19                                   # reads per chunk; chunk*L is a multiple of 16
+    if n <= chunk:
+        return pack_concat(reads[:, ::-1].reshape(-1)), start
+    parts = [pack_concat(reads[s:s + chunk, ::-1].reshape(-1)) for s in range(0, n - n % chunk, chunk)]
+    tail = reads[n - n % chunk:, ::-1].reshape(-1)
+    if tail.size:
+        parts.append(pack_concat(tail))
+    return np.concatenate(parts), start
 
 
 def write_lib_bin(reads: np.ndarray, prefix: str, metadata: str = "synthetic.fa") -> None:

@@ -90,7 +90,7 @@ def test_multi_pass_bucket_ranges(ctx, oracle, golden_dir):
     from megagta_amd import api
     packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
     c2 = api.Context(0)
-    c2.set_mem_limit(96 << 20)
+    c2.set_mem_limit(24 << 20)
     g = c2.build_sdbg(c2.upload_reads(packed, start), 44)
     assert g.stats["n_passes"] > 1
     fx = H.load_streams(os.path.join(golden_dir, "toy", "sdbg_streams.json"))["44"]
