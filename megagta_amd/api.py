@@ -105,6 +105,44 @@ class Context:
                           bucket_tips=counts[:, 2].copy(), stats=st.as_dict())
 
 
+class Graph:
+    """Device-resident succinct de Bruijn graph (mgta_sdbg) <-> SuccinctDBG (succinct_dbg.h:32-247)."""
+
+    def __init__(self, ctx: Context, stream: EdgeStream):
+        self.ctx, self.k = ctx, stream.k
+        recs = np.ascontiguousarray(stream.records, dtype=np.uint16)
+        bi = np.ascontiguousarray(stream.bucket_items, dtype=np.int64)
+        tips = np.ascontiguousarray(stream.tips, dtype=np.uint32)
+        out = C.c_void_p()
+        check(ctx._L.mgta_sdbg_load(ctx.h, stream.k, recs.ctypes.data, recs.size, bi.ctypes.data, tips.ctypes.data, tips.size,
+                                    stream.words_per_tip, C.byref(out)), "mgta_sdbg_load")
+        self.h = out
+        self.size = ctx._L.mgta_sdbg_size(self.h)
+
+    def outgoing(self, edges) -> tuple[np.ndarray, np.ndarray]:
+        """OutgoingEdges (succinct_dbg.cpp:78-97) for a batch: (outdeg int8[n], out int64[n,4])"""
+        e = np.ascontiguousarray(edges, dtype=np.int64)
+        out = np.empty((e.size, 4), dtype=np.int64)
+        deg = np.empty(e.size, dtype=np.int8)
+        check(self.ctx._L.mgta_sdbg_outgoing(self.h, e.ctypes.data, e.size, out.ctypes.data, deg.ctypes.data), "mgta_sdbg_outgoing")
+        return deg, out
+
+    def index_edges(self, kmers: list[str]) -> np.ndarray:
+        """IndexBinarySearchEdge (succinct_dbg.cpp:530-549) of (k+1)-mers; -1 = absent"""
+        m = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 3}
+        seqs = np.array([[m.get(c, 0) for c in s.upper()[: self.k + 1]] for s in kmers], dtype=np.uint8).reshape(len(kmers), self.k + 1)
+        ids = np.empty(len(kmers), dtype=np.int64)
+        check(self.ctx._L.mgta_sdbg_index_edges(self.h, seqs.ctypes.data, len(kmers), ids.ctypes.data), "mgta_sdbg_index_edges")
+        return ids
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx._L.mgta_sdbg_free(self.h)
+            self.h = None
+
+    __del__ = free
+
+
 class Reads:
     def __init__(self, ctx: Context, handle, n_reads: int):
         self.ctx, self.h, self.n_reads = ctx, handle, n_reads

@@ -1,0 +1,207 @@
+// graph.hip — build the device-resident succinct de Bruijn graph from the logical edge stream and
+// answer batched navigation queries (test hooks of the C ABI).
+//
+// Replaces SuccinctDBG::LoadFromMultiFile + init (succinct_dbg.cpp:595-723, succinct_dbg.h:62-86)
+// and RankAndSelect{4Bits,1Bit}::Build (rank_and_select.h:80-150,430-500).
+#include <memory>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "graph.hpp"
+#include "scan.hpp"
+
+namespace mgta {
+
+// G1: pack 64 records into a line, count ones per line: cnt[c*n_lines + line], c = 0 last, 1 tip, 2..5 symbols 1..4
+__global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, int64_t size, GLine *lines, uint64_t n_lines,
+                                                         uint32_t *cnt) {
+    uint64_t li = (uint64_t)blockIdx.x * 4 + wave_id();   // one wave per line, one lane per edge
+    if (li >= n_lines) return;
+    int lane = lane_id();
+    int64_t e = (int64_t)(li << 6) + lane;
+    uint32_t it = e < size ? recs[e] : 0;
+    bool in = e < size;
+    uint32_t w = it & 15;
+    uint64_t b_last = __ballot(in && ((it >> 4) & 1));
+    uint64_t b_tip = __ballot(in && ((it >> 5) & 1));
+    uint64_t b_inv = __ballot(in && (((it >> 5) & 1) || w == 0));
+    uint64_t b_m1 = __ballot(in && ((it >> 8) <= 1));
+    uint64_t sym[4];
+#pragma unroll
+    for (int a = 1; a <= 4; ++a) sym[a - 1] = __ballot(in && w == (uint32_t)a);
+    // W nibbles: lane j contributes w << 4*(j&15) to word j>>4 : OR-reduce inside each group of 16 lanes
+    uint64_t nib = (uint64_t)w << ((lane & 15) * 4);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) nib |= __shfl_xor(nib, d, 64);
+    uint64_t w0 = __shfl(nib, 0, 64), w1 = __shfl(nib, 16, 64), w2 = __shfl(nib, 32, 64), w3 = __shfl(nib, 48, 64);
+    if (lane == 0) {
+        GLine L;
+        L.w[0] = w0; L.w[1] = w1; L.w[2] = w2; L.w[3] = w3;
+        L.last = b_last; L.tip = b_tip; L.invalid = b_inv; L.multi1 = b_m1;
+        L.rank_last = 0; L.rank_tip = 0;
+        L.rank_w[0] = L.rank_w[1] = L.rank_w[2] = L.rank_w[3] = 0;
+        L.pad[0] = L.pad[1] = 0;
+        lines[li] = L;
+        cnt[0 * n_lines + li] = (uint32_t)__popcll(b_last);
+        cnt[1 * n_lines + li] = (uint32_t)__popcll(b_tip);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cnt[(2 + a) * n_lines + li] = (uint32_t)__popcll(sym[a]);
+    }
+}
+
+// G3: write the absolute ranks into the lines and fill the select samples
+__global__ __launch_bounds__(256) void graph_rank_kernel(GLine *lines, uint64_t n_lines, const uint32_t *cnt, const uint64_t *base,
+                                                         uint32_t *sel_last, uint32_t *sel_w1, uint32_t *sel_w2, uint32_t *sel_w3,
+                                                         uint32_t *sel_w4) {
+    uint64_t li = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= n_lines) return;
+    uint32_t *sel[5] = {sel_last, sel_w1, sel_w2, sel_w3, sel_w4};
+    uint64_t b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) b[c] = base[c * n_lines + li];
+    lines[li].rank_last = b[0];
+    lines[li].rank_tip = b[1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) lines[li].rank_w[a] = b[2 + a];
+    // ranks [b, b+c) live in this line: every multiple of 64 among them gets this line as its sample
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        int c = s == 0 ? 0 : s + 1;
+        uint64_t lo = b[c], hi = lo + cnt[c * n_lines + li];
+        for (uint64_t m = (lo + 63) & ~63ull; m < hi; m += 64) sel[s][m >> 6] = (uint32_t)li;
+    }
+}
+
+__global__ void graph_rankf_kernel(GraphDev g, int64_t *rank_f) {
+    if (threadIdx.x < 6) rank_f[threadIdx.x] = g_rank_last(g, g.f[threadIdx.x] - 1);
+}
+
+__global__ __launch_bounds__(256) void graph_outgoing_kernel(GraphDev g, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int64_t o[4] = {-1, -1, -1, -1};
+    int od = g_outgoing(g, edges[i], o);
+    outdeg[i] = (int8_t)od;
+    for (int j = 0; j < 4; ++j) out4[i * 4 + j] = (j < od) ? (o[j] >> 4) : -1;
+}
+
+__global__ __launch_bounds__(64) void graph_index_kernel(GraphDev g, const uint8_t *seqs, int64_t n, int64_t *ids) {
+    int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *s = seqs + i * (g.k + 1);
+    bool ok = true;
+    for (int j = 0; j <= g.k; ++j) ok = ok && s[j] >= 1 && s[j] <= 4;
+    ids[i] = ok ? g_index_edge(g, s) : -1;
+}
+
+}  // namespace mgta
+
+using namespace mgta;
+
+extern "C" {
+
+int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
+                   int64_t n_tip_words, int words_per_tip, mgta_sdbg **out) {
+    if (!ctx || !out || size < 0 || (size > 0 && !recs) || !bucket_items) { set_error("mgta_sdbg_load: bad argument"); return MGTA_EINVAL; }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        auto g = std::make_unique<mgta_sdbg>();
+        g->ctx = ctx;
+        GraphDev &d = g->dev;
+        memset(&d, 0, sizeof(d));
+        d.size = size; d.k = k; d.words_per_tip = words_per_tip;
+        d.f[0] = -1; d.f[1] = 0;                                        // sdbg_multi_io.h:254-268
+        int64_t acc = 0;
+        for (int b = 0; b < MGTA_NUM_BUCKETS; ++b) { acc += bucket_items[b]; d.f[b / (MGTA_NUM_BUCKETS / 4) + 2] = acc; }
+        if (acc != size) { set_error("mgta_sdbg_load: bucket_items sum %lld != size %lld", (long long)acc, (long long)size); return MGTA_EINVAL; }
+        uint64_t n_lines = (uint64_t)((size + 63) / 64);
+        if (n_lines >= 0xFFFFFFFFull) { set_error("graph too large for 32-bit line samples"); return MGTA_EUNSUPPORTED; }
+        d.n_lines = n_lines;
+        g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
+        MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
+        g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
+        if (n_tip_words) MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, hipMemcpyHostToDevice, st));
+        d.lines = g->lines.as<GLine>();
+        d.tip_labels = g->tips.as<uint32_t>();
+        if (size > 0) {
+            DevBuf d_recs, d_cnt, d_base, d_tmp, d_tot;
+            d_recs.alloc((size_t)size * 2, &ctx->live_bytes, &ctx->peak_bytes);
+            MGTA_HIP_CHECK(hipMemcpyAsync(d_recs.p, recs, (size_t)size * 2, hipMemcpyHostToDevice, st));
+            d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, d_recs.as<uint16_t>(), size,
+                               g->lines.as<GLine>(), n_lines, d_cnt.as<uint32_t>());
+            uint64_t tot[6];
+            for (int c = 0; c < 6; ++c)
+                exclusive_scan_u32(st, d_cnt.as<uint32_t>() + c * n_lines, n_lines, d_base.as<uint64_t>() + c * n_lines, d_tmp.as<uint64_t>(),
+                                   d_tot.as<uint64_t>() + c);
+            MGTA_HIP_CHECK(hipMemcpyAsync(tot, d_tot.p, 48, hipMemcpyDeviceToHost, st));
+            MGTA_HIP_CHECK(hipStreamSynchronize(st));
+            d.total_last = (int64_t)tot[0];
+            for (int a = 1; a <= 4; ++a) d.total_w[a] = (int64_t)tot[1 + a];
+            g->sel_last.alloc((tot[0] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            for (int a = 1; a <= 4; ++a) g->sel_w[a].alloc((tot[1 + a] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            d.sel_last = g->sel_last.as<uint32_t>();
+            for (int a = 1; a <= 4; ++a) d.sel_w[a] = g->sel_w[a].as<uint32_t>();
+            hipLaunchKernelGGL(graph_rank_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, g->lines.as<GLine>(), n_lines,
+                               d_cnt.as<uint32_t>(), d_base.as<uint64_t>(), g->sel_last.as<uint32_t>(), g->sel_w[1].as<uint32_t>(),
+                               g->sel_w[2].as<uint32_t>(), g->sel_w[3].as<uint32_t>(), g->sel_w[4].as<uint32_t>());
+            DevBuf d_rf;
+            d_rf.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+            hipLaunchKernelGGL(graph_rankf_kernel, dim3(1), dim3(64), 0, st, d, d_rf.as<int64_t>());
+            MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
+            MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        *out = g.release();
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+void mgta_sdbg_free(mgta_sdbg *g) { delete g; }
+int64_t mgta_sdbg_size(const mgta_sdbg *g) { return g ? g->dev.size : -1; }
+
+int mgta_sdbg_outgoing(mgta_sdbg *g, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg) {
+    if (!g || n < 0 || (n > 0 && (!edges || !out4 || !outdeg))) { set_error("mgta_sdbg_outgoing: bad argument"); return MGTA_EINVAL; }
+    for (int64_t i = 0; i < n; ++i)
+        if (edges[i] < 0 || edges[i] >= g->dev.size) { set_error("edge id %lld out of range", (long long)edges[i]); return MGTA_EINVAL; }
+    if (n == 0) return MGTA_OK;
+    try {
+        mgta_ctx *ctx = g->ctx;
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        DevBuf d_e, d_o, d_d;
+        d_e.alloc(n * 8); d_o.alloc(n * 32); d_d.alloc(n);
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_e.p, edges, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(graph_outgoing_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g->dev, d_e.as<int64_t>(), n,
+                           d_o.as<int64_t>(), d_d.as<int8_t>());
+        MGTA_HIP_CHECK(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        MGTA_HIP_CHECK(hipMemcpyAsync(outdeg, d_d.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_index_edges(mgta_sdbg *g, const uint8_t *seqs, int64_t n, int64_t *edge_ids) {
+    if (!g || n < 0 || (n > 0 && (!seqs || !edge_ids))) { set_error("mgta_sdbg_index_edges: bad argument"); return MGTA_EINVAL; }
+    if (n == 0) return MGTA_OK;
+    try {
+        mgta_ctx *ctx = g->ctx;
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        size_t sb = (size_t)n * (g->dev.k + 1);
+        DevBuf d_s, d_i;
+        d_s.alloc(sb); d_i.alloc(n * 8);
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_s.p, seqs, sb, hipMemcpyHostToDevice, ctx->stream));
+        if (g->dev.size > 0)
+            hipLaunchKernelGGL(graph_index_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, g->dev, d_s.as<uint8_t>(), n,
+                               d_i.as<int64_t>());
+        else
+            MGTA_HIP_CHECK(hipMemsetAsync(d_i.p, 0xFF, n * 8, ctx->stream));
+        MGTA_HIP_CHECK(hipMemcpyAsync(edge_ids, d_i.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// graph.hpp — device-resident succinct de Bruijn graph.
+//
+// The reference keeps five bit-vectors plus three separate two-level rank/select directories
+// (rank_and_select.h:80-124,430-500) and answers one OutgoingEdges with ~10 dependent cache misses.
+// Here everything about 64 consecutive edges lives in ONE 128-byte line (= one gfx950 L2 line):
+// W symbols, last / tip / invalid / multi1 bits and the absolute rank counters needed by Forward /
+// Backward, so Rank is a single line fetch and Select is a sample lookup + (usually) one line.
+// Only the ANSWERS follow the reference: Rank(c,pos) = #c in [0..pos]  (rank_and_select.h:153),
+// Select(r) = position of the r-th one, 0-based (:560), Forward / Backward / OutgoingEdges
+// (succinct_dbg.h:155-170, succinct_dbg.cpp:78-97), IndexBinarySearch[Edge] (:427-549).
+#pragma once
+#include "common.hpp"
+
+namespace mgta {
+
+struct alignas(128) GLine {
+    uint64_t w[4];        // 64 x 4-bit W (edge j: bits 4*(j&15) of w[j>>4]); 0=$ 1-4=ACGT 5-8=ACGT-minus
+    uint64_t last;        // succinct_dbg.h:97
+    uint64_t tip;         // is_tip_
+    uint64_t invalid;     // tip | (W == 0)    succinct_dbg.cpp:717-721, .h:81-85
+    uint64_t multi1;      // stored multiplicity <= 1   succinct_dbg.cpp:680
+    uint64_t rank_last;   // ones of `last` before this line
+    uint64_t rank_tip;    // tips before this line
+    uint64_t rank_w[4];   // occurrences of W == a (a = 1..4, plain symbols only) before this line
+    uint64_t pad[2];
+};
+static_assert(sizeof(GLine) == 128, "one line per 64 edges");
+
+struct GraphDev {
+    const GLine *lines;
+    uint64_t n_lines;
+    int64_t size;
+    int k, words_per_tip;
+    int64_t f[6];          // sdbg_multi_io.h:254-268
+    int64_t rank_f[6];     // rs_last_.Rank(f[i]-1), succinct_dbg.h:74-76
+    int64_t total_last;
+    int64_t total_w[5];    // [1..4]
+    const uint32_t *sel_last;     // line holding the (64*j)-th one of `last`
+    const uint32_t *sel_w[5];     // [1..4]: line holding the (64*j)-th occurrence of symbol a
+    const uint32_t *tip_labels;
+};
+
+// ---- device-side navigation -------------------------------------------------------------------
+__device__ __forceinline__ int g_W(const GraphDev &g, int64_t x) {
+    return (int)((g.lines[x >> 6].w[(x >> 4) & 3] >> ((x & 15) * 4)) & 15);
+}
+__device__ __forceinline__ int g_bit(uint64_t word, int64_t x) { return (int)((word >> (x & 63)) & 1); }
+__device__ __forceinline__ bool g_valid(const GraphDev &g, int64_t x) { return !g_bit(g.lines[x >> 6].invalid, x); }
+__device__ __forceinline__ bool g_last(const GraphDev &g, int64_t x) { return g_bit(g.lines[x >> 6].last, x); }
+__device__ __forceinline__ bool g_tip(const GraphDev &g, int64_t x) { return g_bit(g.lines[x >> 6].tip, x); }
+__device__ __forceinline__ bool g_last_or_tip(const GraphDev &g, int64_t x) {
+    const GLine &L = g.lines[x >> 6];
+    return g_bit(L.last | L.tip, x);
+}
+__device__ __forceinline__ bool g_multi1(const GraphDev &g, int64_t x) { return g_bit(g.lines[x >> 6].multi1, x); }
+
+// nibbles of `word` equal to c -> one bit (lowest of the nibble) each
+__device__ __forceinline__ uint64_t nib_eq(uint64_t word, int c) {
+    uint64_t t = word ^ (0x1111111111111111ull * (uint64_t)c);
+    t |= t >> 1;
+    t |= t >> 2;
+    return ~t & 0x1111111111111111ull;
+}
+
+// number of W == c (c in 1..4) in [0..pos]   (RankAndSelect4Bits::Rank semantics)
+__device__ __forceinline__ int64_t g_rank_w(const GraphDev &g, int c, int64_t pos) {
+    if (pos < 0) return 0;
+    if (pos >= g.size - 1) return g.total_w[c];
+    const GLine &L = g.lines[pos >> 6];
+    int j = (int)(pos & 63);
+    int64_t r = (int64_t)L.rank_w[c - 1];
+    int fw = j >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < fw) r += __popcll(nib_eq(L.w[q], c));
+        else if (q == fw) {
+            int nb = (j & 15) + 1;
+            uint64_t m = nb == 16 ? ~0ull : ((1ull << (4 * nb)) - 1);
+            r += __popcll(nib_eq(L.w[q], c) & m);
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ int64_t g_rank_last(const GraphDev &g, int64_t pos) {   // ones in [0..pos]
+    if (pos < 0) return 0;
+    if (pos >= g.size - 1) return g.total_last;
+    const GLine &L = g.lines[pos >> 6];
+    int j = (int)(pos & 63);
+    uint64_t m = j == 63 ? ~0ull : ((1ull << (j + 1)) - 1);
+    return (int64_t)L.rank_last + __popcll(L.last & m);
+}
+
+__device__ __forceinline__ int select64(uint64_t x, int n) {   // position of the n-th (0-based) set bit
+    int pos = 0;
+    int c = __popc((uint32_t)x);
+    if (n >= c) { n -= c; x >>= 32; pos += 32; }
+    c = __popc((uint32_t)x & 0xFFFFu);
+    if (n >= c) { n -= c; x >>= 16; pos += 16; }
+    c = __popc((uint32_t)x & 0xFFu);
+    if (n >= c) { n -= c; x >>= 8; pos += 8; }
+    c = __popc((uint32_t)x & 0xFu);
+    if (n >= c) { n -= c; x >>= 4; pos += 4; }
+    c = __popc((uint32_t)x & 0x3u);
+    if (n >= c) { n -= c; x >>= 2; pos += 2; }
+    c = (int)(x & 1);
+    if (n >= c) pos += 1;
+    return pos;
+}
+
+__device__ __forceinline__ int64_t g_select_last(const GraphDev &g, int64_t r) {   // RankAndSelect1Bit::Select
+    if (r >= g.total_last) return g.size;
+    if (r < 0) return -1;
+    uint64_t li = g.sel_last[r >> 6];
+    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r) ++li;
+    const GLine &L = g.lines[li];
+    return (int64_t)(li << 6) + select64(L.last, (int)(r - (int64_t)L.rank_last));
+}
+
+__device__ __forceinline__ int64_t g_select_w(const GraphDev &g, int c, int64_t r) {   // RankAndSelect4Bits::Select, c in 1..4
+    if (r >= g.total_w[c]) return g.size;
+    if (r < 0) return -1;
+    uint64_t li = g.sel_w[c][r >> 6];
+    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_w[c - 1] <= r) ++li;
+    const GLine &L = g.lines[li];
+    int rem = (int)(r - (int64_t)L.rank_w[c - 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint64_t e = nib_eq(L.w[q], c);
+        int pc = __popcll(e);
+        if (rem < pc) return (int64_t)(li << 6) + q * 16 + (select64(e, rem) >> 2);
+        rem -= pc;
+    }
+    return g.size;
+}
+
+__device__ __forceinline__ int64_t g_forward(const GraphDev &g, int64_t e) {   // succinct_dbg.h:155-164
+    int a = g_W(g, e);
+    if (a > 4) a -= 4;
+    int64_t cnt = g_rank_w(g, a, e);
+    return g_select_last(g, g.rank_f[a] + cnt - 1);
+}
+
+__device__ __forceinline__ int g_node_last_char(const GraphDev &g, int64_t x) {   // succinct_dbg.h:109-115
+    int i = 1;
+    while (!(g.f[i] > x)) ++i;
+    return i - 1;
+}
+
+__device__ __forceinline__ int64_t g_backward(const GraphDev &g, int64_t e) {   // succinct_dbg.h:166-170
+    int a = g_node_last_char(g, e);
+    int64_t cnt = g_rank_last(g, e - 1) - g.rank_f[a];
+    return g_select_w(g, a, cnt);
+}
+
+// OutgoingEdges (succinct_dbg.cpp:78-97): valid edges of the node Forward(e) points to, in
+// descending id order.  Per edge also its out-label (1..4) and multi1 bit, packed: id<<4 | multi1<<3 | label
+__device__ __forceinline__ int g_outgoing(const GraphDev &g, int64_t e, int64_t out[4]) {
+    if (!g_valid(g, e)) return -1;
+    int od = 0;
+    int64_t x = g_forward(g, e);
+    do {
+        const GLine &L = g.lines[x >> 6];
+        if (!g_bit(L.invalid, x)) {
+            int w = (int)((L.w[(x >> 4) & 3] >> ((x & 15) * 4)) & 15);
+            if (od < 4) out[od] = (x << 4) | ((int64_t)g_bit(L.multi1, x) << 3) | (int64_t)(w > 4 ? w - 4 : w);
+            ++od;
+        }
+        --x;
+    } while (x >= 0 && !g_last_or_tip(g, x));
+    return od > 4 ? 4 : od;
+}
+
+__device__ __forceinline__ int g_tip_char(const GraphDev &g, int64_t tip_rank, int j) {
+    const uint32_t *t = g.tip_labels + (size_t)g.words_per_tip * tip_rank;
+    return (t[j >> 4] >> (15 - (j & 15)) * 2) & 3;
+}
+__device__ __forceinline__ int64_t g_rank_tip(const GraphDev &g, int64_t pos) {   // tips in [0..pos]
+    const GLine &L = g.lines[pos >> 6];
+    int j = (int)(pos & 63);
+    uint64_t m = j == 63 ? ~0ull : ((1ull << (j + 1)) - 1);
+    return (int64_t)L.rank_tip + __popcll(L.tip & m);
+}
+
+// IndexBinarySearch (succinct_dbg.cpp:427-501): node whose label is seq[0..k-1] (symbols 1..4), or -1
+__device__ inline int64_t g_index_node(const GraphDev &g, const uint8_t *seq) {
+    const int k = g.k;
+    int64_t l = g.f[seq[k - 1]], r = g.f[seq[k - 1] + 1] - 1;
+    while (l <= r) {
+        int cmp = 0;
+        int64_t mid = (l + r) / 2, y = mid;
+        for (int i = k - 1; i >= 0; --i) {
+            if (g_tip(g, y)) {
+                int64_t tr = g_rank_tip(g, y) - 1;
+                for (int j = 0; j < i; ++j) {
+                    int c = g_tip_char(g, tr, j) + 1;
+                    if (c < seq[i - j]) { cmp = -1; break; }
+                    if (c > seq[i - j]) { cmp = 1; break; }
+                }
+                if (cmp == 0) {
+                    if (g_tip(g, mid)) cmp = -1;
+                    else {
+                        int c = g_tip_char(g, tr, i) + 1;
+                        if (c < seq[0]) cmp = -1;
+                        else if (c > seq[0]) cmp = 1;
+                    }
+                }
+                break;
+            }
+            y = g_backward(g, y);
+            int c = g_W(g, y);
+            if (c < seq[i]) { cmp = -1; break; }
+            if (c > seq[i]) { cmp = 1; break; }
+        }
+        if (cmp == 0) {
+            int64_t p = mid;                       // GetLastIndex = rs_last_.Succ(mid)
+            while (p < g.size && !g_last(g, p)) ++p;
+            return p;
+        }
+        if (cmp > 0) r = mid - 1; else l = mid + 1;
+    }
+    return -1;
+}
+
+// IndexBinarySearchEdge (succinct_dbg.cpp:530-549): seq has k+1 symbols
+__device__ inline int64_t g_index_edge(const GraphDev &g, const uint8_t *seq) {
+    int64_t node = g_index_node(g, seq);
+    if (node == -1) return -1;
+    do {
+        int lab = g_W(g, node);
+        if (lab == seq[g.k] || lab - 4 == seq[g.k]) return node;
+        --node;
+    } while (node >= 0 && !g_last_or_tip(g, node));
+    return -1;
+}
+
+}  // namespace mgta
+
+struct mgta_sdbg {
+    mgta_ctx *ctx = nullptr;
+    mgta::GraphDev dev;                       // host copy of the descriptor (pointers are device pointers)
+    mgta::DevBuf lines, sel_last, sel_w[5], tips;
+};

@@ -3,14 +3,6 @@
 #include "common.hpp"
 using namespace mgta;
 extern "C" {
-int mgta_sdbg_load(mgta_ctx *, int, const uint16_t *, int64_t, const int64_t *, const uint32_t *, int64_t, int, mgta_sdbg **) {
-    set_error("mgta_sdbg_load: not built yet"); return MGTA_EUNSUPPORTED; }
-void mgta_sdbg_free(mgta_sdbg *) {}
-int64_t mgta_sdbg_size(const mgta_sdbg *) { return -1; }
-int mgta_sdbg_outgoing(mgta_sdbg *, const int64_t *, int64_t, int64_t *, int8_t *) {
-    set_error("mgta_sdbg_outgoing: not built yet"); return MGTA_EUNSUPPORTED; }
-int mgta_sdbg_index_edges(mgta_sdbg *, const uint8_t *, int64_t, int64_t *) {
-    set_error("mgta_sdbg_index_edges: not built yet"); return MGTA_EUNSUPPORTED; }
 int mgta_hmm_load(mgta_ctx *, int, int, const double *, const double *, const double *, const double *, const int32_t *, mgta_hmm **) {
     set_error("mgta_hmm_load: not built yet"); return MGTA_EUNSUPPORTED; }
 void mgta_hmm_free(mgta_hmm *) {}

@@ -11,7 +11,7 @@ constexpr int kScanThreads = 256;
 constexpr int kScanPerThread = 16;
 constexpr int kScanChunk = kScanThreads * kScanPerThread;   // 4096 elements per workgroup
 
-__global__ __launch_bounds__(kScanThreads) void scan_chunk_sums(const uint32_t *in, uint64_t n, uint64_t *chunk_sum) {
+static __global__ __launch_bounds__(kScanThreads) void scan_chunk_sums(const uint32_t *in, uint64_t n, uint64_t *chunk_sum) {
     __shared__ uint64_t scratch[kScanThreads / 64 + 1];
     uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
     uint64_t s = 0;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_chunk_sums(const uint32_t *
 }
 
 // one workgroup of 1024 threads, sequential over tiles of 1024: exclusive scan in place; total -> *total
-__global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *v, uint64_t n, uint64_t *total) {
+static __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *v, uint64_t n, uint64_t *total) {
     __shared__ uint64_t scratch[1024 / 64 + 1];
     __shared__ uint64_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *v, uint64_t 
     if (threadIdx.x == 0 && total) *total = carry_s;
 }
 
-__global__ __launch_bounds__(kScanThreads) void scan_chunks(const uint32_t *in, uint64_t n, const uint64_t *chunk_base,
+static __global__ __launch_bounds__(kScanThreads) void scan_chunks(const uint32_t *in, uint64_t n, const uint64_t *chunk_base,
                                                             uint64_t *out) {
     __shared__ uint64_t scratch[kScanThreads / 64 + 1];
     // blocked arrangement: thread t owns elements [t*16, t*16+16) of the chunk

@@ -1,0 +1,90 @@
+"""Device graph (load + rank/select navigation) vs the oracle and the reference's own answers."""
+import os
+
+import numpy as np
+import pytest
+
+from megagta_amd import readlib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from megagta_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _graphs(ctx, oracle, lib_prefix, k):
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(lib_prefix)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    og = oracle.Graph(oracle.Stream.build(packed, start, k, threads=4))
+    return api.Graph(ctx, stream), og
+
+
+def test_outgoing_all_edges_toy(ctx, oracle, golden_dir):
+    g, og = _graphs(ctx, oracle, os.path.join(golden_dir, "toy", "reads.lib"), 44)
+    assert g.size == og.size
+    rng = np.random.default_rng(1)
+    ids = np.concatenate([np.arange(0, 3000), rng.integers(0, g.size, 20000), np.arange(g.size - 3000, g.size)])
+    deg, out = g.outgoing(ids)
+    for e, d, o in zip(ids.tolist(), deg.tolist(), out.tolist()):
+        n, ref = og.outgoing(e)
+        assert d == n and o[:max(n, 0)] == ref, e
+    # and the reference's own answers (probe)
+    _, qs = H.parse_probe_graph(H.gz_lines(os.path.join(golden_dir, "toy", "graph_k44.txt.gz")))
+    deg, out = g.outgoing([q["e"] for q in qs])
+    for q, d, o in zip(qs, deg.tolist(), out.tolist()):
+        assert d == q["od"] and o[:max(d, 0)] == q["out"]
+
+
+@pytest.mark.parametrize("k", [29, 47])
+def test_outgoing_ragged_every_edge(ctx, oracle, golden_dir, k):
+    """small graphs with tips, $ edges, large multiplicities: every edge id"""
+    g, og = _graphs(ctx, oracle, os.path.join(golden_dir, "ragged", "reads.lib"), k)
+    ids = np.arange(g.size)
+    deg, out = g.outgoing(ids)
+    for e in range(g.size):
+        n, ref = og.outgoing(e)
+        assert deg[e] == n and out[e, :max(n, 0)].tolist() == ref, e
+    _, qs = H.parse_probe_graph(H.gz_lines(os.path.join(golden_dir, "ragged", f"graph_k{k}.txt.gz")))
+    deg, out = g.outgoing([q["e"] for q in qs])
+    for q, d, o in zip(qs, deg.tolist(), out.tolist()):
+        assert d == q["od"] and o[:max(d, 0)] == q["out"]
+
+
+def test_index_edges(ctx, oracle, golden_dir):
+    g, og = _graphs(ctx, oracle, os.path.join(golden_dir, "toy", "reads.lib"), 44)
+    lines = [l.split() for l in H.gz_lines(os.path.join(golden_dir, "toy", "index_k44.txt.gz"))]
+    ids = g.index_edges([l[0] for l in lines])
+    assert ids.tolist() == [int(l[1]) for l in lines]
+    # labels of random existing edges map back to themselves or to the edge of the same node with that out-label
+    rng = np.random.default_rng(2)
+    kmers, want = [], []
+    for e in rng.integers(0, g.size, 400).tolist():
+        n, outs = og.outgoing(e)
+        if n <= 0:
+            continue
+        lab = og.label(e)
+        if "$" in lab:
+            continue
+        for o in outs:
+            w = (og.bitvectors()["w"][o >> 4] >> np.uint64((o & 15) * 4)) & np.uint64(15) if False else None
+        kmers.append(lab)
+    # k-mers (node labels) + each possible next char: compare with the oracle's own search
+    q = [lab + c for lab in kmers[:100] for c in "ACGT"]
+    ids = g.index_edges(q)
+    assert ids.tolist() == [og.index_edge(s) for s in q]
+
+
+def test_empty_graph(ctx):
+    from megagta_amd import api
+    s = api.EdgeStream(k=29, words_per_tip=2, bucket_items=np.zeros(65536, np.int64), records=np.zeros(0, np.uint16),
+                       large=np.zeros(0, np.uint16), tips=np.zeros(0, np.uint32))
+    g = api.Graph(ctx, s)
+    assert g.size == 0
+    assert g.index_edges(["A" * 30]).tolist() == [-1]
