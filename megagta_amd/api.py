@@ -143,6 +143,70 @@ class Graph:
     __del__ = free
 
 
+class DeviceHmm:
+    """Profile-HMM tables on the device (mgta_hmm) <-> ProfileHMM + MostProbablePath (profile_hmm.h, most_probable_path.h)."""
+
+    def __init__(self, ctx: Context, hm):
+        self.ctx, self.M, self.A = ctx, hm.M, hm.A
+        msc = np.ascontiguousarray(hm.msc, dtype=np.float64)
+        tsc = np.ascontiguousarray(hm.tsc, dtype=np.float64)
+        mx = np.ascontiguousarray(hm.max_match, dtype=np.float64)
+        h = np.ascontiguousarray(hm.h, dtype=np.float64)
+        alpha = np.ascontiguousarray(hm.alpha, dtype=np.int32)
+        out = C.c_void_p()
+        check(ctx._L.mgta_hmm_load(ctx.h, hm.M, hm.A, msc.ctypes.data, tsc.ctypes.data, mx.ctypes.data, h.ctypes.data, alpha.ctypes.data,
+                                   C.byref(out)), "mgta_hmm_load")
+        self.h = out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.ctx._L.mgta_hmm_free(self.h)
+            self.h = None
+
+    __del__ = free
+
+
+@dataclass
+class SeedResult:
+    """One seed: HMMGraphSearch::search (hmm_graph_search.h:60-81)"""
+    left: str          # already reverse-complemented
+    right: str
+    right_side: dict
+    left_side: dict
+
+    def contig(self, kmer: str) -> str:
+        return self.left + kmer.lower() + self.right
+
+
+def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str], start_states, prune_len: int = 20,
+                 low_cov_penalty: float = 0.5, cache_mode: int = 0) -> tuple[list[SeedResult], dict]:
+    """Batched HMM-guided A* (mgta_astar_batch).  start_states[i] = model position - 1 (search.cpp:157)."""
+    ctx = graph.ctx
+    klen = graph.k + 1
+    n = len(kmers)
+    for s in kmers:
+        if len(s) < klen:
+            raise MegaGtaError(f"seed k-mer shorter than k+1={klen}")
+    buf = "".join(s[:klen] for s in kmers).encode()
+    ss = np.ascontiguousarray(start_states, dtype=np.int32)
+    results: list[SeedResult] = [None] * n
+
+    def side(p):
+        s = p.contents
+        return dict(ok=s.ok, fval=s.fval, length=s.length, state_no=s.state_no, state=chr(s.state), partial=s.partial, node_id=s.node_id,
+                    n_closed=s.n_closed, n_expanded=s.n_expanded, n_opened=s.n_opened, real_score=s.real_score, score=s.score)
+
+    def sink(user, idx, left, ll, right, rl, rs, ls):
+        results[idx] = SeedResult(left=C.string_at(left, ll).decode(), right=C.string_at(right, rl).decode(), right_side=side(rs),
+                                  left_side=side(ls))
+        return 0
+
+    st = _lib.AstarStats()
+    check(ctx._L.mgta_astar_batch(graph.h, fwd.h, rev.h, buf, ss.ctypes.data, n, prune_len, low_cov_penalty, cache_mode,
+                                  _lib.CONTIG_SINK(sink), None, C.byref(st)), "mgta_astar_batch")
+    return results, st.as_dict()
+
+
 class Reads:
     def __init__(self, ctx: Context, handle, n_reads: int):
         self.ctx, self.h, self.n_reads = ctx, handle, n_reads

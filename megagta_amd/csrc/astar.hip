@@ -1,0 +1,689 @@
+// astar.hip — batched HMM-guided A* over the device-resident succinct de Bruijn graph (gfx950).
+//
+// Replaces the OMP seed loop of search() (search.cpp:184-189) and, per seed and direction,
+// HMMGraphSearch::astarSearch (hmm_graph_search.h:132-343) with NodeEnumerator::enumerateNodes
+// (node_enumerator.h:65-246), AStarNode ordering (a_star_node.h:34-82) and the result walk
+// getHighestScoreNode / partialResultFromGoal (hmm_graph_search.h:83-110,345-356).
+//
+// Mapping: one wavefront per (seed, direction) search, pulled from a work queue by persistent
+// workgroups; all workgroups of one direction share that direction's profile-HMM tables, staged once
+// per workgroup in LDS (fp64: msc, tsc, max_match, heuristic).
+//   * frontier expansion is wave-parallel: lane l = (i,j,k) walks the 3-edge codon path
+//     OutgoingEdges(curr)[i] -> [j] -> [k] through the 128-byte graph lines (<= 64 candidates,
+//     reference order = ascending lane), ballot/popcount compaction of the surviving lanes;
+//   * the order-sensitive bookkeeping (open list = binary heap with libstdc++'s exact
+//     push_heap/pop_heap sift sequence, closed/open hash, node pool) is executed by lane 0 in the
+//     reference's order, in per-search global-memory arenas (tagged entries: no clearing between searches);
+//   * scores are IEEE fp64, compiled with -ffp-contract=off: path log-probabilities are bit-identical
+//     to the x86-64 reference, fval = (int)(10000*(score+2h)) truncates identically.
+// A search that outgrows its arena is re-run with a larger one (never on the CPU).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <string>
+
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "graph.hpp"
+
+struct mgta_hmm {
+    mgta_ctx *ctx = nullptr;
+    int M = 0, A = 0;
+    mgta::DevBuf tab;            // [msc (M+1)*A][tsc 7*(M+1)][maxm (M+1)][h 3*(M+1)]
+    int8_t col[2][64];           // codon (c1*16+c2*4+c3) -> emission column; [0] codonTable, [1] rc_codonTable; -1 = stop
+    size_t n_doubles = 0;
+};
+
+namespace mgta {
+
+constexpr int kAstarWaves = 8;
+constexpr int kAstarThreads = kAstarWaves * 64;
+constexpr uint32_t kNone = 0x7FFFFFFFu;
+constexpr int kMaxKmer = 160;
+
+enum { T_MM = 0, T_MI = 1, T_MD = 2, T_IM = 3, T_II = 4, T_DM = 5, T_DD = 6 };   // profile_hmm.h:25
+enum { ST_M = 0, ST_I = 1, ST_D = 2 };
+
+struct ANode {                    // AStarNode, a_star_node.h:9-33
+    double score, real_score, max_score;
+    int64_t node_id;
+    int32_t parent;               // index in the search's pool, -1 = none
+    int32_t fval;
+    int16_t state_no, length, negative_count;
+    uint16_t em_state;            // nucl_emission (9 bits) | state << 9
+};
+static_assert(sizeof(ANode) == 48, "node layout");
+
+struct HeapEnt {
+    uint64_t prio;                // order of AStarNode::operator< folded into one integer
+    uint32_t node, pad;
+};
+struct HashEnt {
+    uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1)
+    uint32_t val;                 // open-list node index (kNone = none) | closed << 31
+    uint32_t tag;                 // entry is live iff tag == the search's tag
+};
+
+struct HmmView {
+    const double *tab;
+    int M, A;
+    int8_t col_fwd[64];           // codonTable -> column
+    int8_t col_enum[64];          // table used by the enumerator of this direction (codonTable / rc_codonTable)
+};
+
+struct AstarArgs {
+    GraphDev g;
+    HmmView hm[2];
+    const char *kmers;            // n x klen, lower/upper ACGT
+    const int32_t *start_state;
+    const int64_t *start_node;    // [2n]: IndexBinarySearchEdge of the k-mer (dir 0) and of its reverse complement (dir 1)
+    int64_t n_seeds;
+    int klen;                     // k + 1
+    int prune;
+    double low_cov_penalty;       // -log(low_cov_pen)
+    double log2v;
+    const double *exit_prob;      // [3000]
+    const int64_t *todo[2];       // seed indices still to run per direction
+    int64_t n_todo[2];
+    unsigned long long *queue;    // [2]
+    ANode *nodes; HeapEnt *heap; HashEnt *hash;
+    uint32_t cap_nodes, cap_hash; // cap_hash power of two
+    uint32_t *slot_tag;
+    mgta_astar_side *sides;       // [2n]
+    char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
+    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = arena overflow, 3 = bad seed
+    int use_lds;
+};
+
+__device__ __forceinline__ int to_fval(double x) {   // (int)x as x86-64 cvttsd2si does it (INT_MIN when out of range / NaN)
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+    return (int)x;
+}
+__device__ __forceinline__ int srank(int st) { return st == ST_M ? 3 : st == ST_D ? 2 : 1; }
+__device__ __forceinline__ uint64_t make_prio(int fval, int state_no, int st) {   // a < b  <=>  prio(a) < prio(b)
+    return ((uint64_t)((uint32_t)fval ^ 0x80000000u) << 32) | ((uint64_t)(uint16_t)(0xFFFF - (uint16_t)state_no) << 2) | (uint64_t)srank(st);
+}
+__device__ __forceinline__ uint64_t make_key(int64_t node_id, int state_no, int st) {
+    return ((uint64_t)node_id << 18) | ((uint64_t)(uint16_t)state_no << 2) | (uint64_t)(st + 1);
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+struct Search {                   // lane-0 state of one search
+    ANode *nodes; HeapEnt *heap; HashEnt *hash;
+    uint32_t cap_nodes, hmask, tag;
+    uint32_t n_nodes, n_heap, n_keys;
+    bool overflow;
+};
+
+// std::push_heap as libstdc++ does it (bits/stl_heap.h __push_heap)
+__device__ __forceinline__ void heap_sift_up(HeapEnt *h, int64_t hole, HeapEnt v) {
+    int64_t parent = (hole - 1) / 2;
+    while (hole > 0 && h[parent].prio < v.prio) {
+        h[hole] = h[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h[hole] = v;
+}
+__device__ __forceinline__ void heap_push(Search &S, HeapEnt v) { heap_sift_up(S.heap, S.n_heap, v); S.n_heap++; }
+
+// std::pop_heap + pop_back (bits/stl_heap.h __pop_heap / __adjust_heap); returns the former top
+__device__ __forceinline__ HeapEnt heap_pop(Search &S) {
+    HeapEnt *h = S.heap;
+    HeapEnt top = h[0];
+    int64_t n = S.n_heap;
+    if (n > 1) {
+        HeapEnt v = h[n - 1];
+        int64_t len = n - 1, hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (h[second].prio < h[second - 1].prio) second--;
+            h[hole] = h[second];
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            h[hole] = h[second - 1];
+            hole = second - 1;
+        }
+        heap_sift_up(h, hole, v);
+    }
+    S.n_heap--;
+    return top;
+}
+
+// returns the slot of `key` (found) or of the first free slot (not found)
+__device__ __forceinline__ uint32_t hash_find(const Search &S, uint64_t key, bool &found) {
+    uint32_t i = (uint32_t)mix64(key) & S.hmask;
+    while (true) {
+        HashEnt e = S.hash[i];
+        if (e.tag != S.tag) { found = false; return i; }
+        if (e.key == key) { found = true; return i; }
+        i = (i + 1) & S.hmask;
+    }
+}
+__device__ __forceinline__ uint32_t hash_get_or_add(Search &S, uint64_t key) {
+    bool found;
+    uint32_t i = hash_find(S, key, found);
+    if (!found) {
+        HashEnt e; e.key = key; e.val = kNone; e.tag = S.tag;
+        S.hash[i] = e;
+        S.n_keys++;
+        if (S.n_keys * 2 > S.hmask) S.overflow = true;
+    }
+    return i;
+}
+
+__device__ __forceinline__ bool node_less(const ANode &a, int fval, int state_no, int st) {
+    return make_prio(a.fval, a.state_no, a.em_state >> 9) < make_prio(fval, state_no, st);
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
+    extern __shared__ __align__(16) double s_tab[];
+    __shared__ int64_t s_codon[kAstarWaves][64];
+    const int dir = blockIdx.x & 1;
+    const HmmView &hv = a.hm[dir];
+    const int M = hv.M, A = hv.A;
+    const double *tab = hv.tab;
+    if (LDS) {
+        size_t nd = (size_t)(M + 1) * (A + 11);
+        for (size_t i = threadIdx.x; i < nd; i += kAstarThreads) s_tab[i] = hv.tab[i];
+        __syncthreads();
+        tab = s_tab;
+    }
+    const double *msc = tab, *tsc = tab + (size_t)(M + 1) * A, *maxm = tsc + (size_t)7 * (M + 1), *hc = maxm + (M + 1);
+    const int lane = lane_id(), wv = wave_id();
+    const uint32_t slot = blockIdx.x * kAstarWaves + wv;
+    const GraphDev &g = a.g;
+    const bool forward = dir == 0;
+
+    Search S;
+    S.nodes = a.nodes + (size_t)slot * a.cap_nodes;
+    S.heap = a.heap + (size_t)slot * a.cap_nodes;
+    S.hash = a.hash + (size_t)slot * a.cap_hash;
+    S.cap_nodes = a.cap_nodes; S.hmask = a.cap_hash - 1;
+    uint32_t tag = a.slot_tag[slot];
+
+    while (true) {
+        // ---- next search of this direction
+        long long qi = 0;
+        if (lane == 0) qi = (long long)atomicAdd(&a.queue[dir], 1ull);
+        qi = __shfl(qi, 0, 64);
+        if (qi >= a.n_todo[dir]) break;
+        const int64_t seed = a.todo[dir][qi];
+        const int64_t sid = seed * 2 + dir;
+        ++tag;
+        S.tag = tag; S.n_nodes = 0; S.n_heap = 0; S.n_keys = 0; S.overflow = false;
+
+        int64_t n_closed = 0, n_expanded = 0, n_opened = 0;
+        int status = 1, partial = 0, ok = 0;
+        int32_t goal = -1;             // pool index of the node whose path is reported
+        int32_t inter = 0;             // inter_goal_ptr
+        int32_t cur = 0;               // node being expanded (lane 0)
+        bool first = true, done = false;
+
+        // ---- start node (hmm_graph_search.h:132-189), lane 0
+        if (lane == 0) {
+            const char *km = a.kmers + seed * a.klen;
+            int n_aa = a.klen / 3;
+            int sstate = forward ? a.start_state[seed] : (M - a.start_state[seed] - n_aa);   // :73
+            bool bad = sstate < 0 || sstate + n_aa > M || a.klen > kMaxKmer;
+            double sc = 0, rs = 0;
+            if (!bad) {
+                for (int i = 1; i <= n_aa; ++i) {                     // scoreStart / realScoreStart, :112-130
+                    int ci = forward ? (i - 1) : (n_aa - i);          // reverse search scores the reversed protein
+                    int c = 0;
+                    for (int t = 0; t < 3; ++t) {
+                        char ch = km[3 * ci + t];
+                        int b = (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g' || ch == 'N' || ch == 'n') ? 2
+                                : (ch == 'T' || ch == 't') ? 3 : -1;
+                        if (b < 0) bad = true;
+                        c = c * 4 + (b < 0 ? 0 : b);
+                    }
+                    int col = hv.col_fwd[c];
+                    if (col < 0) { bad = true; break; }
+                    double m = msc[(size_t)(sstate + i) * A + col], t = tsc[(size_t)T_MM * (M + 1) + sstate + i - 1];
+                    sc += m + t - maxm[sstate + i];
+                    rs += m + t;
+                }
+            }
+            if (bad) { status = 3; done = true; }
+            else {
+                ANode st;
+                st.parent = -1; st.state_no = (int16_t)(sstate + n_aa); st.em_state = (uint16_t)(ST_M << 9); st.length = (int16_t)n_aa;
+                st.fval = 0; st.score = sc; st.real_score = rs; st.max_score = 0; st.negative_count = 0;
+                st.node_id = a.start_node[sid];
+                S.nodes[0] = st; S.n_nodes = 1;
+                if (st.state_no >= M) { ok = 1; goal = 0; done = true; }          // :193-197
+                else if (st.node_id == -1) { ok = 0; done = true; n_opened = 1; }  // no children -> open.empty() -> false (:235-237)
+                cur = 0; inter = 0;
+            }
+        }
+
+        // ---- main loop: one expansion per iteration
+        while (true) {
+            int64_t cur_id = 0;
+            if (lane == 0 && !done && !first) {
+                // pop until a node that is not closed (hmm_graph_search.h:243-257)
+                bool have = false;
+                while (S.n_heap > 0) {
+                    HeapEnt top = heap_pop(S);
+                    ANode &c = S.nodes[top.node];
+                    bool found;
+                    uint32_t hs = hash_find(S, make_key(c.node_id, c.state_no, c.em_state >> 9), found);
+                    if (found && (S.hash[hs].val >> 31)) continue;                 // closed
+                    cur = (int32_t)top.node;
+                    have = true;
+                    break;
+                }
+                if (!have) {                                                        // open list ran dry (:339-341)
+                    partial = 1; ok = 1; goal = inter; done = true;
+                } else {
+                    const ANode &c = S.nodes[cur];
+                    const ANode &ig = S.nodes[inter];
+                    bool better = (c.real_score + a.exit_prob[c.length]) / a.log2v > (ig.real_score + a.exit_prob[ig.length]) / a.log2v;
+                    if (c.state_no >= M) {                                          // goal (:259-270)
+                        if (better) inter = cur;
+                        ok = 1; goal = inter; done = true;
+                    } else {
+                        uint32_t hs = hash_get_or_add(S, make_key(c.node_id, c.state_no, c.em_state >> 9));
+                        S.hash[hs].val |= 0x80000000u;                              // closed.insert (:272)
+                        n_closed++;
+                        if (better) inter = cur;                                    // :274-277
+                        if (S.overflow) { status = 2; done = true; }
+                    }
+                }
+            }
+            int dflag = __shfl((int)done, 0, 64);
+            if (dflag) break;
+            if (lane == 0) cur_id = S.nodes[cur].node_id;
+            cur_id = __shfl(cur_id, 0, 64);
+
+            // ---- wave-parallel enumeration of the <= 64 codon paths (node_enumerator.h:98-128)
+            int64_t o1[4], o2[4], o3[4];
+            int od1 = g_outgoing(g, cur_id, o1);
+            const int i = lane >> 4, j = (lane >> 2) & 3, kk = lane & 3;
+            bool valid = i < od1;
+            int64_t packed = 0;
+            if (valid) {
+                int64_t e1 = o1[0];
+#pragma unroll
+                for (int t = 1; t < 4; ++t) if (t == i) e1 = o1[t];
+                int od2 = g_outgoing(g, e1 >> 4, o2);
+                valid = j < od2;
+                if (valid) {
+                    int64_t e2 = o2[0];
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) if (t == j) e2 = o2[t];
+                    int od3 = g_outgoing(g, e2 >> 4, o3);
+                    valid = kk < od3;
+                    if (valid) {
+                        int64_t e3 = o3[0];
+#pragma unroll
+                        for (int t = 1; t < 4; ++t) if (t == kk) e3 = o3[t];
+                        int c1 = (int)(e1 & 7) - 1, c2 = (int)(e2 & 7) - 1, c3 = (int)(e3 & 7) - 1;
+                        int low = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1) & (int)((e3 >> 3) & 1);
+                        packed = ((e3 >> 4) << 16) | ((int64_t)low << 9) | (c1 << 6) | (c2 << 3) | c3;
+                    }
+                }
+            }
+            uint64_t vmask = __ballot(valid);
+            if (valid) s_codon[wv][lane] = packed;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- children in reference order, lane 0 (node_enumerator.h:131-244, hmm_graph_search.h:288-336)
+            if (lane == 0) {
+                n_expanded++;
+                const ANode curr = S.nodes[cur];
+                const int cst = curr.em_state >> 9;
+                const int next_state = curr.state_no + 1;
+                double mt, it, dt;
+                const double NEG_INF = -__builtin_inf();
+                const size_t M1 = (size_t)(M + 1);
+                if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
+                else if (cst == ST_D) { mt = tsc[T_DM * M1 + curr.state_no]; it = NEG_INF; dt = tsc[T_DD * M1 + curr.state_no]; }
+                else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
+                const double max_match = maxm[next_state];
+                const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
+
+                auto admit = [&](ANode &nx) {
+                    const int nst = nx.em_state >> 9;
+                    bool open_node = false;
+                    uint32_t hs = 0;
+                    if (first) open_node = true;                                    // :212-233: no pruning / dedup
+                    else {
+                        bool adm = a.prune > 0 ? ((nx.length < 5 || nx.negative_count <= a.prune) && nx.real_score > 0.0) : true;   // :292-293
+                        if (adm) {
+                            bool found;
+                            hs = hash_find(S, make_key(nx.node_id, nx.state_no, nst), found);
+                            uint32_t oi = found ? (S.hash[hs].val & kNone) : kNone;
+                            if (oi != kNone) open_node = node_less(S.nodes[oi], nx.fval, nx.state_no, nst);          // :299-302
+                            else open_node = true;
+                        }
+                    }
+                    if (!open_node) return;
+                    if (S.n_nodes >= S.cap_nodes) { S.overflow = true; return; }
+                    uint32_t idx = S.n_nodes++;
+                    S.nodes[idx] = nx;
+                    if (!first) {
+                        hs = hash_get_or_add(S, make_key(nx.node_id, nx.state_no, nst));
+                        S.hash[hs].val = (S.hash[hs].val & 0x80000000u) | idx;      // open_hash[next] = next (:331)
+                        n_opened++;
+                    }
+                    HeapEnt he; he.prio = make_prio(nx.fval, nx.state_no, nst); he.node = idx; he.pad = 0;
+                    heap_push(S, he);
+                };
+
+                uint64_t vm = vmask;
+                while (vm && !S.overflow) {
+                    int l = __builtin_ctzll(vm);
+                    vm &= vm - 1;
+                    int64_t p = s_codon[wv][l];
+                    int col = hv.col_enum[(int)((p >> 6) & 7) * 16 + (int)((p >> 3) & 7) * 4 + (int)(p & 7)];
+                    if (col < 0) continue;                                          // stop codon (:142-144)
+                    double pen = (p & (1 << 9)) ? a.low_cov_penalty : 0.0;          // :150
+                    ANode nx;
+                    nx.parent = cur; nx.node_id = p >> 16;
+                    nx.state_no = (int16_t)next_state; nx.length = (int16_t)(curr.length + 1);
+                    double e = mt + msc[(size_t)next_state * A + col];
+                    nx.real_score = curr.real_score + e - pen;
+                    if (nx.real_score >= curr.max_score) { nx.max_score = nx.real_score; nx.negative_count = 0; }
+                    else { nx.max_score = curr.max_score; nx.negative_count = (int16_t)(curr.negative_count + 1); }
+                    double self = e - pen - max_match;
+                    nx.score = curr.score + self;
+                    nx.fval = to_fval(10000 * (nx.score + 2.0 * h_m));              // :173
+                    nx.em_state = (uint16_t)((p & 511) | (ST_M << 9));
+                    admit(nx);
+                    if (cst != ST_D) {                                              // insert child (:189-214); isc == 0 except at M
+                        double isc = next_state == M ? NEG_INF : 0.0;
+                        double ei = it + isc;
+                        ANode ni;
+                        ni.parent = cur; ni.node_id = p >> 16;
+                        ni.state_no = curr.state_no; ni.length = (int16_t)(curr.length + 1);
+                        ni.real_score = curr.real_score + ei - pen;
+                        ni.max_score = curr.max_score;
+                        ni.negative_count = (int16_t)(curr.negative_count + 1);
+                        ni.score = curr.score + (ei - pen);
+                        ni.fval = to_fval(10000 * (ni.score + 2.0 * h_i));
+                        ni.em_state = (uint16_t)((p & 511) | (ST_I << 9));
+                        admit(ni);
+                    }
+                }
+                if (cst != ST_I && !S.overflow) {                                   // delete child (:218-244)
+                    ANode nd;
+                    nd.parent = cur; nd.node_id = curr.node_id;
+                    nd.state_no = (int16_t)next_state; nd.length = curr.length;
+                    nd.real_score = curr.real_score + dt;
+                    nd.max_score = curr.max_score;
+                    nd.negative_count = (int16_t)(curr.negative_count + 1);
+                    nd.score = curr.score + (dt - max_match);
+                    nd.fval = to_fval(10000 * (nd.score + 2.0 * h_d));
+                    nd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
+                    admit(nd);
+                }
+                if (S.overflow) { status = 2; done = true; }
+                if (first) {
+                    first = false;
+                    n_opened = 1;
+                    if (S.n_heap == 0) { ok = 0; done = true; }                     // :235-237
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- result (lane 0): getHighestScoreNode + partialResultFromGoal
+        if (lane == 0) {
+            mgta_astar_side r;
+            r.ok = ok; r.partial = partial; r.n_closed = n_closed; r.n_expanded = n_expanded; r.n_opened = n_opened;
+            r.fval = 0; r.length = 0; r.state_no = -1; r.state = '-'; r.node_id = -1; r.real_score = 0; r.score = 0;
+            uint32_t len = 0;
+            char *dst = a.out_seq + (size_t)sid * a.out_cap;
+            if (status == 1 && ok && goal >= 0) {
+                int32_t best = goal;                                                // :345-356
+                for (int32_t p = S.nodes[goal].parent; p >= 0; p = S.nodes[p].parent)
+                    if (S.nodes[p].real_score > S.nodes[best].real_score) best = p;
+                const ANode &gn = S.nodes[best];
+                r.fval = gn.fval; r.length = gn.length; r.state_no = gn.state_no;
+                r.state = "mid"[gn.em_state >> 9]; r.node_id = gn.node_id; r.real_score = gn.real_score; r.score = gn.score;
+                // characters from the goal back to the start, 3 per non-delete node, then the whole string reversed (:92-108)
+                for (int32_t p = best; p >= 0 && S.nodes[p].parent >= 0; p = S.nodes[p].parent) {
+                    const ANode &nd = S.nodes[p];
+                    if ((nd.em_state >> 9) != ST_D) {
+                        if (len + 3 > a.out_cap) { status = 2; break; }
+                        for (int t = 0; t < 3; ++t) dst[len++] = "acgt-"[(nd.em_state >> (3 * t)) & 7];
+                    }
+                }
+                for (uint32_t x = 0; x < len / 2; ++x) { char t = dst[x]; dst[x] = dst[len - 1 - x]; dst[len - 1 - x] = t; }
+            }
+            a.sides[sid] = r;
+            a.out_len[sid] = len;
+            a.status[sid] = status;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) a.slot_tag[slot] = tag;
+}
+
+}  // namespace mgta
+
+using namespace mgta;
+
+static const char kCodonAA[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";   // codon.h:9-106
+
+extern "C" {
+
+int mgta_hmm_load(mgta_ctx *ctx, int M, int A, const double *msc, const double *tsc, const double *max_match, const double *h,
+                  const int32_t *alpha, mgta_hmm **out) {
+    if (!ctx || !msc || !tsc || !max_match || !h || !alpha || !out || M < 1 || M > 30000 || A < 1 || A > 64) {
+        set_error("mgta_hmm_load: bad argument");
+        return MGTA_EINVAL;
+    }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        auto hm = std::make_unique<mgta_hmm>();
+        hm->ctx = ctx; hm->M = M; hm->A = A;
+        size_t M1 = (size_t)M + 1;
+        hm->n_doubles = M1 * (A + 11);
+        std::vector<double> host(hm->n_doubles);
+        std::copy(msc, msc + M1 * A, host.begin());
+        for (size_t j = 0; j < (size_t)A; ++j) host[j] = -INFINITY;                // msc(0, .) = -inf (profile_hmm.h:58-64)
+        std::copy(tsc, tsc + 7 * M1, host.begin() + M1 * A);
+        std::copy(max_match, max_match + M1, host.begin() + M1 * (A + 7));
+        std::copy(h, h + 3 * M1, host.begin() + M1 * (A + 8));
+        hm->tab.alloc(hm->n_doubles * 8, &ctx->live_bytes, &ctx->peak_bytes);
+        MGTA_HIP_CHECK(hipMemcpy(hm->tab.p, host.data(), hm->n_doubles * 8, hipMemcpyHostToDevice));
+        for (int c = 0; c < 64; ++c) {
+            int c1 = c >> 4, c2 = (c >> 2) & 3, c3 = c & 3;
+            char f = kCodonAA[c], r = kCodonAA[(3 - c3) * 16 + (3 - c2) * 4 + (3 - c1)];   // rc_codonTable, codon.h:108-209
+            hm->col[0][c] = (int8_t)(f == '*' ? -1 : alpha[(int)f]);
+            hm->col[1][c] = (int8_t)(r == '*' ? -1 : alpha[(int)r]);
+            if ((f != '*' && alpha[(int)f] < 0) || (r != '*' && alpha[(int)r] < 0)) {
+                set_error("mgta_hmm_load: amino acid without a column in the model alphabet");
+                return MGTA_EINVAL;
+            }
+        }
+        ctx_retain(ctx);
+        *out = hm.release();
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+void mgta_hmm_free(mgta_hmm *h) {
+    if (!h) return;
+    mgta_ctx *c = h->ctx;
+    delete h;
+    ctx_release(c);
+}
+
+int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
+                     int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats) {
+    if (!g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
+    if (cache_mode != 0) {
+        set_error("cache_mode=%d: the sequential shared term_nodes cache (search ... 1) is not built yet; use 0 (cold)", cache_mode);
+        return MGTA_EUNSUPPORTED;
+    }
+    mgta_ctx *ctx = g->ctx;
+    const int klen = g->dev.k + 1;
+    if (klen > kMaxKmer) { set_error("k too large"); return MGTA_EINVAL; }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        mgta_astar_stats ST;
+        memset(&ST, 0, sizeof(ST));
+        ST.n_seeds = n;
+        hipEvent_t ev0, ev1, evk0, evk1;
+        MGTA_HIP_CHECK(hipEventCreate(&ev0)); MGTA_HIP_CHECK(hipEventCreate(&ev1));
+        MGTA_HIP_CHECK(hipEventCreate(&evk0)); MGTA_HIP_CHECK(hipEventCreate(&evk1));
+        MGTA_HIP_CHECK(hipEventRecord(ev0, st));
+        if (n == 0) { if (stats) *stats = ST; return MGTA_OK; }
+
+        // start edges: the k-mer (right search) and its reverse complement (left search), hmm_graph_search.h:163-186
+        std::vector<uint8_t> seqs((size_t)n * 2 * klen);
+        for (int64_t s = 0; s < n; ++s) {
+            const char *km = kmers + s * klen;
+            for (int i = 0; i < klen; ++i) {
+                char c = km[i];
+                int b = (c == 'A' || c == 'a') ? 1 : (c == 'C' || c == 'c') ? 2 : (c == 'G' || c == 'g' || c == 'N' || c == 'n') ? 3
+                        : (c == 'T' || c == 't') ? 4 : 0;                           // dna_map, hmm_graph_search.h:54-58
+                seqs[(size_t)(2 * s) * klen + i] = (uint8_t)b;
+                seqs[(size_t)(2 * s + 1) * klen + (klen - 1 - i)] = (uint8_t)(b ? 5 - b : 0);
+            }
+        }
+        std::vector<int64_t> start_node((size_t)n * 2);
+        int rc = mgta_sdbg_index_edges(g, seqs.data(), n * 2, start_node.data());
+        if (rc != MGTA_OK) return rc;
+
+        const double lcp = -std::log(low_cov_penalty);                              // node_enumerator.h:42
+        std::vector<double> exit_prob(3000);
+        for (int i = 0; i < 3000; ++i) exit_prob[i] = std::log(2.0 / (i + 2)) * 2;  // hmm_graph_search.h:48-52
+
+        DevBuf d_kmers, d_ss, d_sn, d_exit, d_queue, d_sides, d_out, d_len, d_status, d_todo[2];
+        const uint32_t out_cap = (uint32_t)(3 * (2 * std::max(fwd->M, rev->M) + 64));
+        d_kmers.alloc((size_t)n * klen); d_ss.alloc(n * 4); d_sn.alloc(n * 16); d_exit.alloc(3000 * 8); d_queue.alloc(16);
+        d_sides.alloc((size_t)n * 2 * sizeof(mgta_astar_side)); d_out.alloc((size_t)n * 2 * out_cap); d_len.alloc(n * 8);
+        d_status.alloc(n * 8);
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_kmers.p, kmers, (size_t)n * klen, hipMemcpyHostToDevice, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_ss.p, start_state, n * 4, hipMemcpyHostToDevice, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_sn.p, start_node.data(), n * 16, hipMemcpyHostToDevice, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(d_exit.p, exit_prob.data(), 3000 * 8, hipMemcpyHostToDevice, st));
+        MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
+
+        AstarArgs a;
+        memset(&a, 0, sizeof(a));
+        a.g = g->dev;
+        const mgta_hmm *hm[2] = {fwd, rev};
+        size_t lds_bytes = 0;
+        for (int d = 0; d < 2; ++d) {
+            a.hm[d].tab = hm[d]->tab.as<double>(); a.hm[d].M = hm[d]->M; a.hm[d].A = hm[d]->A;
+            memcpy(a.hm[d].col_fwd, hm[d]->col[0], 64);
+            memcpy(a.hm[d].col_enum, hm[d]->col[d], 64);
+            lds_bytes = std::max(lds_bytes, hm[d]->n_doubles * 8);
+        }
+        a.kmers = d_kmers.as<char>(); a.start_state = d_ss.as<int32_t>(); a.start_node = d_sn.as<int64_t>();
+        a.n_seeds = n; a.klen = klen; a.prune = prune_len; a.low_cov_penalty = lcp; a.log2v = std::log(2.0);
+        a.exit_prob = d_exit.as<double>();
+        a.queue = d_queue.as<unsigned long long>();
+        a.sides = d_sides.as<mgta_astar_side>(); a.out_seq = d_out.as<char>(); a.out_cap = out_cap; a.out_len = d_len.as<uint32_t>();
+        a.status = d_status.as<int32_t>();
+        a.use_lds = lds_bytes <= 150 * 1024;
+        if (a.use_lds)
+            MGTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(astar_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_bytes));
+
+        std::vector<int64_t> todo[2];
+        for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
+        std::vector<int32_t> h_status((size_t)n * 2);
+        uint32_t cap_nodes = 1u << 14;
+        for (int attempt = 0; attempt < 5; ++attempt) {
+            int64_t work = (int64_t)std::max(todo[0].size(), todo[1].size());
+            if (work == 0) break;
+            // persistent grid: one workgroup per CU and direction pair, fewer when there is little work
+            int blocks = std::min<int64_t>((int64_t)ctx->num_cus * (a.use_lds ? 1 : 2), 2 * ((work + kAstarWaves - 1) / kAstarWaves));
+            blocks = std::max(2, blocks + (blocks & 1));
+            uint64_t slots = (uint64_t)blocks * kAstarWaves;
+            uint32_t cap_hash = cap_nodes * 2;
+            DevBuf d_nodes, d_heap, d_hash, d_tag;
+            d_nodes.alloc(slots * cap_nodes * sizeof(ANode), &ctx->live_bytes, &ctx->peak_bytes);
+            d_heap.alloc(slots * cap_nodes * sizeof(HeapEnt), &ctx->live_bytes, &ctx->peak_bytes);
+            d_hash.alloc(slots * cap_hash * sizeof(HashEnt), &ctx->live_bytes, &ctx->peak_bytes);
+            d_tag.alloc(slots * 4, &ctx->live_bytes, &ctx->peak_bytes);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_hash.p, 0, slots * cap_hash * sizeof(HashEnt), st));
+            MGTA_HIP_CHECK(hipMemsetAsync(d_tag.p, 0, slots * 4, st));
+            MGTA_HIP_CHECK(hipMemsetAsync(d_queue.p, 0, 16, st));
+            for (int d = 0; d < 2; ++d) {
+                d_todo[d].alloc(std::max<size_t>(1, todo[d].size()) * 8);
+                if (!todo[d].empty()) MGTA_HIP_CHECK(hipMemcpyAsync(d_todo[d].p, todo[d].data(), todo[d].size() * 8, hipMemcpyHostToDevice, st));
+                a.todo[d] = d_todo[d].as<int64_t>(); a.n_todo[d] = (int64_t)todo[d].size();
+            }
+            a.nodes = d_nodes.as<ANode>(); a.heap = d_heap.as<HeapEnt>(); a.hash = d_hash.as<HashEnt>();
+            a.cap_nodes = cap_nodes; a.cap_hash = cap_hash; a.slot_tag = d_tag.as<uint32_t>();
+            MGTA_HIP_CHECK(hipEventRecord(evk0, st));
+            if (a.use_lds) hipLaunchKernelGGL((astar_kernel<true>), dim3(blocks), dim3(kAstarThreads), lds_bytes, st, a);
+            else hipLaunchKernelGGL((astar_kernel<false>), dim3(blocks), dim3(kAstarThreads), 0, st, a);
+            MGTA_HIP_CHECK(hipEventRecord(evk1, st));
+            MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            MGTA_HIP_CHECK(hipStreamSynchronize(st));
+            MGTA_HIP_CHECK(hipGetLastError());
+            float ms = 0;
+            MGTA_HIP_CHECK(hipEventElapsedTime(&ms, evk0, evk1));
+            ST.ms_kernel += ms;
+            for (int d = 0; d < 2; ++d) {
+                std::vector<int64_t> again;
+                for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
+                todo[d].swap(again);
+            }
+            ST.n_retries += (int64_t)(todo[0].size() + todo[1].size());
+            cap_nodes *= 8;                                                         // bigger arenas for the searches that overflowed
+        }
+        if (!todo[0].empty() || !todo[1].empty()) {
+            set_error("%zu searches still overflow their arena after all retries", todo[0].size() + todo[1].size());
+            return MGTA_EOVERFLOW;
+        }
+        // results
+        std::vector<mgta_astar_side> h_sides((size_t)n * 2);
+        std::vector<uint32_t> h_len((size_t)n * 2);
+        std::vector<char> h_out((size_t)n * 2 * out_cap);
+        MGTA_HIP_CHECK(hipMemcpyAsync(h_sides.data(), d_sides.p, h_sides.size() * sizeof(mgta_astar_side), hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(h_len.data(), d_len.p, h_len.size() * 4, hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipEventRecord(ev1, st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        float ms = 0;
+        MGTA_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        ST.ms_total = ms;
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(evk0); (void)hipEventDestroy(evk1);
+        std::string left;
+        for (int64_t s = 0; s < n; ++s) {
+            for (int d = 0; d < 2; ++d) {
+                if (h_status[(size_t)s * 2 + d] == 3) {
+                    set_error("seed %lld: k-mer / model position outside the model (start_state %d)", (long long)s, start_state[s]);
+                    return MGTA_EINVAL;
+                }
+                ST.n_expansions += h_sides[(size_t)s * 2 + d].n_expanded;
+                ST.n_opened += h_sides[(size_t)s * 2 + d].n_opened;
+            }
+            if (sink) {
+                const char *r = h_out.data() + (size_t)(2 * s) * out_cap;
+                const char *l = h_out.data() + (size_t)(2 * s + 1) * out_cap;
+                uint32_t ll = h_len[(size_t)2 * s + 1];
+                left.assign(ll, ' ');
+                for (uint32_t i = 0; i < ll; ++i) {                                  // RevComp, hmm_graph_search.h:362-398
+                    char c = l[ll - 1 - i];
+                    left[i] = c == 'a' ? 't' : c == 'c' ? 'g' : c == 'g' ? 'c' : c == 't' ? 'a' : c;
+                }
+                int src = sink(user, s, left.data(), (int64_t)ll, r, (int64_t)h_len[(size_t)2 * s], &h_sides[(size_t)2 * s],
+                               &h_sides[(size_t)2 * s + 1]);
+                if (src != 0) { set_error("contig sink returned %d", src); return MGTA_ESINK; }
+            }
+        }
+        if (stats) *stats = ST;
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+}  // extern "C"

@@ -59,6 +59,7 @@ struct DevBuf {
 }  // namespace mgta
 
 struct mgta_ctx {
+    int refs = 1;                 // the handle itself + every reads / graph / hmm object created from it
     int device = 0;
     hipStream_t stream = nullptr;
     uint64_t mem_limit = 0;       // 0 = auto
@@ -67,6 +68,11 @@ struct mgta_ctx {
     hipDeviceProp_t prop;
     std::vector<mgta::DevBuf> pool;   // grow-only scratch kept between calls
 };
+
+namespace mgta {
+inline void ctx_retain(mgta_ctx *c) { __atomic_add_fetch(&c->refs, 1, __ATOMIC_RELAXED); }
+void ctx_release(mgta_ctx *c);    // frees the context when the last reference goes (ctx.hip)
+}  // namespace mgta
 
 struct mgta_reads {
     mgta_ctx *ctx = nullptr;

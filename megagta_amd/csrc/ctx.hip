@@ -9,6 +9,12 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+void ctx_release(mgta_ctx *ctx) {
+    if (__atomic_sub_fetch(&ctx->refs, 1, __ATOMIC_ACQ_REL) > 0) return;   // objects created from it are still alive
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
 }  // namespace mgta
 
 extern "C" {
@@ -39,9 +45,7 @@ mgta_ctx *mgta_ctx_create(int device_id) {
 }
 
 void mgta_ctx_destroy(mgta_ctx *ctx) {
-    if (!ctx) return;
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
-    delete ctx;
+    if (ctx) mgta::ctx_release(ctx);
 }
 
 int mgta_ctx_set_mem_limit(mgta_ctx *ctx, uint64_t bytes) {

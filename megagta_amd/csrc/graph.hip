@@ -155,12 +155,18 @@ int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, con
             MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
         }
+        ctx_retain(ctx);
         *out = g.release();
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }
 }
 
-void mgta_sdbg_free(mgta_sdbg *g) { delete g; }
+void mgta_sdbg_free(mgta_sdbg *g) {
+    if (!g) return;
+    mgta_ctx *c = g->ctx;
+    delete g;
+    ctx_release(c);
+}
 int64_t mgta_sdbg_size(const mgta_sdbg *g) { return g ? g->dev.size : -1; }
 
 int mgta_sdbg_outgoing(mgta_sdbg *g, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg) {

@@ -143,7 +143,7 @@ __device__ __forceinline__ int64_t g_forward(const GraphDev &g, int64_t e) {   /
 
 __device__ __forceinline__ int g_node_last_char(const GraphDev &g, int64_t x) {   // succinct_dbg.h:109-115
     int i = 1;
-    while (!(g.f[i] > x)) ++i;
+    while (i < 5 && !(g.f[i] > x)) ++i;
     return i - 1;
 }
 

@@ -847,6 +847,7 @@ int mgta_reads_upload(mgta_ctx *ctx, const uint32_t *packed, uint64_t n_words, c
         MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         r->d_packed = r->own_packed.as<uint32_t>();
         r->d_start = r->own_start.as<uint64_t>();
+        ctx_retain(ctx);
         *out = r.release();
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }
@@ -857,11 +858,17 @@ int mgta_reads_adopt_device(mgta_ctx *ctx, const uint32_t *d_packed, uint64_t n_
     if (!ctx || !d_packed || !d_start || !out) { set_error("mgta_reads_adopt_device: null argument"); return MGTA_EINVAL; }
     auto *r = new mgta_reads;
     r->ctx = ctx; r->d_packed = d_packed; r->d_start = d_start; r->n_words = n_words; r->n_reads = n_reads;
+    ctx_retain(ctx);
     *out = r;
     return MGTA_OK;
 }
 
-void mgta_reads_free(mgta_reads *r) { delete r; }
+void mgta_reads_free(mgta_reads *r) {
+    if (!r) return;
+    mgta_ctx *c = r->ctx;
+    delete r;
+    ctx_release(c);
+}
 
 int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short_reads, int k, int min_count, int need_mercy,
                              int32_t bucket_begin, int32_t bucket_end, mgta_edge_sink sink, void *user, mgta_build_stats *stats) {

@@ -1,0 +1,98 @@
+"""Batched HMM-guided A* on the GPU vs the reference's per-seed results (golden, cold cache) and the oracle.
+Bar: contig strings exact; path log-probabilities (real_score, score) within 1e-4 relative -- in fact bit-equal;
+closed-node counts equal (path-identical search)."""
+import os
+
+import numpy as np
+import pytest
+
+from megagta_amd import hmm as hmmlib
+from megagta_amd import readlib, synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4   # tolerance named by BASELINE.json north_star for HMM path log-probabilities
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from megagta_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def toy(ctx, golden_dir):
+    from megagta_amd import api
+    d = os.path.join(golden_dir, "toy")
+    packed, start = readlib.load_for_build(os.path.join(d, "reads.lib"))
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    g = api.Graph(ctx, stream)
+    fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "for_enone.hmm")))
+    rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "rev_enone.hmm")))
+    return g, fw, rv, d
+
+
+def _close(a, b):
+    return a == b or abs(a - b) <= REL * max(abs(a), abs(b))
+
+
+def _check_side(got, ref):
+    assert got["ok"] == ref["ok"]
+    if ref["ok"]:
+        assert _close(got["real_score"], ref["real"]) and _close(got["score"], ref["score"])
+        assert got["real_score"] == ref["real"] and got["score"] == ref["score"]        # bit-equal fp64 in practice
+        assert (got["fval"], got["length"], got["state_no"], got["state"], got["node_id"]) == \
+               (ref["fval"], ref["length"], ref["state_no"], ref["state"], ref["node"])
+    assert got["n_closed"] == ref["closed"]
+
+
+@pytest.mark.parametrize("fname,prune", [("astar_cold.txt.gz", 20), ("astar_cold_prune0.txt.gz", 0)])
+def test_cold_cache_vs_reference(toy, fname, prune):
+    from megagta_amd import api
+    g, fw, rv, d = toy
+    gold = H.parse_probe_astar(H.gz_lines(os.path.join(d, fname)))
+    res, st = api.astar_search(g, fw, rv, [r["kmer"] for r in gold], [r["start_state"] for r in gold], prune, 0.5)
+    for r, ref in zip(res, gold):
+        _check_side(r.right_side, ref["R"])
+        _check_side(r.left_side, ref["L"])
+        assert r.contig(ref["kmer"]) == ref["contig"]
+    assert st["n_expansions"] == sum(r["R"]["closed"] + r["L"]["closed"] for r in gold) + \
+           sum(int(x.right_side["n_expanded"] > x.right_side["n_closed"]) + int(x.left_side["n_expanded"] > x.left_side["n_closed"]) for x in res)
+
+
+def test_vs_oracle_bigger_graph(ctx, oracle):
+    """1 gene, 20k reads, synthetic seeds (incl. k-mers absent from the graph): GPU == oracle per seed"""
+    from megagta_amd import api
+    import tempfile
+    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_gene_models(mg.genes, td)
+        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
+        seeds = synth.synthetic_seeds(mg.genes[0], 45, 300, seed=4)
+        g = api.Graph(ctx, stream)
+        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+        res, st = api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5)
+        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), 20, 0.5)
+        nexp = 0
+        for (kmer, pos), r in zip(seeds, res):
+            contig, R, L = S.search(kmer, pos - 1, cold=True)
+            assert r.contig(kmer) == contig
+            for got, ref in ((r.right_side, R), (r.left_side, L)):
+                assert got["ok"] == ref.ok and got["n_closed"] == ref.n_closed and got["n_expanded"] == ref.n_expanded
+                assert got["partial"] == ref.partial and got["n_opened"] == ref.n_opened
+                if ref.ok:
+                    assert got["real_score"] == ref.real_score and got["score"] == ref.score and got["fval"] == ref.fval
+                nexp += ref.n_expanded
+        assert st["n_expansions"] == nexp and nexp > 10000
+
+
+def test_bad_seed_is_loud(toy):
+    from megagta_amd import api
+    g, fw, rv, d = toy
+    with pytest.raises(api.MegaGtaError):
+        api.astar_search(g, fw, rv, ["A" * 45], [95], 20, 0.5)      # model position + 15 codons > M = 100
