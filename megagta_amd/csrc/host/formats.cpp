@@ -1,0 +1,315 @@
+// formats.cpp — see formats.hpp
+#include "formats.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+
+namespace mgta_host {
+
+void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "    [ERROR] ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    fflush(stderr);
+    exit(1);
+}
+void logf(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "    [megagta_amd] ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    fflush(stderr);
+}
+
+// ----------------------------------------------------------------------------------------------------
+void PackedReads::append(const uint8_t *codes, size_t n, bool reverse) {
+    if (start.empty()) start.push_back(0);
+    if (reverse) for (size_t i = n; i-- > 0;) push2(codes[i]);
+    else for (size_t i = 0; i < n; ++i) push2(codes[i]);
+    start.push_back(n_bases_);
+    max_len = std::max<int>(max_len, (int)n);
+}
+void PackedReads::finish() {
+    if (start.empty()) start.push_back(0);
+    if (acc_bits_ > 0) { words.push_back((uint32_t)(acc_ << (32 - acc_bits_))); acc_ = 0; acc_bits_ = 0; }
+    if (words.empty()) words.push_back(0);
+}
+
+void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out) {
+    std::ifstream info(prefix + ".lib_info");
+    long long total_bases = 0, num_reads = 0;
+    if (!(info >> total_bases >> num_reads)) die("cannot read %s.lib_info", prefix.c_str());
+    FILE *f = fopen((prefix + ".bin").c_str(), "rb");
+    if (!f) die("cannot open %s.bin", prefix.c_str());
+    out.words.reserve((size_t)total_bases / 16 + 16);
+    out.start.reserve((size_t)num_reads + 2);
+    std::vector<uint32_t> w;
+    std::vector<uint8_t> codes;
+    for (long long r = 0; r < num_reads; ++r) {
+        uint32_t len;
+        if (fread(&len, 4, 1, f) != 1) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
+        size_t nw = (len + 15) / 16;
+        w.resize(nw);
+        if (nw && fread(w.data(), 4, nw, f) != nw) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
+        codes.resize(len);
+        for (uint32_t i = 0; i < len; ++i) codes[i] = (w[i >> 4] >> (30 - 2 * (i & 15))) & 3;   // sequence_package.h:126-129
+        out.append(codes.data(), len, reverse);
+    }
+    fclose(f);
+    out.n_short = (uint64_t)num_reads;
+}
+
+void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out) {
+    if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") die("gzip'ed assist sequences are not supported: %s", path.c_str());
+    std::ifstream info(path + ".info");
+    long long ns = 0, nb = 0;
+    if (!(info >> ns >> nb)) die("cannot read %s.info (num_seq num_bases)", path.c_str());   // s1.cpp:105-108
+    std::ifstream f(path);
+    if (!f.is_open()) die("cannot open %s", path.c_str());
+    auto code = [](char c) -> uint8_t {                                                      // sequence_package.h:67-69
+        switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': case 'N': case 'n': return 2;
+        case 'T': case 't': return 3;
+        default: return 0;
+        }
+    };
+    std::string line;
+    std::vector<uint8_t> seq;
+    bool have = false, fastq = false;
+    auto flush = [&]() { if (have) out.append(seq.data(), seq.size(), reverse); seq.clear(); };
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') { flush(); have = true; fastq = false; continue; }
+        if (line[0] == '@' && !have) { have = true; fastq = true; continue; }
+        if (fastq && line[0] == '+') {               // quality block: skip as many characters as the sequence has
+            size_t need = seq.size(), got = 0;
+            std::string q;
+            while (got < need && std::getline(f, q)) got += q.size();
+            flush();
+            have = false;
+            continue;
+        }
+        for (char c : line) seq.push_back(code(c));
+    }
+    flush();
+}
+
+// ----------------------------------------------------------------------------------------------------
+void write_sdbg(const std::string &prefix, const EdgeStream &s) {
+    FILE *f = fopen((prefix + ".sdbg.0").c_str(), "wb");
+    if (!f) die("cannot write %s.sdbg.0", prefix.c_str());
+    FILE *info = fopen((prefix + ".sdbg_info").c_str(), "w");
+    if (!info) die("cannot write %s.sdbg_info", prefix.c_str());
+    int64_t n_tips = s.words_per_tip ? (int64_t)s.tips.size() / s.words_per_tip : 0;
+    fprintf(info, "k %d\nwords_per_tip_label %d\nnum_buckets %d\nnum_threads %d\n", s.k, s.words_per_tip, 65536, 1);
+    fprintf(info, "total_size %lld\nnum_tips %lld\nlarge_multi %lld\n", (long long)s.recs.size(), (long long)n_tips, (long long)s.large.size());
+    std::vector<unsigned char> buf;
+    size_t ri = 0, li = 0, ti = 0;
+    long long off = 0;
+    for (int b = 0; b < 65536; ++b) {
+        int64_t n = s.bucket_items[b];
+        if (n == 0) { fprintf(info, "%d -1 0 0 0 0\n", b); continue; }
+        buf.clear();
+        int64_t nt = 0, nl = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            uint16_t it = s.recs[ri++];
+            buf.insert(buf.end(), (unsigned char *)&it, (unsigned char *)&it + 2);
+            if ((it >> 8) == 255) { uint16_t m = s.large[li++]; buf.insert(buf.end(), (unsigned char *)&m, (unsigned char *)&m + 2); ++nl; }
+            if ((it >> 5) & 1) {
+                const unsigned char *p = (const unsigned char *)&s.tips[ti];
+                buf.insert(buf.end(), p, p + 4 * s.words_per_tip);
+                ti += s.words_per_tip; ++nt;
+            }
+        }
+        if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) die("write error on %s.sdbg.0", prefix.c_str());
+        fprintf(info, "%d 0 %lld %lld %lld %lld\n", b, off, (long long)n, (long long)nt, (long long)nl);
+        off += (long long)buf.size();
+    }
+    fclose(f);
+    fclose(info);
+}
+
+void read_sdbg(const std::string &prefix, EdgeStream &s) {
+    FILE *info = fopen((prefix + ".sdbg_info").c_str(), "r");
+    if (!info) die("cannot open %s.sdbg_info", prefix.c_str());
+    int nb = 0, nf = 0;
+    long long total = 0, ntips = 0, nlarge = 0;
+    if (fscanf(info, "k %d\n", &s.k) != 1 || fscanf(info, "words_per_tip_label %d\n", &s.words_per_tip) != 1 ||
+        fscanf(info, "num_buckets %d\n", &nb) != 1 || fscanf(info, "num_threads %d\n", &nf) != 1 ||
+        fscanf(info, "total_size %lld\n", &total) != 1 || fscanf(info, "num_tips %lld\n", &ntips) != 1 ||
+        fscanf(info, "large_multi %lld\n", &nlarge) != 1 || nb != 65536)
+        die("%s.sdbg_info: bad header", prefix.c_str());
+    struct Rec { int tid; long long off, items, tips, large; };
+    std::vector<Rec> recs(nb);
+    for (int b = 0; b < nb; ++b) {
+        int dummy;
+        if (fscanf(info, "%d %d %lld %lld %lld %lld\n", &dummy, &recs[b].tid, &recs[b].off, &recs[b].items, &recs[b].tips, &recs[b].large) != 6)
+            die("%s.sdbg_info: bad bucket line %d", prefix.c_str(), b);
+    }
+    fclose(info);
+    std::vector<std::vector<unsigned char>> files(nf);
+    for (int t = 0; t < nf; ++t) {
+        std::string p = prefix + ".sdbg." + std::to_string(t);
+        FILE *f = fopen(p.c_str(), "rb");
+        if (!f) die("cannot open %s", p.c_str());
+        fseek(f, 0, SEEK_END);
+        long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        files[t].resize((size_t)sz);
+        if (sz && fread(files[t].data(), 1, (size_t)sz, f) != (size_t)sz) die("read error on %s", p.c_str());
+        fclose(f);
+    }
+    s.recs.clear(); s.large.clear(); s.tips.clear();
+    s.recs.reserve((size_t)total);
+    for (int b = 0; b < nb; ++b) {
+        s.bucket_items[b] = recs[b].items; s.bucket_tips[b] = recs[b].tips; s.bucket_large[b] = recs[b].large;
+        if (recs[b].tid < 0 || recs[b].items == 0) continue;
+        const unsigned char *p = files[recs[b].tid].data() + recs[b].off;
+        for (long long i = 0; i < recs[b].items; ++i) {
+            uint16_t it;
+            memcpy(&it, p, 2); p += 2;
+            s.recs.push_back(it);
+            if ((it >> 8) == 255) { uint16_t m; memcpy(&m, p, 2); p += 2; s.large.push_back(m); }
+            if ((it >> 5) & 1)
+                for (int t = 0; t < s.words_per_tip; ++t) { uint32_t w; memcpy(&w, p, 4); p += 4; s.tips.push_back(w); }
+        }
+    }
+    if ((long long)s.recs.size() != total) die("%s: %zu records decoded, header says %lld", prefix.c_str(), s.recs.size(), total);
+}
+
+// ----------------------------------------------------------------------------------------------------
+static const double NEG_INF = -std::numeric_limits<double>::infinity();
+
+static double prob(const std::string &tok) { return tok == "*" ? 0.0 : std::exp(-1 * std::stod(tok)); }   // hmmer3b_parser.h:111-116
+
+static double heuristic(const ProfileHmm &hm, char pre, int state_no) {                                    // most_probable_path.h:48-118
+    enum { MM, MI, MD, IM, II, DM, DD };
+    const size_t M1 = (size_t)hm.M + 1;
+    double h = 0;
+    for (int i = state_no + 1; i <= hm.M; ++i) {
+        double mt, it, dt;
+        if (pre == 'm') { mt = hm.tsc[MM * M1 + i - 1]; it = hm.tsc[MI * M1 + i - 1]; dt = hm.tsc[MD * M1 + i - 1]; }
+        else if (pre == 'd') { mt = hm.tsc[DM * M1 + i - 1]; it = NEG_INF; dt = hm.tsc[DD * M1 + i - 1]; }
+        else { mt = hm.tsc[IM * M1 + i - 1]; it = hm.tsc[II * M1 + i - 1]; dt = NEG_INF; }
+        double best_m = NEG_INF;
+        for (int j = 0; j < hm.A; ++j) best_m = std::max(best_m, hm.msc[(size_t)i * hm.A + j]);
+        mt += best_m - hm.max_match[i];
+        dt -= hm.max_match[i];
+        it = NEG_INF;                                                                                      // :100
+        if (it > mt && it > dt) { h += it; pre = 'i'; --i; }
+        else if (dt > mt && dt > it) { h += dt; pre = 'd'; }
+        else { h += mt; pre = 'm'; }
+    }
+    return h;
+}
+
+bool parse_hmm(const std::string &path, ProfileHmm &hm) {
+    std::ifstream f(path);
+    if (!f.is_open()) return false;
+    std::fill(hm.alpha, hm.alpha + 127, -1);
+    std::string line, w1, w2;
+    std::getline(f, line);
+    bool got_hmm = false;
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        w1.clear(); w2.clear();
+        iss >> w1 >> w2;
+        if (w1 == "NAME") hm.name = w2;
+        else if (w1 == "LENG") hm.M = std::stoi(w2);
+        else if (w1 == "HMM") {
+            std::istringstream a(line);
+            std::string tok;
+            a >> tok;
+            int c = 0;
+            while (a >> tok) { hm.alpha[toupper(tok[0])] = c; hm.alpha[tolower(tok[0])] = c; ++c; }
+            hm.A = c;
+            got_hmm = true;
+            break;
+        }
+    }
+    if (!got_hmm || hm.M <= 0 || hm.A <= 0) die("%s: not a HMMER3 text model (LENG / HMM line missing)", path.c_str());
+    std::getline(f, line);
+    std::getline(f, line);
+    {
+        std::istringstream iss(line);
+        std::string tag, tok;
+        iss >> tag;
+        if (tag != "COMPO") die("%s: COMPO line required (hmmer3b_parser.h:63-75)", path.c_str());
+        for (int j = 0; j < hm.A; ++j) { iss >> tok; hm.compo.push_back(std::exp(-1 * std::stod(tok))); }
+    }
+    const int M = hm.M, A = hm.A;
+    const size_t M1 = (size_t)M + 1;
+    hm.msc.assign(M1 * A, 0.0);
+    hm.tsc.assign(7 * M1, 0.0);
+    hm.max_match.assign(M1, NEG_INF);
+    for (int i = 0; i <= M; ++i) {
+        std::string tok;
+        if (i > 0) {
+            std::getline(f, line);
+            std::istringstream iss(line);
+            iss >> tok;
+            for (int j = 0; j < A; ++j) {
+                iss >> tok;
+                double v = std::log(prob(tok) / hm.compo[j]);
+                hm.msc[(size_t)i * A + j] = v;
+                if (v > hm.max_match[i]) hm.max_match[i] = v;
+            }
+        }
+        std::getline(f, line);
+        std::getline(f, line);
+        std::istringstream iss(line);
+        for (int t = 0; t < 7; ++t) { iss >> tok; hm.tsc[(size_t)t * M1 + i] = std::log(prob(tok)); }
+    }
+    hm.h.assign(3 * M1, 0.0);
+    for (int i = 0; i <= M; ++i) {
+        hm.h[i] = heuristic(hm, 'm', i);
+        hm.h[M1 + i] = heuristic(hm, 'i', i);
+        hm.h[2 * M1 + i] = heuristic(hm, 'd', i);
+    }
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------
+std::vector<GeneEntry> read_gene_list(const std::string &path) {
+    std::vector<GeneEntry> out;
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        GeneEntry g;
+        iss >> g.name >> g.fwd_hmm >> g.rev_hmm;
+        out.push_back(g);
+    }
+    return out;
+}
+
+bool read_seeds(const std::string &path, std::vector<std::string> &kmers, std::vector<int32_t> &start_state) {
+    std::ifstream f(path);
+    if (!f.is_open()) return false;
+    std::string line, col[8];
+    while (std::getline(f, line)) {
+        std::istringstream iss(line);
+        for (int i = 0; i < 8; ++i) { col[i].clear(); iss >> col[i]; }
+        std::transform(col[3].begin(), col[3].end(), col[3].begin(), ::tolower);      // search.cpp:156
+        kmers.push_back(col[3]);
+        start_state.push_back(std::stoi(col[7]) - 1);                                 // search.cpp:157
+    }
+    return true;
+}
+
+}  // namespace mgta_host

@@ -1,0 +1,62 @@
+// formats.hpp — host-side file formats of the drop-in boundary (C++17, no reference code):
+//   reads.lib.bin / .lib_info   sequence_manager.cpp:375-410, read_lib_functions-inl.h:216-261
+//   assist FASTA + .info         cx1_read2sdbg_s1.cpp:104-134
+//   .sdbg.N / .sdbg_info         sdbg_multi_io.h:34-417
+//   HMMER3 text models           hmmer3b_parser.h:19-201, most_probable_path.h:48-118
+//   gene_list.txt, *_starting_kmers.txt   search.cpp:105-162
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mgta_host {
+
+[[noreturn]] void die(const char *fmt, ...);
+void logf(const char *fmt, ...);   // stderr progress line, "    [file:line] ..." style is not required by the driver
+
+// ---- packed reads ---------------------------------------------------------------------------------
+struct PackedReads {
+    std::vector<uint32_t> words;     // 2 bit / base, base j of a word at bits 30-2j, reads concatenated
+    std::vector<uint64_t> start;     // [n+1] in bases
+    uint64_t n_short = 0;            // reads that came from the library (the rest are assist sequences)
+    int max_len = 0;
+    void append(const uint8_t *codes, size_t n, bool reverse);
+    void finish();
+  private:
+    uint64_t acc_ = 0;
+    int acc_bits_ = 0;
+    uint64_t n_bases_ = 0;
+    void push2(unsigned c) {
+        acc_ = (acc_ << 2) | c; acc_bits_ += 2; ++n_bases_;
+        if (acc_bits_ == 32) { words.push_back((uint32_t)acc_); acc_ = 0; acc_bits_ = 0; }
+    }
+};
+void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out);          // ReadBinaryLibs
+void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out);        // s1.cpp:104-134
+
+// ---- SdBG files -------------------------------------------------------------------------------------
+struct EdgeStream {
+    int k = 0, words_per_tip = 0;
+    std::vector<int64_t> bucket_items = std::vector<int64_t>(65536, 0), bucket_tips = std::vector<int64_t>(65536, 0),
+                         bucket_large = std::vector<int64_t>(65536, 0);
+    std::vector<uint16_t> recs, large;
+    std::vector<uint32_t> tips;
+};
+void write_sdbg(const std::string &prefix, const EdgeStream &s);   // one file PREFIX.sdbg.0 + PREFIX.sdbg_info
+void read_sdbg(const std::string &prefix, EdgeStream &s);
+
+// ---- profile HMM --------------------------------------------------------------------------------------
+struct ProfileHmm {
+    std::string name;
+    int M = 0, A = 0;
+    int32_t alpha[127];
+    std::vector<double> compo, msc, tsc, max_match, h;   // msc [(M+1)*A], tsc [7*(M+1)], h [3*(M+1)]
+};
+bool parse_hmm(const std::string &path, ProfileHmm &hm);
+
+// ---- search inputs ------------------------------------------------------------------------------------
+struct GeneEntry { std::string name, fwd_hmm, rev_hmm; };
+std::vector<GeneEntry> read_gene_list(const std::string &path);                           // search.cpp:105-122
+bool read_seeds(const std::string &path, std::vector<std::string> &kmers, std::vector<int32_t> &start_state);   // :146-162
+
+}  // namespace mgta_host

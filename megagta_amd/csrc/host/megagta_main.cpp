@@ -1,0 +1,226 @@
+// megagta_main.cpp — `megagta buildgraph` / `megagta search`: the process-level drop-in boundary
+// (argv, files, stderr, exit code) of the reference's multi-call binary (megagta.cpp:33-78) for the
+// two sub-commands on the hot path.  Host code only; all compute goes through the C ABI of
+// libmegagta_hip.so.  Other sub-commands (buildlib, denovo, findstart, filterbylen, translate,
+// readstat) are outside the path and are NOT provided here.
+//
+//   buildgraph  -k INT -m INT --host_mem F --mem_flag INT --gpu_mem F --output_prefix STR
+//               --num_cpu_threads INT --num_output_threads INT --read_lib_file STR
+//               [--need_mercy] [--assist_seq FASTA]                       build_graph.cpp:38-48
+//   search      <sdbg_prefix> <gene_list> <starting_kmers_prefix> <output_prefix> <prune_len>
+//               <low_cov_penalty> [num_threads]                            search.cpp:72-90
+#include <getopt.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/megagta_hip.h"
+#include "formats.hpp"
+
+using namespace mgta_host;
+
+static double now_s() {
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+struct RssLine {   // AutoMaxRssRecorder, utils.h:99-128
+    double t0 = now_s();
+    ~RssLine() {
+        struct rusage u;
+        getrusage(RUSAGE_SELF, &u);
+        logf("Real: %.4lf\tuser: %.4lf\tsys: %.4lf\tmaxrss: %ld", now_s() - t0, u.ru_utime.tv_sec + 1e-6 * u.ru_utime.tv_usec,
+             u.ru_stime.tv_sec + 1e-6 * u.ru_stime.tv_usec, u.ru_maxrss);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+static int sink_collect(void *user, int32_t b0, int32_t b1, const int64_t *counts, const uint16_t *recs, int64_t n, const uint16_t *large,
+                        int64_t nl, const uint32_t *tips, int64_t ntw) {
+    EdgeStream &s = *static_cast<EdgeStream *>(user);
+    for (int32_t b = b0; b < b1; ++b) {
+        s.bucket_items[b] = counts[3 * (b - b0)];
+        s.bucket_large[b] = counts[3 * (b - b0) + 1];
+        s.bucket_tips[b] = counts[3 * (b - b0) + 2];
+    }
+    s.recs.insert(s.recs.end(), recs, recs + n);
+    s.large.insert(s.large.end(), large, large + nl);
+    s.tips.insert(s.tips.end(), tips, tips + ntw);
+    return 0;
+}
+
+static int main_buildgraph(int argc, char **argv) {
+    RssLine rss;
+    int k = 0, min_count = 0, mem_flag = 1, n_threads = 0, n_out_threads = 0, need_mercy = 0;
+    double host_mem = 0, gpu_mem = 0;
+    std::string out_prefix, lib_file, assist;
+    static struct option opts[] = {{"kmer_k", required_argument, 0, 'k'}, {"min_kmer_frequency", required_argument, 0, 'm'},
+                                   {"host_mem", required_argument, 0, 1}, {"gpu_mem", required_argument, 0, 2},
+                                   {"num_cpu_threads", required_argument, 0, 3}, {"num_output_threads", required_argument, 0, 4},
+                                   {"read_lib_file", required_argument, 0, 5}, {"assist_seq", required_argument, 0, 6},
+                                   {"output_prefix", required_argument, 0, 7}, {"mem_flag", required_argument, 0, 8},
+                                   {"need_mercy", no_argument, 0, 9}, {0, 0, 0, 0}};
+    optind = 1;
+    int ch;
+    bool bad = false;
+    while ((ch = getopt_long(argc, argv, "k:m:", opts, nullptr)) != -1) {
+        switch (ch) {
+        case 'k': k = atoi(optarg); break;
+        case 'm': min_count = atoi(optarg); break;
+        case 1: host_mem = atof(optarg); break;
+        case 2: gpu_mem = atof(optarg); break;
+        case 3: n_threads = atoi(optarg); break;
+        case 4: n_out_threads = atoi(optarg); break;
+        case 5: lib_file = optarg; break;
+        case 6: assist = optarg; break;
+        case 7: out_prefix = optarg; break;
+        case 8: mem_flag = atoi(optarg); break;
+        case 9: need_mercy = 1; break;
+        default: bad = true;
+        }
+    }
+    // same argument checks and messages as build_graph.cpp:52-83
+    const char *why = nullptr;
+    if (bad) why = "uknown option";
+    else if (lib_file.empty()) why = "No input file!";
+    else if (host_mem == 0) why = "Please specify the host memory!";
+    else if (n_threads == 1) why = "Number of CPU threads should be at least 2!";
+    else if (n_threads != 0 && n_out_threads >= n_threads) why = "Number of output threads must be less than number of CPU threads!";
+    if (why) {
+        fprintf(stderr, "%s\nUsage: sdbg_builder read2sdbg --read_lib_file fastx_file -o out\n", why);
+        return 1;
+    }
+    (void)mem_flag;
+    if (min_count < 1) min_count = 1;
+
+    double t0 = now_s();
+    PackedReads pr;
+    load_read_lib(lib_file, /*reverse=*/true, pr);                       // cx1_read2sdbg_s1.cpp:97,117
+    if (!assist.empty()) load_assist_fasta(assist, /*reverse=*/true, pr); // :121-134
+    pr.finish();
+    logf("%zu reads, %d max read length, %llu total bases (load %.3f s)", pr.start.size() - 1, pr.max_len,
+         (unsigned long long)pr.start.back(), now_s() - t0);
+
+    mgta_ctx *ctx = mgta_ctx_create(0);
+    if (!ctx) die("%s", mgta_last_error());
+    if (gpu_mem > 0) mgta_ctx_set_mem_limit(ctx, (uint64_t)gpu_mem);
+    EdgeStream s;
+    s.k = k; s.words_per_tip = (2 * k + 31) / 32;
+    mgta_build_stats st;
+    int rc = mgta_sdbg_build(ctx, pr.words.data(), pr.words.size(), pr.start.data(), pr.start.size() - 1, pr.n_short, k, min_count,
+                             min_count > 1 ? need_mercy : 0, sink_collect, &s, &st);
+    if (rc != MGTA_OK) die("mgta_sdbg_build: %s", mgta_last_error());
+    mgta_ctx_destroy(ctx);
+    logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
+         (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);
+    double t1 = now_s();
+    write_sdbg(out_prefix, s);
+    long long nw[9] = {0};
+    for (uint16_t r : s.recs) nw[r & 15]++;
+    logf("Number of $ A C G T A- C- G- T-:");                           // s2_post_proc, cx1_read2sdbg_s2.cpp:899-915
+    logf("%lld %lld %lld %lld %lld %lld %lld %lld %lld", nw[0], nw[1], nw[2], nw[3], nw[4], nw[5], nw[6], nw[7], nw[8]);
+    logf("Total number of edges: %zu", s.recs.size());
+    logf("Total number of $v edges: %zu (write %.3f s)", s.words_per_tip ? s.tips.size() / s.words_per_tip : 0, now_s() - t1);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct FastaOut {
+    FILE *f;
+    const std::string *gene;
+    const std::vector<std::string> *kmers;
+};
+static int sink_contig(void *user, int64_t i, const char *left, int64_t ll, const char *right, int64_t rl, const mgta_astar_side *,
+                       const mgta_astar_side *) {
+    FastaOut &o = *static_cast<FastaOut *>(user);                        // hmm_graph_search.h:79
+    fprintf(o.f, ">%s_contig_%lld_contig_%lld\n%.*s%s%.*s\n", o.gene->c_str(), (long long)(2 * i), (long long)(2 * i + 1), (int)ll, left,
+            (*o.kmers)[i].c_str(), (int)rl, right);
+    return 0;
+}
+
+static mgta_hmm *upload_hmm(mgta_ctx *ctx, const std::string &path) {
+    ProfileHmm hm;
+    if (!parse_hmm(path, hm)) die("cannot open HMM %s", path.c_str());
+    mgta_hmm *out = nullptr;
+    if (mgta_hmm_load(ctx, hm.M, hm.A, hm.msc.data(), hm.tsc.data(), hm.max_match.data(), hm.h.data(), hm.alpha, &out) != MGTA_OK)
+        die("mgta_hmm_load(%s): %s", path.c_str(), mgta_last_error());
+    return out;
+}
+
+static int main_search(int argc, char **argv) {
+    RssLine rss;
+    if (argc < 7) {
+        fprintf(stderr, "Usage: %s <succinct_dbg> <gene_list> <starting_kmers_prefix> <output_prefix> <prune_len> <low_cov_penalty> [num_threads=0]\n",
+                argv[0]);
+        return 1;
+    }
+    int prune = atoi(argv[5]);
+    double pen = atof(argv[6]);
+    // argv[7] (num_threads) is accepted and ignored: the batch runs on the device
+    double t0 = now_s();
+    logf("Loading SdBG...");
+    EdgeStream s;
+    read_sdbg(argv[1], s);
+    mgta_ctx *ctx = mgta_ctx_create(0);
+    if (!ctx) die("%s", mgta_last_error());
+    mgta_sdbg *g = nullptr;
+    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
+                       s.words_per_tip, &g) != MGTA_OK)
+        die("mgta_sdbg_load: %s", mgta_last_error());
+    logf("Done! Time elapsed: %.4lf", now_s() - t0);
+    const size_t klen = (size_t)s.k + 1;
+    for (const GeneEntry &gene : read_gene_list(argv[2])) {
+        double tg = now_s();
+        logf("START %s", gene.name.c_str());
+        mgta_hmm *fw = upload_hmm(ctx, gene.fwd_hmm), *rv = upload_hmm(ctx, gene.rev_hmm);
+        std::vector<std::string> kmers;
+        std::vector<int32_t> start;
+        std::string sk = std::string(argv[3]) + "_" + gene.name + "_starting_kmers.txt";
+        std::string on = std::string(argv[4]) + "_raw_contigs_" + gene.name + ".fasta";
+        FILE *out = fopen(on.c_str(), "w");
+        if (!out) die("cannot write %s", on.c_str());
+        if (!read_seeds(sk, kmers, start)) {                              // search.cpp:163-167: report and go on
+            fprintf(stderr, "    [ERROR] Fail to open %s\n", sk.c_str());
+            fclose(out);
+            mgta_hmm_free(fw); mgta_hmm_free(rv);
+            continue;
+        }
+        logf("Searching from %zu starting kmers", kmers.size());
+        std::string flat;
+        flat.reserve(kmers.size() * klen);
+        for (const std::string &km : kmers) {
+            if (km.size() < klen) die("%s: seed k-mer shorter than k+1 = %zu", sk.c_str(), klen);
+            flat.append(km, 0, klen);
+        }
+        FastaOut fo{out, &gene.name, &kmers};
+        mgta_astar_stats st;
+        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, 0, sink_contig, &fo, &st) != MGTA_OK)
+            die("mgta_astar_batch: %s", mgta_last_error());
+        fclose(out);
+        mgta_hmm_free(fw); mgta_hmm_free(rv);
+        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device)", gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total);
+    }
+    mgta_sdbg_free(g);
+    mgta_ctx_destroy(ctx);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) {
+        fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs on the MI355X hot path:\n        buildgraph    build succinct de Bruijn graph\n"
+                        "        search        HMM-guided search of gene contigs\n        dumpversion   dump version\n", argv[0]);
+        return 1;
+    }
+    std::string sub = argv[1];
+    if (sub == "buildgraph") return main_buildgraph(argc - 1, argv + 1);
+    if (sub == "search") return main_search(argc - 1, argv + 1);
+    if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
+    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildgraph, search): run it with the reference's megagta binary\n", sub.c_str());
+    return 1;
+}

@@ -879,7 +879,7 @@ int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_sho
         set_error("bucket range [%d,%d) invalid", bucket_begin, bucket_end);
         return MGTA_EINVAL;
     }
-    if (min_count != 1 || need_mercy) {
+    if (min_count != 1) {   // need_mercy only acts when min_count > 1 (s2_read_mercy_prepare, cx1_read2sdbg_s2.cpp:106-107)
         set_error("min_count=%d need_mercy=%d: stage 1 (solid-edge counting, cx1_read2sdbg_s1.cpp) is not built yet", min_count, need_mercy);
         return MGTA_EUNSUPPORTED;
     }

@@ -1,0 +1,97 @@
+"""The process-level drop-in boundary: `megagta buildgraph` / `megagta search` (C++ host + libmegagta_hip.so)
+driven by the Python-3 driver, next to the stock reference binary for the steps outside the path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from megagta_amd import synth
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
+BIN = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
+DRIVER = os.path.join(ROOT, "megagta_amd", "megagta.py")
+
+
+def _need():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/megagta (the prebuilt reference) is not present")
+    assert os.path.exists(BIN), "megagta_amd/bin/megagta missing: run __graft_entry__.build()"
+
+
+@pytest.fixture(scope="module")
+def toy_inputs(tmp_path_factory, golden_dir):
+    d = tmp_path_factory.mktemp("e2e")
+    mg = synth.make_metagenome(6000, 150, (("rplB", 100),), seed=11, reads_per_genome=1000)    # == tests/golden/toy
+    synth.write_fasta(mg.reads, str(d / "reads.fa"))
+    toy = os.path.join(golden_dir, "toy")
+    (d / "gene_list.txt").write_text(f"rplB {toy}/for_enone.hmm {toy}/rev_enone.hmm {toy}/ref_aligned.faa\n")
+    return d
+
+
+def test_single_k_pipeline_matches_reference_artifacts(toy_inputs, oracle, golden_dir):
+    _need()
+    d = toy_inputs
+    out = d / "out1"
+    r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "45", "-o", str(out),
+                        "-t", "4", "--ref-bin", REF], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
+    toy = os.path.join(golden_dir, "toy")
+    # graph files written by OUR buildgraph decode (with the oracle's reader = the reference format) to the reference's stream
+    s = oracle.Stream.read(str(out / "k44" / "44")).edges()
+    assert s.md5() == H.load_streams(os.path.join(toy, "sdbg_streams.json"))["44"]["md5"]
+    # seeds come from the reference's findstart on OUR reads.lib.bin -> identical to the golden seed file
+    assert (out / "k44" / "44_rplB_starting_kmers.txt").read_text() == open(os.path.join(toy, "44_rplB_starting_kmers.txt")).read()
+    # contigs: one record per seed, names as hmm_graph_search.h:79, sequences == per-seed cold-cache results of the reference
+    gold = H.parse_probe_astar(H.gz_lines(os.path.join(toy, "astar_cold.txt.gz")))
+    lines = (out / "k44" / "44_raw_contigs_rplB.fasta").read_text().splitlines()
+    assert lines[0::2] == [f">rplB_contig_{2 * i}_contig_{2 * i + 1}" for i in range(len(gold))]
+    assert lines[1::2] == [g["contig"] for g in gold]
+    # driver artefacts
+    assert (out / "opts.txt").exists() and (out / "contigs" / "rplB" / "nucl_merged.fasta").exists()
+    done = [l.split() for l in (out / "tmp" / "cp.txt").read_text().splitlines()]
+    assert [int(a[0]) for a in done] == list(range(len(done))) and all(a[1] == "done" for a in done)
+
+
+def test_assist_seq_graph_matches_reference(toy_inputs, oracle):
+    """multi-k step: k=29 graph (ours) -> denovo (reference) -> k=44 graph with --assist_seq: ours == reference's, bit for bit"""
+    _need()
+    d = toy_inputs
+    w = d / "mk"
+    w.mkdir()
+    (w / "reads.lib").write_text(f"reads.fa\nse {d / 'reads.fa'}\n")
+    run = lambda cmd: subprocess.run(cmd, check=True, capture_output=True)
+    run([REF, "buildlib", str(w / "reads.lib"), str(w / "reads.lib")])
+    common = ["-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4",
+              "--num_output_threads", "1", "--read_lib_file", str(w / "reads.lib")]
+    run([BIN, "buildgraph", "-k", "29", "--output_prefix", str(w / "29")] + common)
+    run([REF, "denovo", "-s", str(w / "29"), "-o", str(w / "29"), "-t", "4", "--min_standalone", "400", "--max_tip_len", "150",
+         "--min_contig", "45"])
+    assert os.path.getsize(w / "29.contigs.fa") > 0
+    run([BIN, "buildgraph", "-k", "44", "--output_prefix", str(w / "ours44"), "--assist_seq", str(w / "29.contigs.fa")] + common)
+    run([REF, "buildgraph", "-k", "44", "--output_prefix", str(w / "ref44"), "--assist_seq", str(w / "29.contigs.fa")] + common)
+    a, b = oracle.Stream.read(str(w / "ours44")).edges(), oracle.Stream.read(str(w / "ref44")).edges()
+    assert a.md5() == b.md5() and a.records.size > 0
+    # and the reference's own `search` accepts our graph files
+    (w / "gl.txt").write_text((d / "gene_list.txt").read_text())
+    with open(w / "ours44_rplB_starting_kmers.txt", "w") as f:
+        subprocess.run([REF, "findstart", (d / "gene_list.txt").read_text().split()[3], str(w / "reads.lib.bin"), "45", "1"], stdout=f,
+                       check=True, stderr=subprocess.DEVNULL)
+    run([REF, "search", str(w / "ours44"), str(w / "gl.txt"), str(w / "ours44"), str(w / "refsearch"), "20", "0.5", "1"])
+    assert os.path.getsize(w / "refsearch_raw_contigs_rplB.fasta") > 0
+
+
+def test_error_behaviour():
+    _need()
+    r = subprocess.run([BIN, "buildgraph", "-k", "44", "-m", "1", "--host_mem", "1e9"], capture_output=True, text=True)
+    assert r.returncode == 1 and "No input file!" in r.stderr                         # build_graph.cpp:52-54
+    r = subprocess.run([BIN, "buildgraph", "-k", "44", "-m", "1", "--host_mem", "1e9", "--read_lib_file", "x", "--num_cpu_threads", "1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "at least 2" in r.stderr                              # :69-71
+    r = subprocess.run([BIN, "search", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr                                   # search.cpp:72-75
+    r = subprocess.run([BIN, "denovo"], capture_output=True, text=True)
+    assert r.returncode == 1
