@@ -141,8 +141,11 @@ typedef int (*mgta_contig_sink)(void *user, int64_t seed_index, const char *left
                                 const mgta_astar_side *left_side);
 
 /* kmers: n x (k+1) characters ACGT (any case), start_state[i] = model position - 1 (search.cpp:157).
- * cache_mode 0 = cold (every seed independent, embarrassingly parallel);
- * cache_mode 1 = warm, seeds processed sequentially sharing the term_nodes caches like `search ... 1`. */
+ * cache_mode 0 = cold: every seed independent (empty term_nodes caches), embarrassingly parallel;
+ * cache_mode B >= 1 = shared term_nodes caches (search.cpp:182) with an ordered-commit window: the search of seed j
+ *   sees exactly the paths found by seeds <= j - B, whatever the scheduling.  B = 1 is the reference's sequential
+ *   run (`search ... 1`, bit-identical FASTA); larger B trades that equivalence for up to B searches in flight per
+ *   direction while staying deterministic. */
 int mgta_astar_batch(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
                      const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
                      int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);

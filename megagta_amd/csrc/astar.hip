@@ -64,6 +64,13 @@ struct HashEnt {
     uint32_t tag;                 // entry is live iff tag == the search's tag
 };
 
+struct CacheEnt {
+    unsigned long long key;       // parent key (0 = empty)
+    unsigned long long val;       // ~(owner seed << 16 | em_state of the child (nucl_emission | state << 9)); 0 = unset.
+                                  // One atomicMax of the complement keeps the lowest owner = "first insert wins" of the
+                                  // sequential reference (and lets the table start as all-zero bytes).
+};
+
 struct HmmView {
     const double *tab;
     int M, A;
@@ -91,8 +98,15 @@ struct AstarArgs {
     uint32_t *slot_tag;
     mgta_astar_side *sides;       // [2n]
     char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
-    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = arena overflow, 3 = bad seed
+    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = arena overflow, 3 = bad seed, 4 = gate timeout
     int use_lds;
+    // shared term_nodes caches (search.cpp:182), one per direction.  window = 0: off (cold).  window = B >= 1: the
+    // search of seed j sees exactly the paths committed by seeds <= j - B (B = 1: the reference's sequential run).
+    int window;
+    CacheEnt *cache[2];
+    uint64_t cache_mask[2];
+    unsigned long long *frontier; // [2] number of leading seeds whose search of that direction has committed
+    uint32_t *committed;          // [2][n] flags
 };
 
 __device__ __forceinline__ int to_fval(double x) {   // (int)x as x86-64 cvttsd2si does it (INT_MIN when out of range / NaN)
@@ -181,6 +195,49 @@ __device__ __forceinline__ bool node_less(const ANode &a, int fval, int state_no
     return make_prio(a.fval, a.state_no, a.em_state >> 9) < make_prio(fval, state_no, st);
 }
 
+// agent-scope accesses: the caches / frontier are written by other CUs (and XCDs) of the same launch
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// child descriptor cached for `key` and visible to seed `seed` under window B, or -1
+__device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
+    const CacheEnt *tab = a.cache[dir];
+    uint64_t i = mix64(key) & a.cache_mask[dir];
+    while (true) {
+        unsigned long long k = ld_agent(&tab[i].key);
+        if (k == 0) return -1;
+        if (k == key) {
+            unsigned long long v = ld_agent(&tab[i].val);
+            if (v == 0ull) return -1;
+            v = ~v;
+            int64_t owner = (int64_t)(v >> 16);
+            return owner <= seed - a.window ? (int)(v & 0xFFFF) : -1;
+        }
+        i = (i + 1) & a.cache_mask[dir];
+    }
+}
+__device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t seed, int em_state) {
+    CacheEnt *tab = a.cache[dir];
+    uint64_t i = mix64(key) & a.cache_mask[dir];
+    unsigned long long v = ((unsigned long long)seed << 16) | (unsigned long long)(em_state & 0xFFFF);
+    while (true) {
+        unsigned long long k = ld_agent(&tab[i].key);
+        if (k == 0) {
+            unsigned long long expect = 0;
+            if (__hip_atomic_compare_exchange_strong(&tab[i].key, &expect, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                k = key;
+            else
+                k = expect;
+        }
+        if (k == key) {
+            __hip_atomic_fetch_max(&tab[i].val, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        i = (i + 1) & a.cache_mask[dir];
+    }
+}
+
 template <bool LDS>
 __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     extern __shared__ __align__(16) double s_tab[];
@@ -216,6 +273,24 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         if (qi >= a.n_todo[dir]) break;
         const int64_t seed = a.todo[dir][qi];
         const int64_t sid = seed * 2 + dir;
+        if (a.window > 0) {
+            // seeds are taken in order; wait until every seed <= seed - window has committed its path.
+            // The seed at the frontier is always held by a running wave, so this terminates; the spin is bounded anyway.
+            int gate_ok = 1;
+            if (lane == 0) {
+                long long need = (long long)seed - a.window + 1;
+                unsigned long long spins = 0;
+                while ((long long)ld_agent(&a.frontier[dir]) < need) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > (1ull << 28)) { gate_ok = 0; break; }
+                }
+            }
+            gate_ok = __shfl(gate_ok, 0, 64);
+            if (!gate_ok) {
+                if (lane == 0) a.status[sid] = 4;
+                break;
+            }
+        }
         ++tag;
         S.tag = tag; S.n_nodes = 0; S.n_heap = 0; S.n_keys = 0; S.overflow = false;
 
@@ -350,6 +425,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
                 const double max_match = maxm[next_state];
                 const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
+                // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
+                const int cached = a.window > 0 ? cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), seed) : -1;
+                const int cached_st = cached >= 0 ? (cached >> 9) : -1;
+                bool stop = false;                                                  // `return` inside enumerateNodes
 
                 auto admit = [&](ANode &nx) {
                     const int nst = nx.em_state >> 9;
@@ -380,12 +459,17 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 };
 
                 uint64_t vm = vmask;
-                while (vm && !S.overflow) {
+                while (vm && !S.overflow && !stop) {
                     int l = __builtin_ctzll(vm);
                     vm &= vm - 1;
                     int64_t p = s_codon[wv][l];
                     int col = hv.col_enum[(int)((p >> 6) & 7) * 16 + (int)((p >> 3) & 7) * 4 + (int)(p & 7)];
                     if (col < 0) continue;                                          // stop codon (:142-144)
+                    if (cached >= 0) {                                              // child_node->node_id != packed >> 16 (:146-148)
+                        // a 3-edge path is fixed by its end edge, so "same node id" == "same codon" for m/i children;
+                        // a cached delete child carries the parent's own node id
+                        if (cached_st == ST_D ? ((p >> 16) != curr.node_id) : ((int)(p & 511) != (cached & 511))) continue;
+                    }
                     double pen = (p & (1 << 9)) ? a.low_cov_penalty : 0.0;          // :150
                     ANode nx;
                     nx.parent = cur; nx.node_id = p >> 16;
@@ -399,6 +483,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     nx.fval = to_fval(10000 * (nx.score + 2.0 * h_m));              // :173
                     nx.em_state = (uint16_t)((p & 511) | (ST_M << 9));
                     admit(nx);
+                    if (cached_st == ST_M) { stop = true; break; }                  // *child_node == next -> return (:178-181)
                     if (cst != ST_D) {                                              // insert child (:189-214); isc == 0 except at M
                         double isc = next_state == M ? NEG_INF : 0.0;
                         double ei = it + isc;
@@ -412,9 +497,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         ni.fval = to_fval(10000 * (ni.score + 2.0 * h_i));
                         ni.em_state = (uint16_t)((p & 511) | (ST_I << 9));
                         admit(ni);
+                        if (cached_st == ST_I) { stop = true; break; }              // (:207-210)
                     }
                 }
-                if (cst != ST_I && !S.overflow) {                                   // delete child (:218-244)
+                if (cst != ST_I && !S.overflow && !stop) {                          // delete child (:218-244)
                     ANode nd;
                     nd.parent = cur; nd.node_id = curr.node_id;
                     nd.state_no = (int16_t)next_state; nd.length = curr.length;
@@ -463,6 +549,28 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             a.sides[sid] = r;
             a.out_len[sid] = len;
             a.status[sid] = status;
+            if (a.window > 0) {
+                // partialResultFromGoal: term_nodes.insert(parent -> child) along the reported path (:97-103)
+                if (status == 1 && ok && goal >= 0) {
+                    int32_t best = goal;
+                    for (int32_t p = S.nodes[goal].parent; p >= 0; p = S.nodes[p].parent)
+                        if (S.nodes[p].real_score > S.nodes[best].real_score) best = p;
+                    for (int32_t p = best; p >= 0 && S.nodes[p].parent >= 0; p = S.nodes[p].parent) {
+                        const ANode &par = S.nodes[S.nodes[p].parent];
+                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9), seed, S.nodes[p].em_state);
+                    }
+                }
+                __threadfence();
+                __hip_atomic_store(&a.committed[(size_t)dir * a.n_seeds + seed], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                while (true) {                                                      // advance the commit frontier
+                    unsigned long long F = ld_agent(&a.frontier[dir]);
+                    if ((long long)F >= a.n_seeds) break;
+                    unsigned int c = __hip_atomic_fetch_add(&a.committed[(size_t)dir * a.n_seeds + F], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!c) break;
+                    unsigned long long e = F;
+                    __hip_atomic_compare_exchange_strong(&a.frontier[dir], &e, F + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -523,10 +631,7 @@ void mgta_hmm_free(mgta_hmm *h) {
 int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
                      int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats) {
     if (!g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
-    if (cache_mode != 0) {
-        set_error("cache_mode=%d: the sequential shared term_nodes cache (search ... 1) is not built yet; use 0 (cold)", cache_mode);
-        return MGTA_EUNSUPPORTED;
-    }
+    if (cache_mode < 0) { set_error("cache_mode must be >= 0"); return MGTA_EINVAL; }
     mgta_ctx *ctx = g->ctx;
     const int klen = g->dev.k + 1;
     if (klen > kMaxKmer) { set_error("k too large"); return MGTA_EINVAL; }
@@ -599,11 +704,35 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
         std::vector<int32_t> h_status((size_t)n * 2);
         uint32_t cap_nodes = 1u << 14;
-        for (int attempt = 0; attempt < 5; ++attempt) {
+        // warm modes: seeds must run in order in ONE launch (no re-runs), so the arenas are sized generously up front
+        DevBuf d_cache[2], d_frontier, d_committed;
+        a.window = cache_mode;
+        if (cache_mode > 0) {
+            cap_nodes = 1u << 18;
+            for (int d = 0; d < 2; ++d) {
+                uint64_t want = 2ull * (uint64_t)n * (2ull * (uint64_t)hm[d]->M + 64), cap = 1024;
+                while (cap < want) cap <<= 1;
+                d_cache[d].alloc(cap * sizeof(CacheEnt), &ctx->live_bytes, &ctx->peak_bytes);
+                MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, cap * sizeof(CacheEnt), st));
+                a.cache[d] = d_cache[d].as<CacheEnt>(); a.cache_mask[d] = cap - 1;
+            }
+            d_frontier.alloc(16); d_committed.alloc((size_t)n * 2 * 4);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_frontier.p, 0, 16, st));
+            MGTA_HIP_CHECK(hipMemsetAsync(d_committed.p, 0, (size_t)n * 2 * 4, st));
+            a.frontier = d_frontier.as<unsigned long long>(); a.committed = d_committed.as<uint32_t>();
+        }
+        for (int attempt = 0; attempt < (cache_mode > 0 ? 1 : 5); ++attempt) {
             int64_t work = (int64_t)std::max(todo[0].size(), todo[1].size());
             if (work == 0) break;
             // persistent grid: one workgroup per CU and direction pair, fewer when there is little work
             int blocks = std::min<int64_t>((int64_t)ctx->num_cus * (a.use_lds ? 1 : 2), 2 * ((work + kAstarWaves - 1) / kAstarWaves));
+            if (cache_mode > 0) {   // at most `window` searches of a direction can be in flight; cap the arena footprint
+                blocks = std::min<int64_t>(blocks, 2 * (((int64_t)cache_mode + kAstarWaves - 1) / kAstarWaves));
+                size_t free_b = 0, total_b = 0;
+                MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                uint64_t per_slot = (uint64_t)cap_nodes * (sizeof(ANode) + sizeof(HeapEnt) + 2 * sizeof(HashEnt));
+                while (blocks > 2 && (uint64_t)blocks * kAstarWaves * per_slot > free_b * 0.6) blocks -= 2;
+            }
             blocks = std::max(2, blocks + (blocks & 1));
             uint64_t slots = (uint64_t)blocks * kAstarWaves;
             uint32_t cap_hash = cap_nodes * 2;
@@ -641,9 +770,14 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             cap_nodes *= 8;                                                         // bigger arenas for the searches that overflowed
         }
         if (!todo[0].empty() || !todo[1].empty()) {
-            set_error("%zu searches still overflow their arena after all retries", todo[0].size() + todo[1].size());
+            set_error("%zu searches still overflow their arena (%u nodes) after all retries", todo[0].size() + todo[1].size(), cap_nodes / 8);
             return MGTA_EOVERFLOW;
         }
+        for (int64_t s = 0; s < n * 2; ++s)
+            if (h_status[(size_t)s] == 4 || h_status[(size_t)s] == 0) {
+                set_error("search %lld did not run (ordered-commit gate timed out)", (long long)s);
+                return MGTA_EHIP;
+            }
         // results
         std::vector<mgta_astar_side> h_sides((size_t)n * 2);
         std::vector<uint32_t> h_len((size_t)n * 2);

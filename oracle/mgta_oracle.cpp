@@ -612,6 +612,12 @@ struct Searcher {
     double low_cov_penalty;                                 // -log(low_cov_pen), node_enumerator.h:42
     double exit_prob[3000];                                 // hmm_graph_search.h:48-52
     Cache cache[2];
+    // windowed warm mode: seed j sees the paths of seeds <= j - window (window 1 == the reference's sequential sharing)
+    int window = 1;
+    int64_t seed_counter = 0;
+    struct Pending { int64_t seed; int dir; Key parent, child; };
+    std::vector<Pending> pending;
+    int cur_dir = 0;
     std::vector<Node *> pool;
     Node *alloc() { pool.push_back(new Node); return pool.back(); }
     void release() { for (Node *n : pool) delete n; pool.clear(); }
@@ -769,12 +775,13 @@ Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache,
 }
 
 // partialResultFromGoal, hmm_graph_search.h:83-110
-std::string path_string(Node *goal, Cache &cache) {
+std::string path_string(Searcher &S, int dir, Node *goal) {
     std::string s;
     for (Node *p = goal; p && p->from; p = p->from) {
         if (p->state != 'd')
             for (int i = 0; i < 3; ++i) s.push_back("acgt-"[(p->nucl_emission >> (3 * i)) & 7]);
-        cache.emplace(key_of(*p->from), key_of(*p));                        // insert keeps the first (hash_table_st.h:309-331)
+        // term_nodes.insert keeps the first value of a key (hash_table_st.h:309-331); applied when the window allows
+        S.pending.push_back(Searcher::Pending{S.seed_counter, dir, key_of(*p->from), key_of(*p)});
     }
     std::reverse(s.begin(), s.end());
     return s;
@@ -979,22 +986,33 @@ orc_searcher *orc_searcher_new(const orc_graph *g, const orc_hmm *fwd, const orc
     return s;
 }
 void orc_searcher_free(orc_searcher *s) { s->release(); delete s; }
-void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); }
+void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); s->pending.clear(); s->seed_counter = 0; }
+void orc_searcher_set_window(orc_searcher *s, int window) { s->window = window < 1 ? 1 : window; }
 
 int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, orc_astar_result *right, orc_astar_result *left,
                         char *contig, int64_t cap) {
     std::string kmer(kmer_c);
     for (auto &c : kmer) c = (char)tolower(c);                              // search.cpp:156
     if ((int)kmer.size() < s->g->k + 1) return -1;
+    {   // make the paths of seeds <= j - window visible, in seed order (first insert wins)
+        size_t keep = 0;
+        for (size_t i = 0; i < s->pending.size(); ++i) {
+            const auto &p = s->pending[i];
+            if (p.seed <= s->seed_counter - s->window) s->cache[p.dir].emplace(p.parent, p.child);
+            else s->pending[keep++] = p;
+        }
+        s->pending.resize(keep);
+    }
     AstarOut o1, o2;
     Node *g1 = astar_from_kmer(*s, 0, start_state, kmer, o1);               // hmm_graph_search.h:67
-    std::string rs = g1 ? path_string(g1, s->cache[0]) : std::string();
+    std::string rs = g1 ? path_string(*s, 0, g1) : std::string();
     fill_result(right, o1, g1);
     int lstate = s->hm[1]->M - start_state - int(kmer.size() / 3);          // :73
     Node *g2 = astar_from_kmer(*s, 1, lstate, kmer, o2);
-    std::string ls = g2 ? path_string(g2, s->cache[1]) : std::string();
+    std::string ls = g2 ? path_string(*s, 1, g2) : std::string();
     fill_result(left, o2, g2);
     s->release();
+    s->seed_counter++;
     std::string out = revcomp(ls) + kmer + rs;                              // :77-79
     if ((int64_t)out.size() + 1 > cap) return -2;
     memcpy(contig, out.c_str(), out.size() + 1);

@@ -94,6 +94,8 @@ orc_searcher *orc_searcher_new(const orc_graph *, const orc_hmm *fwd, const orc_
                                double low_cov_penalty);
 void orc_searcher_free(orc_searcher *);
 void orc_searcher_clear_cache(orc_searcher *);                    /* drop the term_nodes caches (cold mode) */
+/* windowed sharing: seed j sees the paths found by seeds <= j - window; 1 = the reference's sequential run */
+void orc_searcher_set_window(orc_searcher *, int window);
 /* one seed = HMMGraphSearch::search [hmm_graph_search.h:60-81]; kmer is lower/upper-case ACGT of
  * length k+1; contig receives "<left><kmer><right>" (lower case).  Returns contig length or <0. */
 int64_t orc_search_seed(orc_searcher *, const char *kmer, int start_state, orc_astar_result *right,

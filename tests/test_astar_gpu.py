@@ -96,3 +96,49 @@ def test_bad_seed_is_loud(toy):
     g, fw, rv, d = toy
     with pytest.raises(api.MegaGtaError):
         api.astar_search(g, fw, rv, ["A" * 45], [95], 20, 0.5)      # model position + 15 codons > M = 100
+
+
+def test_warm_sequential_equals_reference_search_1thread(toy):
+    """cache_mode 1: shared term_nodes caches with ordered commits == `megagta search ... 1` (per seed AND the FASTA file)"""
+    from megagta_amd import api
+    g, fw, rv, d = toy
+    gold = H.parse_probe_astar(H.gz_lines(os.path.join(d, "astar_warm.txt.gz")))
+    res, st = api.astar_search(g, fw, rv, [r["kmer"] for r in gold], [r["start_state"] for r in gold], 20, 0.5, cache_mode=1)
+    for r, ref in zip(res, gold):
+        _check_side(r.right_side, ref["R"])
+        _check_side(r.left_side, ref["L"])
+        assert r.contig(ref["kmer"]) == ref["contig"]
+    fasta = H.gz_lines(os.path.join(d, "44_raw_contigs_rplB.fasta.gz"))
+    assert fasta[1::2] == [r.contig(ref["kmer"]) for r, ref in zip(res, gold)]
+    cold = H.parse_probe_astar(H.gz_lines(os.path.join(d, "astar_cold.txt.gz")))
+    assert st["n_expansions"] < sum(c["R"]["closed"] + c["L"]["closed"] for c in cold) / 3      # the cache really short-cuts
+
+
+@pytest.mark.parametrize("window", [1, 4, 64])
+def test_windowed_warm_vs_oracle(ctx, oracle, window):
+    """cache_mode B: seed j sees the paths of seeds <= j-B; deterministic whatever the GPU scheduling; == oracle with the same window"""
+    from megagta_amd import api
+    import tempfile
+    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_gene_models(mg.genes, td)
+        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
+        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
+        g = api.Graph(ctx, stream)
+        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+        runs = [api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=window) for _ in range(2)]
+        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), 20, 0.5)
+        S.clear_cache()
+        S.set_window(window)
+        for i, (kmer, pos) in enumerate(seeds):
+            contig, R, L = S.search(kmer, pos - 1, cold=False)
+            for res, _ in runs:
+                r = res[i]
+                assert r.contig(kmer) == contig, (window, i)
+                for got, ref in ((r.right_side, R), (r.left_side, L)):
+                    assert got["ok"] == ref.ok and got["n_closed"] == ref.n_closed and got["n_expanded"] == ref.n_expanded
+                    if ref.ok:
+                        assert got["real_score"] == ref.real_score and got["fval"] == ref.fval
