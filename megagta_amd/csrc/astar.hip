@@ -31,6 +31,7 @@ struct mgta_hmm {
     int M = 0, A = 0;
     mgta::DevBuf tab;            // [msc (M+1)*A][tsc 7*(M+1)][maxm (M+1)][h 3*(M+1)]
     int8_t col[2][64];           // codon (c1*16+c2*4+c3) -> emission column; [0] codonTable, [1] rc_codonTable; -1 = stop
+    mgta::DevBuf d_col;          // the same 128 bytes on the device
     size_t n_doubles = 0;
 };
 
@@ -54,9 +55,10 @@ struct ANode {                    // AStarNode, a_star_node.h:9-33
 };
 static_assert(sizeof(ANode) == 48, "node layout");
 
-struct HeapEnt {
-    uint64_t prio;                // order of AStarNode::operator< folded into one integer
-    uint32_t node, pad;
+struct HeapEnt {                  // 16 bytes; the priority (fval, -state_no, state rank) is rebuilt from key + fval
+    uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1)
+    int32_t fval;
+    uint32_t node;                // index in the search's node pool
 };
 struct HashEnt {
     uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1)
@@ -74,8 +76,8 @@ struct CacheEnt {
 struct HmmView {
     const double *tab;
     int M, A;
-    int8_t col_fwd[64];           // codonTable -> column
-    int8_t col_enum[64];          // table used by the enumerator of this direction (codonTable / rc_codonTable)
+    const int8_t *col_fwd;        // [64] codonTable -> column
+    const int8_t *col_enum;       // [64] table used by the enumerator of this direction (codonTable / rc_codonTable)
 };
 
 struct AstarArgs {
@@ -105,6 +107,7 @@ struct AstarArgs {
     int window;
     CacheEnt *cache[2];
     uint64_t cache_mask[2];
+    unsigned long long *prof;     // [8] diagnostic cycle sums (MGTA_ASTAR_PROFILE builds only)
     unsigned long long *frontier; // [2] number of leading seeds whose search of that direction has committed
     uint32_t *committed;          // [2][n] flags
 };
@@ -125,74 +128,96 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
-struct Search {                   // lane-0 state of one search
-    ANode *nodes; HeapEnt *heap; HashEnt *hash;
-    uint32_t cap_nodes, hmask, tag;
-    uint32_t n_nodes, n_heap, n_keys;
-    bool overflow;
-};
+// ---- open list: binary heap whose first kLdsHeap entries (levels 0..8) live in LDS, the rest in the search's arena.
+// The sift sequences are libstdc++'s (bits/stl_heap.h __push_heap / __adjust_heap) so nodes of equal priority leave
+// the list in the reference's order; they are executed by the whole wave: a pop prefetches five levels of the subtree
+// under the hole with 62 lanes (one memory round trip per five levels), a push loads every ancestor at once.
+constexpr uint32_t kLdsHeap = 511;
 
-// std::push_heap as libstdc++ does it (bits/stl_heap.h __push_heap)
-__device__ __forceinline__ void heap_sift_up(HeapEnt *h, int64_t hole, HeapEnt v) {
-    int64_t parent = (hole - 1) / 2;
-    while (hole > 0 && h[parent].prio < v.prio) {
-        h[hole] = h[parent];
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    h[hole] = v;
+__device__ __forceinline__ uint64_t ent_prio(const HeapEnt &e) {   // AStarNode::operator< (a_star_node.h:34-82) as one integer
+    int st = (int)(e.key & 3) - 1;
+    return ((uint64_t)((uint32_t)e.fval ^ 0x80000000u) << 32) | ((uint64_t)(uint16_t)(0xFFFF - (uint16_t)((e.key >> 2) & 0xFFFF)) << 2) |
+           (uint64_t)srank(st);
 }
-__device__ __forceinline__ void heap_push(Search &S, HeapEnt v) { heap_sift_up(S.heap, S.n_heap, v); S.n_heap++; }
+__device__ __forceinline__ HeapEnt hget(const HeapEnt *lds, const HeapEnt *glob, uint64_t i) { return i < kLdsHeap ? lds[i] : glob[i]; }
+__device__ __forceinline__ void hset(HeapEnt *lds, HeapEnt *glob, uint64_t i, const HeapEnt &e) {
+    if (i < kLdsHeap) lds[i] = e; else glob[i] = e;
+}
+__device__ __forceinline__ HeapEnt shfl_ent(const HeapEnt &e, int src) {
+    HeapEnt r;
+    r.key = __shfl(e.key, src, 64);
+    r.fval = __shfl(e.fval, src, 64);
+    r.node = __shfl(e.node, src, 64);
+    return r;
+}
 
-// std::pop_heap + pop_back (bits/stl_heap.h __pop_heap / __adjust_heap); returns the former top
-__device__ __forceinline__ HeapEnt heap_pop(Search &S) {
-    HeapEnt *h = S.heap;
-    HeapEnt top = h[0];
-    int64_t n = S.n_heap;
-    if (n > 1) {
-        HeapEnt v = h[n - 1];
-        int64_t len = n - 1, hole = 0, second = 0;
-        while (second < (len - 1) / 2) {
-            second = 2 * (second + 1);
-            if (h[second].prio < h[second - 1].prio) second--;
-            h[hole] = h[second];
-            hole = second;
-        }
-        if ((len & 1) == 0 && second == (len - 2) / 2) {
-            second = 2 * (second + 1);
-            h[hole] = h[second - 1];
-            hole = second - 1;
-        }
-        heap_sift_up(h, hole, v);
+// __push_heap(first, hole, 0, v): every lane calls it with the same arguments
+__device__ __forceinline__ void heap_sift_up(HeapEnt *lds, HeapEnt *glob, uint64_t hole, const HeapEnt &v) {
+    const int lane = lane_id();
+    const int depth = 63 - __builtin_clzll(hole + 1);                 // number of ancestors of `hole`
+    const uint64_t pv = ent_prio(v);
+    HeapEnt e = v;
+    bool less = false;
+    if (lane < depth) {
+        e = hget(lds, glob, ((hole + 1) >> (lane + 1)) - 1);
+        less = ent_prio(e) < pv;
     }
-    S.n_heap--;
+    uint64_t bal = __ballot(less);
+    int s = __builtin_ctzll(~bal);                                     // ancestors that move down one level
+    if (s > depth) s = depth;
+    if (lane < s) hset(lds, glob, ((hole + 1) >> lane) - 1, e);
+    if (lane == 0) hset(lds, glob, ((hole + 1) >> s) - 1, v);
+}
+
+// pop_heap + pop_back; n = current size (> 0); returns the former top
+__device__ __forceinline__ HeapEnt heap_pop(HeapEnt *lds, HeapEnt *glob, uint32_t n) {
+    const int lane = lane_id();
+    HeapEnt top = hget(lds, glob, 0);
+    if (n > 1) {
+        const HeapEnt v = hget(lds, glob, n - 1);
+        const int64_t len = (int64_t)n - 1;
+        int64_t hole = 0;
+        // __adjust_heap: while (hole < (len-1)/2) move the larger child up
+        while (hole < (len - 1) / 2) {
+            const int64_t base = hole;
+            int d = 31 - __builtin_clz((unsigned)lane + 2);            // depth 1..5 below `base` for lanes 0..61
+            int64_t idx = ((base + 1) << d) - 1 + (((int64_t)lane + 2) - (1ll << d));
+            HeapEnt e;
+            e.key = 0; e.fval = 0; e.node = 0;
+            if (lane < 62 && idx < len) e = hget(lds, glob, (uint64_t)idx);
+            uint64_t pr = ent_prio(e);
+            int o = 0;
+#pragma unroll
+            for (int t = 1; t <= 5; ++t) {
+                if (!(hole < (len - 1) / 2)) break;
+                int ll = (1 << t) - 2 + 2 * o;                         // lane holding the left child; right child = ll + 1
+                uint64_t pl = __shfl(pr, ll, 64), prr = __shfl(pr, ll + 1, 64);
+                int pick = (prr < pl) ? 0 : 1;                         // second = right; if (right < left) --second
+                HeapEnt ce = shfl_ent(e, ll + pick);
+                if (lane == 0) hset(lds, glob, (uint64_t)hole, ce);
+                hole = 2 * hole + 1 + pick;
+                o = 2 * o + pick;
+            }
+        }
+        if ((len & 1) == 0 && hole == (len - 2) / 2) {                 // a last, single (left) child
+            HeapEnt ce = hget(lds, glob, (uint64_t)(2 * hole + 1));
+            if (lane == 0) hset(lds, glob, (uint64_t)hole, ce);
+            hole = 2 * hole + 1;
+        }
+        heap_sift_up(lds, glob, (uint64_t)hole, v);
+    }
     return top;
 }
 
-// returns the slot of `key` (found) or of the first free slot (not found)
-__device__ __forceinline__ uint32_t hash_find(const Search &S, uint64_t key, bool &found) {
-    uint32_t i = (uint32_t)mix64(key) & S.hmask;
+// ---- closed set + open_hash: one open-addressing table per search; every lane probes the same key (one request)
+__device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask, uint32_t tag, uint64_t key, bool &found, uint32_t &val) {
+    uint32_t i = (uint32_t)mix64(key) & hmask;
     while (true) {
-        HashEnt e = S.hash[i];
-        if (e.tag != S.tag) { found = false; return i; }
-        if (e.key == key) { found = true; return i; }
-        i = (i + 1) & S.hmask;
+        HashEnt e = tab[i];
+        if (e.tag != tag) { found = false; val = kNone; return i; }
+        if (e.key == key) { found = true; val = e.val; return i; }
+        i = (i + 1) & hmask;
     }
-}
-__device__ __forceinline__ uint32_t hash_get_or_add(Search &S, uint64_t key) {
-    bool found;
-    uint32_t i = hash_find(S, key, found);
-    if (!found) {
-        HashEnt e; e.key = key; e.val = kNone; e.tag = S.tag;
-        S.hash[i] = e;
-        S.n_keys++;
-        if (S.n_keys * 2 > S.hmask) S.overflow = true;
-    }
-    return i;
-}
-
-__device__ __forceinline__ bool node_less(const ANode &a, int fval, int state_no, int st) {
-    return make_prio(a.fval, a.state_no, a.em_state >> 9) < make_prio(fval, state_no, st);
 }
 
 // agent-scope accesses: the caches / frontier are written by other CUs (and XCDs) of the same launch
@@ -201,8 +226,9 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 }
 // child descriptor cached for `key` and visible to seed `seed` under window B, or -1
 __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
-    const CacheEnt *tab = a.cache[dir];
-    uint64_t i = mix64(key) & a.cache_mask[dir];
+    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    uint64_t i = mix64(key) & cmask;
     while (true) {
         unsigned long long k = ld_agent(&tab[i].key);
         if (k == 0) return -1;
@@ -213,12 +239,13 @@ __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_
             int64_t owner = (int64_t)(v >> 16);
             return owner <= seed - a.window ? (int)(v & 0xFFFF) : -1;
         }
-        i = (i + 1) & a.cache_mask[dir];
+        i = (i + 1) & cmask;
     }
 }
 __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t seed, int em_state) {
-    CacheEnt *tab = a.cache[dir];
-    uint64_t i = mix64(key) & a.cache_mask[dir];
+    CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    uint64_t i = mix64(key) & cmask;
     unsigned long long v = ((unsigned long long)seed << 16) | (unsigned long long)(em_state & 0xFFFF);
     while (true) {
         unsigned long long k = ld_agent(&tab[i].key);
@@ -234,16 +261,28 @@ __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64
             __hip_atomic_fetch_max(&tab[i].val, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        i = (i + 1) & a.cache_mask[dir];
+        i = (i + 1) & cmask;
     }
 }
+
+#ifdef MGTA_ASTAR_PROFILE   // diagnostic build only: per-phase cycle sums (s_memtime), lane 0 of every wave
+#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; }
+#define PROF_FLUSH if (lane == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&a.prof[q_], pacc_[q_]);
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH
+#endif
 
 template <bool LDS>
 __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     extern __shared__ __align__(16) double s_tab[];
-    __shared__ int64_t s_codon[kAstarWaves][64];
+    __shared__ HeapEnt s_heap[kAstarWaves][kLdsHeap + 1];
     const int dir = blockIdx.x & 1;
-    const HmmView &hv = a.hm[dir];
+    HmmView hv;                                                     // select by value: no indexed access into the kernel arguments
+    hv.tab = dir ? a.hm[1].tab : a.hm[0].tab; hv.M = dir ? a.hm[1].M : a.hm[0].M; hv.A = dir ? a.hm[1].A : a.hm[0].A;
+    hv.col_fwd = dir ? a.hm[1].col_fwd : a.hm[0].col_fwd; hv.col_enum = dir ? a.hm[1].col_enum : a.hm[0].col_enum;
     const int M = hv.M, A = hv.A;
     const double *tab = hv.tab;
     if (LDS) {
@@ -252,26 +291,30 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         __syncthreads();
         tab = s_tab;
     }
-    const double *msc = tab, *tsc = tab + (size_t)(M + 1) * A, *maxm = tsc + (size_t)7 * (M + 1), *hc = maxm + (M + 1);
+    const size_t M1 = (size_t)M + 1;
+    const double *msc = tab, *tsc = tab + M1 * A, *maxm = tsc + 7 * M1, *hc = maxm + M1;
     const int lane = lane_id(), wv = wave_id();
     const uint32_t slot = blockIdx.x * kAstarWaves + wv;
     const GraphDev &g = a.g;
     const bool forward = dir == 0;
+    const double NEG_INF = -__builtin_inf();
 
-    Search S;
-    S.nodes = a.nodes + (size_t)slot * a.cap_nodes;
-    S.heap = a.heap + (size_t)slot * a.cap_nodes;
-    S.hash = a.hash + (size_t)slot * a.cap_hash;
-    S.cap_nodes = a.cap_nodes; S.hmask = a.cap_hash - 1;
+    // per-search arena (every lane holds the same scalars; stores are done by lane 0)
+    ANode *const nodes = a.nodes + (size_t)slot * a.cap_nodes;
+    HeapEnt *const gheap = a.heap + (size_t)slot * a.cap_nodes;
+    HashEnt *const hash = a.hash + (size_t)slot * a.cap_hash;
+    HeapEnt *const lheap = s_heap[wv];
+    const uint32_t hmask = a.cap_hash - 1;
     uint32_t tag = a.slot_tag[slot];
+    PROF_DECL
 
     while (true) {
         // ---- next search of this direction
         long long qi = 0;
         if (lane == 0) qi = (long long)atomicAdd(&a.queue[dir], 1ull);
         qi = __shfl(qi, 0, 64);
-        if (qi >= a.n_todo[dir]) break;
-        const int64_t seed = a.todo[dir][qi];
+        if (qi >= (dir ? a.n_todo[1] : a.n_todo[0])) break;
+        const int64_t seed = (dir ? a.todo[1] : a.todo[0])[qi];
         const int64_t sid = seed * 2 + dir;
         if (a.window > 0) {
             // seeds are taken in order; wait until every seed <= seed - window has committed its path.
@@ -292,25 +335,23 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
         }
         ++tag;
-        S.tag = tag; S.n_nodes = 0; S.n_heap = 0; S.n_keys = 0; S.overflow = false;
-
+        uint32_t n_nodes = 0, n_heap = 0, n_keys = 0;
         int64_t n_closed = 0, n_expanded = 0, n_opened = 0;
         int status = 1, partial = 0, ok = 0;
-        int32_t goal = -1;             // pool index of the node whose path is reported
-        int32_t inter = 0;             // inter_goal_ptr
-        int32_t cur = 0;               // node being expanded (lane 0)
+        int32_t goal = -1, inter = 0, cur = 0;
         bool first = true, done = false;
+        ANode curr;                                                     // node being expanded
 
-        // ---- start node (hmm_graph_search.h:132-189), lane 0
-        if (lane == 0) {
+        // ---- start node (hmm_graph_search.h:132-189)
+        {
             const char *km = a.kmers + seed * a.klen;
             int n_aa = a.klen / 3;
             int sstate = forward ? a.start_state[seed] : (M - a.start_state[seed] - n_aa);   // :73
             bool bad = sstate < 0 || sstate + n_aa > M || a.klen > kMaxKmer;
             double sc = 0, rs = 0;
             if (!bad) {
-                for (int i = 1; i <= n_aa; ++i) {                     // scoreStart / realScoreStart, :112-130
-                    int ci = forward ? (i - 1) : (n_aa - i);          // reverse search scores the reversed protein
+                for (int i = 1; i <= n_aa; ++i) {                      // scoreStart / realScoreStart, :112-130
+                    int ci = forward ? (i - 1) : (n_aa - i);           // the reverse search scores the reversed protein
                     int c = 0;
                     for (int t = 0; t < 3; ++t) {
                         char ch = km[3 * ci + t];
@@ -321,259 +362,290 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     }
                     int col = hv.col_fwd[c];
                     if (col < 0) { bad = true; break; }
-                    double m = msc[(size_t)(sstate + i) * A + col], t = tsc[(size_t)T_MM * (M + 1) + sstate + i - 1];
+                    double m = msc[(size_t)(sstate + i) * A + col], t = tsc[(size_t)T_MM * M1 + sstate + i - 1];
                     sc += m + t - maxm[sstate + i];
                     rs += m + t;
                 }
             }
             if (bad) { status = 3; done = true; }
             else {
-                ANode st;
-                st.parent = -1; st.state_no = (int16_t)(sstate + n_aa); st.em_state = (uint16_t)(ST_M << 9); st.length = (int16_t)n_aa;
-                st.fval = 0; st.score = sc; st.real_score = rs; st.max_score = 0; st.negative_count = 0;
-                st.node_id = a.start_node[sid];
-                S.nodes[0] = st; S.n_nodes = 1;
-                if (st.state_no >= M) { ok = 1; goal = 0; done = true; }          // :193-197
-                else if (st.node_id == -1) { ok = 0; done = true; n_opened = 1; }  // no children -> open.empty() -> false (:235-237)
-                cur = 0; inter = 0;
+                curr.parent = -1; curr.state_no = (int16_t)(sstate + n_aa); curr.em_state = (uint16_t)(ST_M << 9); curr.length = (int16_t)n_aa;
+                curr.fval = 0; curr.score = sc; curr.real_score = rs; curr.max_score = 0; curr.negative_count = 0;
+                curr.node_id = a.start_node[sid];
+                if (lane == 0) nodes[0] = curr;
+                n_nodes = 1;
+                if (curr.state_no >= M) { ok = 1; goal = 0; done = true; }            // :193-197
+                else if (curr.node_id == -1) { ok = 0; done = true; n_opened = 1; }    // no children -> open.empty() -> false (:235-237)
             }
         }
 
         // ---- main loop: one expansion per iteration
-        while (true) {
-            int64_t cur_id = 0;
-            if (lane == 0 && !done && !first) {
+        PROF(0)
+        while (!done) {
+            if (!first) {
                 // pop until a node that is not closed (hmm_graph_search.h:243-257)
                 bool have = false;
-                while (S.n_heap > 0) {
-                    HeapEnt top = heap_pop(S);
-                    ANode &c = S.nodes[top.node];
+                uint32_t hs = 0, hval = kNone;
+                uint64_t hkey = 0;
+                while (n_heap > 0) {
+                    HeapEnt top = heap_pop(lheap, gheap, n_heap);
+                    --n_heap;
                     bool found;
-                    uint32_t hs = hash_find(S, make_key(c.node_id, c.state_no, c.em_state >> 9), found);
-                    if (found && (S.hash[hs].val >> 31)) continue;                 // closed
+                    hs = hash_find(hash, hmask, tag, top.key, found, hval);
+                    if (found && (hval >> 31)) continue;                               // closed
                     cur = (int32_t)top.node;
+                    hkey = top.key;
+                    if (!found) ++n_keys;                                              // (children of the first expansion are not in open_hash)
                     have = true;
                     break;
                 }
-                if (!have) {                                                        // open list ran dry (:339-341)
-                    partial = 1; ok = 1; goal = inter; done = true;
-                } else {
-                    const ANode &c = S.nodes[cur];
-                    const ANode &ig = S.nodes[inter];
-                    bool better = (c.real_score + a.exit_prob[c.length]) / a.log2v > (ig.real_score + a.exit_prob[ig.length]) / a.log2v;
-                    if (c.state_no >= M) {                                          // goal (:259-270)
-                        if (better) inter = cur;
-                        ok = 1; goal = inter; done = true;
-                    } else {
-                        uint32_t hs = hash_get_or_add(S, make_key(c.node_id, c.state_no, c.em_state >> 9));
-                        S.hash[hs].val |= 0x80000000u;                              // closed.insert (:272)
-                        n_closed++;
-                        if (better) inter = cur;                                    // :274-277
-                        if (S.overflow) { status = 2; done = true; }
-                    }
+                PROF(1)
+                if (!have) { partial = 1; ok = 1; goal = inter; break; }              // open list ran dry (:339-341)
+                curr = nodes[cur];
+                const ANode ig = nodes[inter];
+                bool better = (curr.real_score + a.exit_prob[curr.length]) / a.log2v > (ig.real_score + a.exit_prob[ig.length]) / a.log2v;
+                if (curr.state_no >= M) {                                              // goal (:259-270)
+                    if (better) inter = cur;
+                    ok = 1; goal = inter;
+                    break;
                 }
+                if (lane == 0) { HashEnt e; e.key = hkey; e.val = hval | 0x80000000u; e.tag = tag; hash[hs] = e; }   // closed.insert (:272)
+                n_closed++;
+                if (better) inter = cur;                                               // :274-277
+                if (n_keys * 2 > hmask) { status = 2; break; }
             }
-            int dflag = __shfl((int)done, 0, 64);
-            if (dflag) break;
-            if (lane == 0) cur_id = S.nodes[cur].node_id;
-            cur_id = __shfl(cur_id, 0, 64);
+            PROF(2)
+            const int cst = curr.em_state >> 9;
+            const int next_state = curr.state_no + 1;
+            // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
+            int cached = -1;
+            if (a.window > 0) {
+                if (lane == 0) cached = cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), seed);
+                cached = __shfl(cached, 0, 64);
+            }
+            const int cached_st = cached >= 0 ? (cached >> 9) : -1;
 
+            PROF(3)
             // ---- wave-parallel enumeration of the <= 64 codon paths (node_enumerator.h:98-128)
-            int64_t o1[4], o2[4], o3[4];
-            int od1 = g_outgoing(g, cur_id, o1);
+            int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            LineR Ls = g_load_line(g, (uint64_t)curr.node_id >> 6), Lt;
+            uint64_t lt_idx = 0;
+            int od1 = g_outgoing_line(g, Ls, curr.node_id, p0, p1, p2, p3, Lt, lt_idx);
             const int i = lane >> 4, j = (lane >> 2) & 3, kk = lane & 3;
             bool valid = i < od1;
             int64_t packed = 0;
             if (valid) {
-                int64_t e1 = o1[0];
-#pragma unroll
-                for (int t = 1; t < 4; ++t) if (t == i) e1 = o1[t];
-                int od2 = g_outgoing(g, e1 >> 4, o2);
+                int64_t e1 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, i);
+                if ((uint64_t)(e1 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e1 >> 10));   // (e1 >> 4) >> 6: rare, a node's edges straddle two lines
+                Ls = Lt;
+                int od2 = g_outgoing_line(g, Ls, e1 >> 4, p0, p1, p2, p3, Lt, lt_idx);
                 valid = j < od2;
                 if (valid) {
-                    int64_t e2 = o2[0];
-#pragma unroll
-                    for (int t = 1; t < 4; ++t) if (t == j) e2 = o2[t];
-                    int od3 = g_outgoing(g, e2 >> 4, o3);
+                    int64_t e2 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, j);
+                    if ((uint64_t)(e2 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e2 >> 10));
+                    Ls = Lt;
+                    int od3 = g_outgoing_line(g, Ls, e2 >> 4, p0, p1, p2, p3, Lt, lt_idx);
                     valid = kk < od3;
                     if (valid) {
-                        int64_t e3 = o3[0];
-#pragma unroll
-                        for (int t = 1; t < 4; ++t) if (t == kk) e3 = o3[t];
+                        int64_t e3 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, kk);
                         int c1 = (int)(e1 & 7) - 1, c2 = (int)(e2 & 7) - 1, c3 = (int)(e3 & 7) - 1;
                         int low = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1) & (int)((e3 >> 3) & 1);
                         packed = ((e3 >> 4) << 16) | ((int64_t)low << 9) | (c1 << 6) | (c2 << 3) | c3;
                     }
                 }
             }
-            uint64_t vmask = __ballot(valid);
-            if (valid) s_codon[wv][lane] = packed;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            n_expanded++;
+            PROF(4)
 
-            // ---- children in reference order, lane 0 (node_enumerator.h:131-244, hmm_graph_search.h:288-336)
-            if (lane == 0) {
-                n_expanded++;
-                const ANode curr = S.nodes[cur];
-                const int cst = curr.em_state >> 9;
-                const int next_state = curr.state_no + 1;
-                double mt, it, dt;
-                const double NEG_INF = -__builtin_inf();
-                const size_t M1 = (size_t)(M + 1);
-                if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
-                else if (cst == ST_D) { mt = tsc[T_DM * M1 + curr.state_no]; it = NEG_INF; dt = tsc[T_DD * M1 + curr.state_no]; }
-                else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
-                const double max_match = maxm[next_state];
-                const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
-                // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
-                const int cached = a.window > 0 ? cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), seed) : -1;
-                const int cached_st = cached >= 0 ? (cached >> 9) : -1;
-                bool stop = false;                                                  // `return` inside enumerateNodes
+            // ---- children (node_enumerator.h:131-244): every lane scores ITS codon's match / insert child
+            double mt, it, dt;
+            if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
+            else if (cst == ST_D) { mt = tsc[T_DM * M1 + curr.state_no]; it = NEG_INF; dt = tsc[T_DD * M1 + curr.state_no]; }
+            else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
+            const double max_match = maxm[next_state];
+            const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
 
-                auto admit = [&](ANode &nx) {
-                    const int nst = nx.em_state >> 9;
-                    bool open_node = false;
-                    uint32_t hs = 0;
-                    if (first) open_node = true;                                    // :212-233: no pruning / dedup
-                    else {
-                        bool adm = a.prune > 0 ? ((nx.length < 5 || nx.negative_count <= a.prune) && nx.real_score > 0.0) : true;   // :292-293
-                        if (adm) {
-                            bool found;
-                            hs = hash_find(S, make_key(nx.node_id, nx.state_no, nst), found);
-                            uint32_t oi = found ? (S.hash[hs].val & kNone) : kNone;
-                            if (oi != kNone) open_node = node_less(S.nodes[oi], nx.fval, nx.state_no, nst);          // :299-302
-                            else open_node = true;
-                        }
-                    }
-                    if (!open_node) return;
-                    if (S.n_nodes >= S.cap_nodes) { S.overflow = true; return; }
-                    uint32_t idx = S.n_nodes++;
-                    S.nodes[idx] = nx;
-                    if (!first) {
-                        hs = hash_get_or_add(S, make_key(nx.node_id, nx.state_no, nst));
-                        S.hash[hs].val = (S.hash[hs].val & 0x80000000u) | idx;      // open_hash[next] = next (:331)
-                        n_opened++;
-                    }
-                    HeapEnt he; he.prio = make_prio(nx.fval, nx.state_no, nst); he.node = idx; he.pad = 0;
-                    heap_push(S, he);
-                };
+            int col = -1;
+            if (valid) col = hv.col_enum[(int)((packed >> 6) & 7) * 16 + (int)((packed >> 3) & 7) * 4 + (int)(packed & 7)];
+            bool use = valid && col >= 0;                                              // stop codon (:142-144)
+            if (use && cached >= 0)                                                    // child_node->node_id != packed >> 16 (:146-148)
+                use = cached_st == ST_D ? ((packed >> 16) == curr.node_id) : ((int)(packed & 511) == (cached & 511));
+            const bool any_pass = __ballot(use) != 0;
+            // a cached match/insert child ends the enumeration at that child (:178-181,207-210)
+            const bool want_ins = use && cst != ST_D && cached_st != ST_M;
+            const bool want_del = cst != ST_I && !((cached_st == ST_M || cached_st == ST_I) && any_pass);
 
-                uint64_t vm = vmask;
-                while (vm && !S.overflow && !stop) {
-                    int l = __builtin_ctzll(vm);
-                    vm &= vm - 1;
-                    int64_t p = s_codon[wv][l];
-                    int col = hv.col_enum[(int)((p >> 6) & 7) * 16 + (int)((p >> 3) & 7) * 4 + (int)(p & 7)];
-                    if (col < 0) continue;                                          // stop codon (:142-144)
-                    if (cached >= 0) {                                              // child_node->node_id != packed >> 16 (:146-148)
-                        // a 3-edge path is fixed by its end edge, so "same node id" == "same codon" for m/i children;
-                        // a cached delete child carries the parent's own node id
-                        if (cached_st == ST_D ? ((p >> 16) != curr.node_id) : ((int)(p & 511) != (cached & 511))) continue;
-                    }
-                    double pen = (p & (1 << 9)) ? a.low_cov_penalty : 0.0;          // :150
-                    ANode nx;
-                    nx.parent = cur; nx.node_id = p >> 16;
-                    nx.state_no = (int16_t)next_state; nx.length = (int16_t)(curr.length + 1);
-                    double e = mt + msc[(size_t)next_state * A + col];
-                    nx.real_score = curr.real_score + e - pen;
-                    if (nx.real_score >= curr.max_score) { nx.max_score = nx.real_score; nx.negative_count = 0; }
-                    else { nx.max_score = curr.max_score; nx.negative_count = (int16_t)(curr.negative_count + 1); }
-                    double self = e - pen - max_match;
-                    nx.score = curr.score + self;
-                    nx.fval = to_fval(10000 * (nx.score + 2.0 * h_m));              // :173
-                    nx.em_state = (uint16_t)((p & 511) | (ST_M << 9));
-                    admit(nx);
-                    if (cached_st == ST_M) { stop = true; break; }                  // *child_node == next -> return (:178-181)
-                    if (cst != ST_D) {                                              // insert child (:189-214); isc == 0 except at M
-                        double isc = next_state == M ? NEG_INF : 0.0;
-                        double ei = it + isc;
-                        ANode ni;
-                        ni.parent = cur; ni.node_id = p >> 16;
-                        ni.state_no = curr.state_no; ni.length = (int16_t)(curr.length + 1);
-                        ni.real_score = curr.real_score + ei - pen;
-                        ni.max_score = curr.max_score;
-                        ni.negative_count = (int16_t)(curr.negative_count + 1);
-                        ni.score = curr.score + (ei - pen);
-                        ni.fval = to_fval(10000 * (ni.score + 2.0 * h_i));
-                        ni.em_state = (uint16_t)((p & 511) | (ST_I << 9));
-                        admit(ni);
-                        if (cached_st == ST_I) { stop = true; break; }              // (:207-210)
-                    }
-                }
-                if (cst != ST_I && !S.overflow && !stop) {                          // delete child (:218-244)
-                    ANode nd;
-                    nd.parent = cur; nd.node_id = curr.node_id;
-                    nd.state_no = (int16_t)next_state; nd.length = curr.length;
-                    nd.real_score = curr.real_score + dt;
-                    nd.max_score = curr.max_score;
-                    nd.negative_count = (int16_t)(curr.negative_count + 1);
-                    nd.score = curr.score + (dt - max_match);
-                    nd.fval = to_fval(10000 * (nd.score + 2.0 * h_d));
-                    nd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
-                    admit(nd);
-                }
-                if (S.overflow) { status = 2; done = true; }
-                if (first) {
-                    first = false;
-                    n_opened = 1;
-                    if (S.n_heap == 0) { ok = 0; done = true; }                     // :235-237
-                }
+            ANode cm, ci;                                                              // this lane's match / insert child
+            cm.parent = cur; ci.parent = cur;
+            cm.node_id = packed >> 16; ci.node_id = packed >> 16;
+            cm.length = (int16_t)(curr.length + 1); ci.length = cm.length;
+            cm.state_no = (int16_t)next_state; ci.state_no = curr.state_no;
+            cm.em_state = (uint16_t)((packed & 511) | (ST_M << 9)); ci.em_state = (uint16_t)((packed & 511) | (ST_I << 9));
+            const double pen = (packed & (1 << 9)) ? a.low_cov_penalty : 0.0;          // :150
+            {
+                double e = mt + (use ? msc[(size_t)next_state * A + col] : 0.0);
+                cm.real_score = curr.real_score + e - pen;
+                if (cm.real_score >= curr.max_score) { cm.max_score = cm.real_score; cm.negative_count = 0; }
+                else { cm.max_score = curr.max_score; cm.negative_count = (int16_t)(curr.negative_count + 1); }
+                cm.score = curr.score + (e - pen - max_match);
+                cm.fval = to_fval(10000 * (cm.score + 2.0 * h_m));                     // :173
+                double ei = it + (next_state == M ? NEG_INF : 0.0);                    // isc == 0 except at node M
+                ci.real_score = curr.real_score + ei - pen;
+                ci.max_score = curr.max_score;
+                ci.negative_count = (int16_t)(curr.negative_count + 1);
+                ci.score = curr.score + (ei - pen);
+                ci.fval = to_fval(10000 * (ci.score + 2.0 * h_i));
             }
-            __builtin_amdgcn_wave_barrier();
+            ANode cd;                                                                  // delete child (:218-244), same in every lane
+            cd.parent = cur; cd.node_id = curr.node_id;
+            cd.state_no = (int16_t)next_state; cd.length = curr.length;
+            cd.real_score = curr.real_score + dt;
+            cd.max_score = curr.max_score;
+            cd.negative_count = (int16_t)(curr.negative_count + 1);
+            cd.score = curr.score + (dt - max_match);
+            cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
+            cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
+
+            // ---- admission (hmm_graph_search.h:288-311): prune test + open_hash lookup, all children in parallel
+            auto admissible = [&](const ANode &nx) {
+                return a.prune > 0 ? ((nx.length < 5 || nx.negative_count <= a.prune) && nx.real_score > 0.0) : true;
+            };
+            auto probe_open = [&](const ANode &nx, bool want) -> bool {               // per-lane probe of this lane's own key
+                if (!want) return false;
+                if (first) return true;                                                // :212-233: no pruning / dedup
+                if (!admissible(nx)) return false;
+                uint64_t key = make_key(nx.node_id, nx.state_no, nx.em_state >> 9);
+                uint32_t ii = (uint32_t)mix64(key) & hmask;
+                while (true) {
+                    HashEnt e = hash[ii];
+                    if (e.tag != tag) return true;
+                    if (e.key == key) {
+                        uint32_t oi = e.val & kNone;
+                        if (oi == kNone) return true;
+                        return nodes[oi].fval < nx.fval;                               // got->second < next (:299-302); equal keys => only fval differs
+                    }
+                    ii = (ii + 1) & hmask;
+                }
+            };
+            const bool open_m = probe_open(cm, use);
+            const bool open_i = probe_open(ci, want_ins);
+            const bool open_d = probe_open(cd, want_del && lane == 0);
+            const uint64_t mm = __ballot(open_m), mi = __ballot(open_i);
+            PROF(5)
+            const bool del = __shfl((int)open_d, 0, 64) != 0;
+            const uint32_t n_new = (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi) + (del ? 1u : 0u);
+            if (n_nodes + n_new > a.cap_nodes) { status = 2; break; }
+            // node indices in reference order: codon by codon (ascending lane), match before insert, delete last
+            const uint64_t lt = lanemask_lt();
+            const uint32_t idx_m = n_nodes + (uint32_t)__popcll(mm & lt) + (uint32_t)__popcll(mi & lt);
+            const uint32_t idx_i = idx_m + (open_m ? 1u : 0u);
+            if (open_m) nodes[idx_m] = cm;
+            if (open_i) nodes[idx_i] = ci;
+            const uint32_t idx_d = n_nodes + n_new - 1;
+            if (del && lane == 0) nodes[idx_d] = cd;
+            // commit in order: open_hash[next] = next (:331) and open.push (:335)
+            uint64_t todo_m = mm, todo_i = mi;
+            while (todo_m | todo_i) {
+                int lm = todo_m ? __builtin_ctzll(todo_m) : 64, li = todo_i ? __builtin_ctzll(todo_i) : 64;
+                bool is_m = lm <= li;                                                  // same lane: match first
+                int src = is_m ? lm : li;
+                if (is_m) todo_m &= todo_m - 1; else todo_i &= todo_i - 1;
+                HeapEnt he;
+                he.key = __shfl(make_key(is_m ? cm.node_id : ci.node_id, is_m ? cm.state_no : ci.state_no, is_m ? ST_M : ST_I), src, 64);
+                he.fval = __shfl(is_m ? cm.fval : ci.fval, src, 64);
+                he.node = __shfl(is_m ? idx_m : idx_i, src, 64);
+                if (!first) {
+                    bool found; uint32_t val;
+                    uint32_t hs = hash_find(hash, hmask, tag, he.key, found, val);
+                    if (lane == 0) { HashEnt e; e.key = he.key; e.val = (found ? (val & 0x80000000u) : 0u) | he.node; e.tag = tag; hash[hs] = e; }
+                    if (!found) ++n_keys;
+                    n_opened++;
+                }
+                heap_sift_up(lheap, gheap, n_heap, he);
+                ++n_heap;
+            }
+            if (del) {
+                HeapEnt he;
+                he.key = make_key(cd.node_id, cd.state_no, ST_D); he.fval = cd.fval; he.node = idx_d;
+                if (!first) {
+                    bool found; uint32_t val;
+                    uint32_t hs = hash_find(hash, hmask, tag, he.key, found, val);
+                    if (lane == 0) { HashEnt e; e.key = he.key; e.val = (found ? (val & 0x80000000u) : 0u) | he.node; e.tag = tag; hash[hs] = e; }
+                    if (!found) ++n_keys;
+                    n_opened++;
+                }
+                heap_sift_up(lheap, gheap, n_heap, he);
+                ++n_heap;
+            }
+            n_nodes += n_new;
+            PROF(6)
+            if (n_keys * 2 > hmask) { status = 2; break; }
+            if (first) {
+                first = false;
+                n_opened = 1;
+                if (n_heap == 0) { ok = 0; break; }                                    // :235-237
+            }
         }
 
-        // ---- result (lane 0): getHighestScoreNode + partialResultFromGoal
-        if (lane == 0) {
+        // ---- result: getHighestScoreNode + partialResultFromGoal (hmm_graph_search.h:83-110,345-356)
+        {
             mgta_astar_side r;
             r.ok = ok; r.partial = partial; r.n_closed = n_closed; r.n_expanded = n_expanded; r.n_opened = n_opened;
             r.fval = 0; r.length = 0; r.state_no = -1; r.state = '-'; r.node_id = -1; r.real_score = 0; r.score = 0;
             uint32_t len = 0;
             char *dst = a.out_seq + (size_t)sid * a.out_cap;
+            int32_t best = -1;
             if (status == 1 && ok && goal >= 0) {
-                int32_t best = goal;                                                // :345-356
-                for (int32_t p = S.nodes[goal].parent; p >= 0; p = S.nodes[p].parent)
-                    if (S.nodes[p].real_score > S.nodes[best].real_score) best = p;
-                const ANode &gn = S.nodes[best];
+                best = goal;
+                double best_rs = nodes[goal].real_score;
+                for (int32_t p = nodes[goal].parent; p >= 0;) {
+                    ANode nd = nodes[p];
+                    if (nd.real_score > best_rs) { best = p; best_rs = nd.real_score; }
+                    p = nd.parent;
+                }
+                const ANode gn = nodes[best];
                 r.fval = gn.fval; r.length = gn.length; r.state_no = gn.state_no;
                 r.state = "mid"[gn.em_state >> 9]; r.node_id = gn.node_id; r.real_score = gn.real_score; r.score = gn.score;
-                // characters from the goal back to the start, 3 per non-delete node, then the whole string reversed (:92-108)
-                for (int32_t p = best; p >= 0 && S.nodes[p].parent >= 0; p = S.nodes[p].parent) {
-                    const ANode &nd = S.nodes[p];
+                // 3 characters per non-delete node from the goal back to the start, then reversed (:92-108);
+                // term_nodes.insert(parent -> child) along the same walk (:97-103)
+                ANode nd = gn;
+                while (nd.parent >= 0) {
                     if ((nd.em_state >> 9) != ST_D) {
                         if (len + 3 > a.out_cap) { status = 2; break; }
-                        for (int t = 0; t < 3; ++t) dst[len++] = "acgt-"[(nd.em_state >> (3 * t)) & 7];
+                        if (lane == 0)
+                            for (int t = 0; t < 3; ++t) dst[len + t] = "acgt-"[(nd.em_state >> (3 * t)) & 7];
+                        len += 3;
                     }
+                    const ANode par = nodes[nd.parent];
+                    if (a.window > 0 && lane == 0)
+                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9), seed, nd.em_state);
+                    nd = par;
                 }
-                for (uint32_t x = 0; x < len / 2; ++x) { char t = dst[x]; dst[x] = dst[len - 1 - x]; dst[len - 1 - x] = t; }
+                if (lane == 0)
+                    for (uint32_t x = 0; x < len / 2; ++x) { char t = dst[x]; dst[x] = dst[len - 1 - x]; dst[len - 1 - x] = t; }
             }
-            a.sides[sid] = r;
-            a.out_len[sid] = len;
-            a.status[sid] = status;
-            if (a.window > 0) {
-                // partialResultFromGoal: term_nodes.insert(parent -> child) along the reported path (:97-103)
-                if (status == 1 && ok && goal >= 0) {
-                    int32_t best = goal;
-                    for (int32_t p = S.nodes[goal].parent; p >= 0; p = S.nodes[p].parent)
-                        if (S.nodes[p].real_score > S.nodes[best].real_score) best = p;
-                    for (int32_t p = best; p >= 0 && S.nodes[p].parent >= 0; p = S.nodes[p].parent) {
-                        const ANode &par = S.nodes[S.nodes[p].parent];
-                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9), seed, S.nodes[p].em_state);
+            if (lane == 0) {
+                a.sides[sid] = r;
+                a.out_len[sid] = len;
+                a.status[sid] = status;
+                if (a.window > 0) {
+                    __threadfence();
+                    __hip_atomic_store(&a.committed[(size_t)dir * a.n_seeds + seed], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    while (true) {                                                      // advance the commit frontier
+                        unsigned long long F = ld_agent(&a.frontier[dir]);
+                        if ((long long)F >= a.n_seeds) break;
+                        unsigned int c = __hip_atomic_fetch_add(&a.committed[(size_t)dir * a.n_seeds + F], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!c) break;
+                        unsigned long long e = F;
+                        __hip_atomic_compare_exchange_strong(&a.frontier[dir], &e, F + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                }
-                __threadfence();
-                __hip_atomic_store(&a.committed[(size_t)dir * a.n_seeds + seed], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                while (true) {                                                      // advance the commit frontier
-                    unsigned long long F = ld_agent(&a.frontier[dir]);
-                    if ((long long)F >= a.n_seeds) break;
-                    unsigned int c = __hip_atomic_fetch_add(&a.committed[(size_t)dir * a.n_seeds + F], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!c) break;
-                    unsigned long long e = F;
-                    __hip_atomic_compare_exchange_strong(&a.frontier[dir], &e, F + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
+        PROF(7)
         __builtin_amdgcn_wave_barrier();
     }
+    PROF_FLUSH
     if (lane == 0) a.slot_tag[slot] = tag;
 }
 
@@ -615,6 +687,8 @@ int mgta_hmm_load(mgta_ctx *ctx, int M, int A, const double *msc, const double *
                 return MGTA_EINVAL;
             }
         }
+        hm->d_col.alloc(128, &ctx->live_bytes, &ctx->peak_bytes);
+        MGTA_HIP_CHECK(hipMemcpy(hm->d_col.p, hm->col, 128, hipMemcpyHostToDevice));
         ctx_retain(ctx);
         *out = hm.release();
         return MGTA_OK;
@@ -685,17 +759,21 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         size_t lds_bytes = 0;
         for (int d = 0; d < 2; ++d) {
             a.hm[d].tab = hm[d]->tab.as<double>(); a.hm[d].M = hm[d]->M; a.hm[d].A = hm[d]->A;
-            memcpy(a.hm[d].col_fwd, hm[d]->col[0], 64);
-            memcpy(a.hm[d].col_enum, hm[d]->col[d], 64);
+            a.hm[d].col_fwd = hm[d]->d_col.as<int8_t>();
+            a.hm[d].col_enum = hm[d]->d_col.as<int8_t>() + 64 * d;
             lds_bytes = std::max(lds_bytes, hm[d]->n_doubles * 8);
         }
         a.kmers = d_kmers.as<char>(); a.start_state = d_ss.as<int32_t>(); a.start_node = d_sn.as<int64_t>();
         a.n_seeds = n; a.klen = klen; a.prune = prune_len; a.low_cov_penalty = lcp; a.log2v = std::log(2.0);
         a.exit_prob = d_exit.as<double>();
         a.queue = d_queue.as<unsigned long long>();
+        DevBuf d_prof;
+        d_prof.alloc(64);
+        MGTA_HIP_CHECK(hipMemsetAsync(d_prof.p, 0, 64, st));
+        a.prof = d_prof.as<unsigned long long>();
         a.sides = d_sides.as<mgta_astar_side>(); a.out_seq = d_out.as<char>(); a.out_cap = out_cap; a.out_len = d_len.as<uint32_t>();
         a.status = d_status.as<int32_t>();
-        a.use_lds = lds_bytes <= 150 * 1024;
+        a.use_lds = lds_bytes + sizeof(HeapEnt) * (kLdsHeap + 1) * kAstarWaves + 2048 <= 160 * 1024;   // tables + LDS heap tops
         if (a.use_lds)
             MGTA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(astar_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds_bytes));
@@ -778,6 +856,16 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 set_error("search %lld did not run (ordered-commit gate timed out)", (long long)s);
                 return MGTA_EHIP;
             }
+#ifdef MGTA_ASTAR_PROFILE
+        {
+            unsigned long long hp[8];
+            MGTA_HIP_CHECK(hipMemcpy(hp, d_prof.p, 64, hipMemcpyDeviceToHost));
+            const char *nm[8] = {"setup", "pop+closedprobe", "node+closedins", "cache", "graph", "children+probe", "commit", "result"};
+            unsigned long long tot = 0;
+            for (int q = 0; q < 8; ++q) tot += hp[q];
+            for (int q = 0; q < 8; ++q) fprintf(stderr, "[astar-prof] %-16s %6.2f %%\n", nm[q], 100.0 * hp[q] / (tot ? tot : 1));
+        }
+#endif
         // results
         std::vector<mgta_astar_side> h_sides((size_t)n * 2);
         std::vector<uint32_t> h_len((size_t)n * 2);

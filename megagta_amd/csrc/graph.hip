@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, i
         L.last = b_last; L.tip = b_tip; L.invalid = b_inv; L.multi1 = b_m1;
         L.rank_last = 0; L.rank_tip = 0;
         L.rank_w[0] = L.rank_w[1] = L.rank_w[2] = L.rank_w[3] = 0;
-        L.pad[0] = L.pad[1] = 0;
+        L.fwd_hint[0] = L.fwd_hint[1] = L.fwd_hint[2] = L.fwd_hint[3] = 0;
         lines[li] = L;
         cnt[0 * n_lines + li] = (uint32_t)__popcll(b_last);
         cnt[1 * n_lines + li] = (uint32_t)__popcll(b_tip);
@@ -69,6 +69,23 @@ __global__ __launch_bounds__(256) void graph_rank_kernel(GLine *lines, uint64_t 
         int c = s == 0 ? 0 : s + 1;
         uint64_t lo = b[c], hi = lo + cnt[c * n_lines + li];
         for (uint64_t m = (lo + 63) & ~63ull; m < hi; m += 64) sel[s][m >> 6] = (uint32_t)li;
+    }
+}
+
+// G4: forward hints (needs rank_f): line of Select(rank_f[a] + #a before this line)
+__global__ __launch_bounds__(256) void graph_hint_kernel(GraphDev g, GLine *lines) {
+    uint64_t li = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= g.n_lines) return;
+#pragma unroll
+    for (int a = 1; a <= 4; ++a) {
+        int64_t r0 = g.rank_f[a] + (int64_t)lines[li].rank_w[a - 1];
+        uint64_t h = g.n_lines - 1;
+        if (r0 < g.total_last) {
+            if (r0 < 0) r0 = 0;
+            h = g.sel_last[r0 >> 6];
+            while (h + 1 < g.n_lines && (int64_t)lines[h + 1].rank_last <= r0) ++h;
+        }
+        lines[li].fwd_hint[a - 1] = (uint32_t)h;
     }
 }
 
@@ -153,6 +170,8 @@ int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, con
             d_rf.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
             hipLaunchKernelGGL(graph_rankf_kernel, dim3(1), dim3(64), 0, st, d, d_rf.as<int64_t>());
             MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
+            MGTA_HIP_CHECK(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(graph_hint_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d, g->lines.as<GLine>());
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
         }
         ctx_retain(ctx);

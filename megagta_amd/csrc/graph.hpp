@@ -22,7 +22,8 @@ struct alignas(128) GLine {
     uint64_t rank_last;   // ones of `last` before this line
     uint64_t rank_tip;    // tips before this line
     uint64_t rank_w[4];   // occurrences of W == a (a = 1..4, plain symbols only) before this line
-    uint64_t pad[2];
+    uint32_t fwd_hint[4]; // line where Forward of the first W == a edge at/after this line lands (a = 1..4): Forward(e) needs
+                          // no select-sample lookup, it starts from this hint and advances at most a line or two
 };
 static_assert(sizeof(GLine) == 128, "one line per 64 edges");
 
@@ -138,7 +139,13 @@ __device__ __forceinline__ int64_t g_forward(const GraphDev &g, int64_t e) {   /
     int a = g_W(g, e);
     if (a > 4) a -= 4;
     int64_t cnt = g_rank_w(g, a, e);
-    return g_select_last(g, g.rank_f[a] + cnt - 1);
+    int64_t r = g.rank_f[a] + cnt - 1;
+    if (r >= g.total_last) return g.size;
+    if (r < 0) return -1;
+    uint64_t li = g.lines[e >> 6].fwd_hint[a - 1];
+    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r) ++li;
+    const GLine &L = g.lines[li];
+    return (int64_t)(li << 6) + select64(L.last, (int)(r - (int64_t)L.rank_last));
 }
 
 __device__ __forceinline__ int g_node_last_char(const GraphDev &g, int64_t x) {   // succinct_dbg.h:109-115
@@ -168,6 +175,83 @@ __device__ __forceinline__ int g_outgoing(const GraphDev &g, int64_t e, int64_t 
         }
         --x;
     } while (x >= 0 && !g_last_or_tip(g, x));
+    return od > 4 ? 4 : od;
+}
+
+// ---- line-at-a-time navigation for the A* kernel -------------------------------------------------
+// A whole 128-byte line is pulled into registers with one burst of loads; OutgoingEdges then costs one more
+// burst (the hinted target line) instead of a chain of dependent 8-byte loads.  The target line is handed
+// back: the returned child edges live in it, so the next level starts without a fetch.  Everything is kept
+// in named scalars (no indexed register arrays: those would be demoted to scratch memory).
+struct LineR {
+    uint64_t w0, w1, w2, w3, last, tip, invalid, multi1, rank_last, rw0, rw1, rw2, rw3, h01, h23;
+};
+__device__ __forceinline__ LineR g_load_line(const GraphDev &g, uint64_t li) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(g.lines + li);
+    uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5], v6 = q[6], v7 = q[7];
+    auto u64 = [](uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); };
+    LineR L;
+    L.w0 = u64(v0.x, v0.y); L.w1 = u64(v0.z, v0.w); L.w2 = u64(v1.x, v1.y); L.w3 = u64(v1.z, v1.w);
+    L.last = u64(v2.x, v2.y); L.tip = u64(v2.z, v2.w); L.invalid = u64(v3.x, v3.y); L.multi1 = u64(v3.z, v3.w);
+    L.rank_last = u64(v4.x, v4.y);                      // (v4.z, v4.w) = rank_tip, not needed here
+    L.rw0 = u64(v5.x, v5.y); L.rw1 = u64(v5.z, v5.w); L.rw2 = u64(v6.x, v6.y); L.rw3 = u64(v6.z, v6.w);
+    L.h01 = u64(v7.x, v7.y); L.h23 = u64(v7.z, v7.w);
+    return L;
+}
+__device__ __forceinline__ uint64_t sel4(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, int i) {
+    uint64_t lo = (i & 1) ? a1 : a0, hi = (i & 1) ? a3 : a2;
+    return (i & 2) ? hi : lo;
+}
+__device__ __forceinline__ int l_W(const LineR &L, int64_t x) {
+    return (int)((sel4(L.w0, L.w1, L.w2, L.w3, (int)(x >> 4) & 3) >> ((x & 15) * 4)) & 15);
+}
+
+// `Le` must be line e>>6.  Outgoing edges (packed id<<4 | multi1<<3 | label) in o0..o3; Lt / lt_idx = line of o0.
+__device__ __forceinline__ int g_outgoing_line(const GraphDev &g, const LineR &Le, int64_t e, int64_t &o0, int64_t &o1, int64_t &o2,
+                                               int64_t &o3, LineR &Lt, uint64_t &lt_idx) {
+    if (g_bit(Le.invalid, e)) return -1;
+    int a = l_W(Le, e);
+    if (a > 4) a -= 4;
+    // Rank(a, e) from the registers (RankAndSelect4Bits::Rank, rank_and_select.h:153)
+    int64_t cnt;
+    if (e >= g.size - 1) cnt = a == 1 ? g.total_w[1] : a == 2 ? g.total_w[2] : a == 3 ? g.total_w[3] : g.total_w[4];
+    else {
+        int j = (int)(e & 63), fw = j >> 4;
+        int nb = (j & 15) + 1;
+        uint64_t m = nb == 16 ? ~0ull : ((1ull << (4 * nb)) - 1);
+        cnt = (int64_t)sel4(Le.rw0, Le.rw1, Le.rw2, Le.rw3, a - 1);
+        uint64_t e0 = nib_eq(Le.w0, a), e1 = nib_eq(Le.w1, a), e2 = nib_eq(Le.w2, a), e3 = nib_eq(Le.w3, a);
+        cnt += __popcll(fw > 0 ? e0 : (e0 & m));
+        if (fw >= 1) cnt += __popcll(fw > 1 ? e1 : (e1 & m));
+        if (fw >= 2) cnt += __popcll(fw > 2 ? e2 : (e2 & m));
+        if (fw >= 3) cnt += __popcll(e3 & m);
+    }
+    const int64_t rf = a == 1 ? g.rank_f[1] : a == 2 ? g.rank_f[2] : a == 3 ? g.rank_f[3] : g.rank_f[4];
+    int64_t r = rf + cnt - 1;                                             // Forward: Select(rank_f[a] + count - 1), succinct_dbg.h:155-164
+    if (r >= g.total_last || r < 0) return 0;
+    uint64_t hh = (a <= 2) ? Le.h01 : Le.h23;
+    uint64_t li = (a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32);           // fwd_hint[a-1]
+    LineR A = g_load_line(g, li);
+    uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
+        do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
+        A = g_load_line(g, li);
+    }
+    int64_t x = (int64_t)(li << 6) + select64(A.last, (int)(r - (int64_t)A.rank_last));
+    Lt = A; lt_idx = li;
+    int od = 0;
+    do {                                                                  // succinct_dbg.cpp:85-94
+        const bool in = (uint64_t)(x >> 6) == li;                         // almost always: the node's edges sit in the target line
+        bool inval = in ? g_bit(A.invalid, x) : !g_valid(g, x);
+        if (!inval) {
+            int w = in ? l_W(A, x) : g_W(g, x);
+            int m1 = in ? g_bit(A.multi1, x) : (int)g_multi1(g, x);
+            int64_t v = (x << 4) | ((int64_t)m1 << 3) | (int64_t)(w > 4 ? w - 4 : w);
+            if (od == 0) o0 = v; else if (od == 1) o1 = v; else if (od == 2) o2 = v; else if (od == 3) o3 = v;
+            ++od;
+        }
+        --x;
+    } while (x >= 0 && !(((uint64_t)(x >> 6) == li) ? g_bit(A.last | A.tip, x) : (int)g_last_or_tip(g, x)));
     return od > 4 ? 4 : od;
 }
 
