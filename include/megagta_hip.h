@@ -43,6 +43,8 @@ mgta_ctx *mgta_ctx_create(int device_id);            /* NULL on failure (see mgt
 void mgta_ctx_destroy(mgta_ctx *);
 /* memory the build may use on the device; 0 = 90 % of what is free (cf. --host_mem/--mem_flag, build_graph.cpp:40-47) */
 int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
+/* diagnostic switch: 1 = sort every key with global LSD passes only (the round-1 path; also the fallback for oversized segments) */
+int mgta_ctx_set_full_lsd(mgta_ctx *, int on);
 
 /* ------------------------------------------------------------------------------------------------
  * SdBG construction  (replaces CX1::run() with the s2 plug-ins: cx1.h:443-623,
@@ -69,6 +71,8 @@ typedef struct mgta_build_stats {
     double ms_total;                 /* device time, reads resident -> last record in device memory */
     double ms_count, ms_gen, ms_sort, ms_emit, ms_d2h;
     double ms_sort_scatter;          /* summed duration of the radix scatter launches (HIP events) */
+    double ms_local_sort;            /* duration of the segment-local (LDS) finishing sort */
+    int64_t n_big_segments;          /* key segments too long for LDS, finished by global passes */
     uint64_t bytes_peak;             /* device bytes allocated at the peak */
 } mgta_build_stats;
 

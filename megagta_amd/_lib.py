@@ -21,7 +21,8 @@ class BuildStats(C.Structure):
                 ("n_reads", C.c_int64), ("n_kmers", C.c_int64), ("n_items", C.c_int64), ("n_edges", C.c_int64),
                 ("n_tips", C.c_int64), ("n_large", C.c_int64), ("n_sort_launches", C.c_int64), ("ms_total", C.c_double),
                 ("ms_count", C.c_double), ("ms_gen", C.c_double), ("ms_sort", C.c_double), ("ms_emit", C.c_double),
-                ("ms_d2h", C.c_double), ("ms_sort_scatter", C.c_double), ("bytes_peak", C.c_uint64)]
+                ("ms_d2h", C.c_double), ("ms_sort_scatter", C.c_double), ("ms_local_sort", C.c_double), ("n_big_segments", C.c_int64),
+                ("bytes_peak", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -53,6 +54,7 @@ SYMBOLS = {
     "mgta_ctx_create": (C.c_void_p, [C.c_int]),
     "mgta_ctx_destroy": (None, [C.c_void_p]),
     "mgta_ctx_set_mem_limit": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "mgta_ctx_set_full_lsd": (C.c_int, [C.c_void_p, C.c_int]),
     "mgta_reads_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mgta_reads_adopt_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mgta_reads_free": (None, [C.c_void_p]),

@@ -58,6 +58,10 @@ class Context:
 
     __del__ = close
 
+    def set_full_lsd(self, on: bool):
+        """diagnostic: sort with global LSD passes only (no segment-local LDS finish)"""
+        check(self._L.mgta_ctx_set_full_lsd(self.h, int(on)), "mgta_ctx_set_full_lsd")
+
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 

@@ -63,6 +63,7 @@ struct mgta_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint64_t mem_limit = 0;       // 0 = auto
+    int force_full_lsd = 0;
     uint64_t live_bytes = 0, peak_bytes = 0;
     int num_cus = 256;
     hipDeviceProp_t prop;

@@ -48,6 +48,12 @@ void mgta_ctx_destroy(mgta_ctx *ctx) {
     if (ctx) mgta::ctx_release(ctx);
 }
 
+int mgta_ctx_set_full_lsd(mgta_ctx *ctx, int on) {
+    if (!ctx) return MGTA_EINVAL;
+    ctx->force_full_lsd = on;
+    return MGTA_OK;
+}
+
 int mgta_ctx_set_mem_limit(mgta_ctx *ctx, uint64_t bytes) {
     if (!ctx) return MGTA_EINVAL;
     ctx->mem_limit = bytes;

@@ -23,6 +23,7 @@
 // Everything is integer / byte work bound by HBM traffic; no MFMA.  Parity: bit-exact edge stream vs
 // the oracle (tests/test_sdbg_build_gpu.py).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <memory>
 
@@ -261,37 +262,27 @@ __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uin
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
-// stable scatter of one 32768-key tile by the current digit
+// shared state of one scatter workgroup
 template <int W>
-__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
-                                                                      uint64_t n_tiles, const uint64_t *rowoff,
-                                                                      const uint64_t *totals) {
-    __shared__ Key<W> s_keys[kSubTile];
-    __shared__ uint32_t s_whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile
-    __shared__ uint32_t s_start[256];               // first position of each digit value inside the sorted sub-tile
-    __shared__ uint32_t s_total[256];
-    __shared__ uint64_t s_gbase[256];               // global destination of the next key of each digit value
-    __shared__ uint32_t s_scratch[kSortThreads / 64 + 1];
+struct ScatterShared {
+    Key<W> keys[kSubTile];
+    uint32_t whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile
+    uint32_t start[256];               // first position of each digit value inside the sorted sub-tile
+    uint32_t total[256];
+    uint64_t gbase[256];               // global destination of the next key of each digit value
+    uint32_t scratch[kSortThreads / 64 + 1];
+};
+
+// stable scatter of in[0..n) by digit d to out[gbase[digit]++...], sub-tile by sub-tile (gbase must be set; all threads call)
+template <int W>
+__device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const uint64_t ltmask = lanemask_lt();
-
-    // global base of every digit value for this tile = scan(totals)[digit] + rowoff[digit][tile]
-    {
-        __shared__ uint64_t s64[kSortThreads / 64 + 1];
-        uint64_t t = tid < 256 ? totals[tid] : 0;
-        uint64_t ex = block_excl_scan64<kSortThreads>(t, s64, nullptr);
-        if (tid < 256) s_gbase[tid] = ex + rowoff[(uint64_t)tid * n_tiles + blockIdx.x];
-    }
-    volatile uint32_t *whist = &s_whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
+    volatile uint32_t *whist = &sh.whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
     for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
     __syncthreads();
-
-    const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
-    for (int st = 0; st < kSubTilesPerBlock; ++st) {
-        uint64_t sub_base = tile_base + (uint64_t)st * kSubTile;
-        if (sub_base >= n) break;
+    for (uint64_t sub_base = 0; sub_base < n; sub_base += kSubTile) {
         uint32_t n_valid = (uint32_t)((n - sub_base) < (uint64_t)kSubTile ? (n - sub_base) : (uint64_t)kSubTile);
-
         // phase 1: load (wave w owns keys [w*512, w*512+512) of the sub-tile, 64 at a time) + rank inside the wave chunk
         Key<W> key[kItemsPerThread];
         uint32_t dr[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
@@ -325,21 +316,21 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W
         if (tid < 256) {
 #pragma unroll
             for (int w = 0; w < kSortWaves; ++w) {
-                uint32_t c = s_whist[w][tid];
-                s_whist[w][tid] = tot;
+                uint32_t c = sh.whist[w][tid];
+                sh.whist[w][tid] = tot;
                 tot += c;
             }
-            s_total[tid] = tot;
+            sh.total[tid] = tot;
         }
-        uint32_t ex = block_excl_scan<kSortThreads>(tot, s_scratch, nullptr);
-        if (tid < 256) s_start[tid] = ex;
+        uint32_t ex = block_excl_scan<kSortThreads>(tot, sh.scratch, nullptr);
+        if (tid < 256) sh.start[tid] = ex;
         __syncthreads();
         // phase 3: place the keys in sorted order in LDS
 #pragma unroll
         for (int it = 0; it < kItemsPerThread; ++it) {
             if (dr[it] >> 31) {
                 uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
-                s_keys[s_start[dg] + s_whist[wv][dg] + rk] = key[it];
+                sh.keys[sh.start[dg] + sh.whist[wv][dg] + rk] = key[it];
             }
         }
         __syncthreads();
@@ -348,17 +339,244 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W
         for (int it = 0; it < kItemsPerThread; ++it) {
             uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
             if (j < n_valid) {
-                Key<W> kk = s_keys[j];
+                Key<W> kk = sh.keys[j];
                 uint32_t dg = get_digit<W>(kk, d);
-                out[s_gbase[dg] + (j - s_start[dg])] = kk;
+                out[sh.gbase[dg] + (j - sh.start[dg])] = kk;
             }
         }
         __syncthreads();
         // phase 5: advance the global bases, clear the wave counters
-        if (tid < 256) s_gbase[tid] += s_total[tid];
+        if (tid < 256) sh.gbase[tid] += sh.total[tid];
         for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
         __syncthreads();
     }
+}
+
+// stable scatter of one 32768-key tile by the current digit
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
+                                                                      uint64_t n_tiles, const uint64_t *rowoff,
+                                                                      const uint64_t *totals) {
+    __shared__ ScatterShared<W> sh;
+    __shared__ uint64_t s64[kSortThreads / 64 + 1];
+    const int tid = threadIdx.x;
+    // global base of every digit value for this tile = scan(totals)[digit] + rowoff[digit][tile]
+    uint64_t t = tid < 256 ? totals[tid] : 0;
+    uint64_t ex = block_excl_scan64<kSortThreads>(t, s64, nullptr);
+    if (tid < 256) sh.gbase[tid] = ex + rowoff[(uint64_t)tid * n_tiles + blockIdx.x];
+    __syncthreads();
+    const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
+    if (tile_base >= n) return;
+    const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
+    scatter_subtiles<W>(sh, in + tile_base, out, cnt, d);
+}
+
+// One workgroup sorts ONE oversized segment [big[b], big_end[b]) on all the low digits: census, scan and scatter of
+// every pass inside the same launch, ping-ponging between the two key buffers (the range is private to the workgroup).
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void segment_sort_kernel(Key<W> *buf_a, Key<W> *buf_b, const uint64_t *big, const uint64_t *big_end,
+                                                                     const Digit *low_plan, int n_low) {
+    __shared__ ScatterShared<W> sh;
+    __shared__ uint64_t s64[kSortThreads / 64 + 1];
+    __shared__ uint32_t s_cnt[256];
+    const int tid = threadIdx.x;
+    const uint64_t s0 = big[blockIdx.x], cnt = big_end[blockIdx.x] - s0;
+    Key<W> *x = buf_a + s0, *y = buf_b + s0;
+    for (int pass = 0; pass < n_low; ++pass) {
+        const Digit d = low_plan[pass];
+        if (tid < 256) s_cnt[tid] = 0;
+        __syncthreads();
+        for (uint64_t i = tid; i < cnt; i += kSortThreads) atomicAdd(&s_cnt[get_digit<W>(x[i], d)], 1u);
+        __syncthreads();
+        uint64_t c = tid < 256 ? s_cnt[tid] : 0;
+        uint64_t ex = block_excl_scan64<kSortThreads>(c, s64, nullptr);
+        if (tid < 256) sh.gbase[tid] = ex;
+        __syncthreads();
+        scatter_subtiles<W>(sh, x, y, cnt, d);
+        __threadfence();                         // the next pass re-reads what this one wrote (other waves' stores, L1 lines of an older pass)
+        __syncthreads();
+        Key<W> *t = x; x = y; y = t;
+    }
+    if (x != buf_a + s0)                         // odd number of passes: bring the result back to the main buffer
+        for (uint64_t i = tid; i < cnt; i += kSortThreads) y[i] = x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4b. segment-local finish.  After P global passes on the P most significant key bytes the array is
+// partitioned into segments of equal 8P-bit prefix (in arbitrary inner order).  Each workgroup takes
+// the whole segments that START in its stride of the array (<= LocalCfg<W>::kTile keys), sorts them on the
+// remaining bits entirely in LDS/registers (LSD, same wave-match ranking as the global scatter; the
+// segment rank is the most significant digit so segments keep their order) and writes them back in
+// place: these keys cross HBM once more instead of once per remaining digit.  A segment that does
+// not fit is reported in `big` and finished by global passes over just that range.
+// ---------------------------------------------------------------------------------------------
+template <int W> struct LocalCfg {
+    static constexpr int kTile = W <= 4 ? 4096 : 2048;           // keys sorted in LDS by one workgroup (LDS budget: kTile * 4W bytes)
+    static constexpr int kIpt = kTile / kSortThreads;
+    static constexpr int kChunk = kTile / kSortWaves;
+    static constexpr uint32_t kStride = kTile / 2;                // a workgroup owns the segments that START in its stride
+    static constexpr int kThreads = kSortThreads;
+    static constexpr uint64_t kItemsPerBlockStride = kStride;
+};
+
+template <int W>
+__device__ __forceinline__ uint32_t key_prefix(const Key<W> &key, int P) { return P == 0 ? 0u : (key.w[0] >> (32 - 8 * P)); }
+
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, uint64_t n, int P, const Digit *low_plan, int n_low,
+                                                                  uint64_t *big, uint32_t *big_count, uint32_t big_cap) {
+    constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
+    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride;
+    __shared__ Key<W> s_keys[kTile];
+    __shared__ uint16_t s_seg[kTile];
+    __shared__ uint32_t s_whist[kSortWaves][256];
+    __shared__ uint32_t s_start[256];
+    __shared__ uint32_t s_scratch[kSortThreads / 64 + 1];
+    __shared__ unsigned long long s_first, s_lasthead, s_end;
+    __shared__ uint32_t s_wheads[kSortWaves + 1];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const uint64_t ltmask = lanemask_lt();
+    const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
+    const uint64_t hi = lo + kLocalStride < n ? lo + kLocalStride : n;
+    const unsigned long long NONE = ~0ull;
+    if (tid == 0) { s_first = NONE; s_lasthead = 0; s_end = NONE; }
+    __syncthreads();
+    auto is_head = [&](uint64_t idx) { return idx == 0 || key_prefix<W>(keys[idx], P) != key_prefix<W>(keys[idx - 1], P); };
+    // 1. first / last segment head inside [lo, hi)
+    for (uint64_t idx = lo + tid; idx < hi; idx += kSortThreads)
+        if (is_head(idx)) { atomicMin(&s_first, (unsigned long long)idx); atomicMax(&s_lasthead, (unsigned long long)idx); }
+    __syncthreads();
+    const uint64_t first = s_first;
+    if (first == NONE) return;                                       // the stride lies inside one long segment
+    // 2. end of the tile: the first head at or after hi, as long as the tile stays <= kTile keys
+    const uint64_t limit = first + kTile < n ? first + kTile : n;
+    for (uint64_t idx = hi + tid; idx <= limit && idx < n; idx += kSortThreads)
+        if (is_head(idx)) atomicMin(&s_end, (unsigned long long)idx);
+    __syncthreads();
+    uint64_t end = s_end;
+    if (end == NONE) {
+        if (limit == n) end = n;
+        else {                                                       // the last segment starting here is too long for LDS
+            end = s_lasthead;
+            if (tid == 0) {
+                uint32_t q = atomicAdd(big_count, 1u);
+                if (q < big_cap) big[q] = end;
+            }
+        }
+    }
+    const uint32_t nt = (uint32_t)(end - first);
+    if (nt == 0) return;
+
+    // 3. load in (wave chunk, round, lane) order + rank of the segment inside the tile
+    Key<W> key[kIpt];
+    uint32_t seg[kIpt];
+    uint32_t running = 0;
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+        bool valid = j < nt, head = false;
+        if (valid) {
+            key[it] = keys[first + j];
+            head = j == 0 || key_prefix<W>(key[it], P) != key_prefix<W>(keys[first + j - 1], P);
+        }
+        uint64_t bal = __ballot(head);
+        seg[it] = running + (uint32_t)__popcll(bal & (ltmask | (1ull << lane)));   // heads at positions <= j inside this wave chunk
+        running += (uint32_t)__popcll(bal);
+    }
+    if (lane == 0) s_wheads[wv] = running;
+    __syncthreads();
+    uint32_t before = 0, nseg = 0;
+    for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_wheads[w]; if (w < wv) before += c; nseg += c; }
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) seg[it] = seg[it] + before - 1;
+    const int n_seg_pass = nseg <= 1 ? 0 : (nseg <= 256 ? 1 : 2);
+
+    // 4. LSD passes: the low key digits, then the segment rank
+    volatile uint32_t *whist = &s_whist[0][0];
+    for (int pass = 0; pass < n_low + n_seg_pass; ++pass) {
+        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
+        __syncthreads();
+        const bool by_seg = pass >= n_low;
+        Digit d;
+        d.pos = 0; d.bits = 8;
+        if (!by_seg) d = low_plan[pass];
+        const int seg_shift = by_seg ? 8 * (pass - n_low) : 0;
+        uint32_t dr[kIpt];
+#pragma unroll
+        for (int it = 0; it < kIpt; ++it) {
+            uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+            bool valid = j < nt;
+            uint32_t dg = 0;
+            if (valid) dg = by_seg ? ((seg[it] >> seg_shift) & 255u) : get_digit<W>(key[it], d);
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                uint64_t bal = __ballot((dg >> b) & 1u);
+                peers &= ((dg >> b) & 1u) ? bal : ~bal;
+            }
+            uint32_t rank = (uint32_t)__popcll(peers & ltmask), cnt = (uint32_t)__popcll(peers), prev = 0;
+            if (valid) {
+                prev = whist[wv * 256 + dg];
+                if (rank == cnt - 1) whist[wv * 256 + dg] = prev + cnt;
+            }
+            dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
+        }
+        __syncthreads();
+        uint32_t tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = tot; tot += c; }
+        }
+        uint32_t ex = block_excl_scan<kSortThreads>(tot, s_scratch, nullptr);
+        if (tid < 256) s_start[tid] = ex;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kIpt; ++it) {
+            if (dr[it] >> 31) {
+                uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
+                uint32_t pos = s_start[dg] + s_whist[wv][dg] + rk;
+                s_keys[pos] = key[it];
+                s_seg[pos] = (uint16_t)seg[it];
+            }
+        }
+        __syncthreads();
+        if (pass + 1 < n_low + n_seg_pass) {                         // back into registers in position order
+#pragma unroll
+            for (int it = 0; it < kIpt; ++it) {
+                uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+                if (j < nt) { key[it] = s_keys[j]; seg[it] = s_seg[j]; }
+            }
+            __syncthreads();
+        }
+    }
+    // 5. write back (coalesced).  With zero passes (a single segment of identical low bits cannot happen: n_low >= 1) LDS holds the result.
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+        if (j < nt) keys[first + j] = s_keys[j];
+    }
+}
+
+// first segment head after `start` (end of a big segment): one workgroup per big segment
+template <int W>
+__global__ __launch_bounds__(256) void segment_end_kernel(const Key<W> *keys, uint64_t n, int P, const uint64_t *big, uint64_t *big_end) {
+    __shared__ unsigned long long s_end;
+    const uint64_t start = big[blockIdx.x];
+    const uint32_t pre = key_prefix<W>(keys[start], P);
+    if (threadIdx.x == 0) s_end = ~0ull;
+    __syncthreads();
+    for (uint64_t base = start + 1; base < n; base += 256 * 16) {
+        unsigned long long found = ~0ull;
+        for (int i = 0; i < 16; ++i) {
+            uint64_t idx = base + (uint64_t)i * 256 + threadIdx.x;
+            if (idx < n && key_prefix<W>(keys[idx], P) != pre && (unsigned long long)idx < found) found = idx;
+        }
+        if (found != ~0ull) atomicMin(&s_end, found);
+        __syncthreads();
+        if (s_end != ~0ull) break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) big_end[blockIdx.x] = s_end == ~0ull ? n : s_end;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -618,10 +836,21 @@ static std::vector<Digit> digit_plan(int k, int W) {
     return plan;
 }
 
+// most significant digits first: digit i = key bits [32W - 8(i+1), 32W - 8i)
+static Digit top_digit(int W, int i) { return Digit{32 * W - 8 * (i + 1), 8}; }
+// digits of the bits below 32W - 8P, least significant first (flags, then characters; the zero pad is skipped)
+static std::vector<Digit> low_digit_plan(int k, int W, int P) {
+    std::vector<Digit> plan;
+    int pad = 32 * W - 2 * k - 4, top = 32 * W - 8 * P;
+    if (top > 0) plan.push_back(Digit{0, std::min(4, top)});
+    for (int pos = 4 + pad; pos < top; pos += 8) plan.push_back(Digit{pos, std::min(8, top - pos)});
+    return plan;
+}
+
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -725,23 +954,69 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucke
             sa.out = d_a;
             hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             S.ms_gen += t_ph.stop();
-            // ---- 4. LSD radix sort
+            // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
             Key<W> *src = d_a, *dst = d_b;
-            for (const Digit &dg : plan) {
-                hipLaunchKernelGGL((radix_census_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, n_items, dg,
-                                   n_tiles, d_hist);
-                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, n_tiles, d_totals);
-                hipEvent_t e0, e1;
-                MGTA_HIP_CHECK(hipEventCreate(&e0));
-                MGTA_HIP_CHECK(hipEventCreate(&e1));
-                MGTA_HIP_CHECK(hipEventRecord(e0, stream));
-                hipLaunchKernelGGL((radix_scatter_kernel<W>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, stream, src, dst, n_items,
-                                   dg, n_tiles, d_hist, d_totals);
-                MGTA_HIP_CHECK(hipEventRecord(e1, stream));
-                scatter_ev.emplace_back(e0, e1);
-                S.n_sort_launches++;
-                std::swap(src, dst);
+            auto global_pass = [&](Key<W> *from, Key<W> *to, uint64_t cnt, const Digit &dg, bool timed) {
+                uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
+                hipLaunchKernelGGL((radix_census_kernel<W>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, tiles, d_totals);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timed) {
+                    MGTA_HIP_CHECK(hipEventCreate(&e0));
+                    MGTA_HIP_CHECK(hipEventCreate(&e1));
+                    MGTA_HIP_CHECK(hipEventRecord(e0, stream));
+                }
+                hipLaunchKernelGGL((radix_scatter_kernel<W>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles,
+                                   d_hist, d_totals);
+                if (timed) {
+                    MGTA_HIP_CHECK(hipEventRecord(e1, stream));
+                    scatter_ev.emplace_back(e0, e1);
+                    S.n_sort_launches++;
+                }
+            };
+            // P: smallest number of leading bytes that leaves segments of ~<= 256 keys on average
+            const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
+            int P = 0;
+            while (P < max_top && (double)n_items / std::pow(256.0, P) > 256.0) ++P;
+            if (ctx->force_full_lsd) P = 0;
+            for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(W, i), true); std::swap(src, dst); }
+            const std::vector<Digit> low = low_digit_plan(k, W, P);
+            Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
+            MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
+            const uint32_t big_cap = 1u << 16;
+            uint64_t *d_big = pool_get<uint64_t>(ctx, S_BIG, (2 * (uint64_t)big_cap + 2) * 8);
+            uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * big_cap);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 8, stream));
+            uint64_t l_blocks = (n_items + LocalCfg<W>::kStride - 1) / LocalCfg<W>::kStride;
+            hipEvent_t le0, le1;
+            MGTA_HIP_CHECK(hipEventCreate(&le0));
+            MGTA_HIP_CHECK(hipEventCreate(&le1));
+            MGTA_HIP_CHECK(hipEventRecord(le0, stream));
+            hipLaunchKernelGGL((local_sort_kernel<W>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, P, d_plan,
+                               (int)low.size(), d_big, d_big_count, big_cap);
+            MGTA_HIP_CHECK(hipEventRecord(le1, stream));
+            uint32_t n_big = 0;
+            MGTA_HIP_CHECK(hipMemcpyAsync(&n_big, d_big_count, 4, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            {
+                float ms = 0;
+                MGTA_HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
+                S.ms_local_sort += ms;
+                (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
+            }
+            if (n_big > big_cap) { set_error("more than %u oversized key segments in one pass", big_cap); return MGTA_EUNSUPPORTED; }
+            if (n_big > 0) {
+                // segments too long for LDS (hot k-mers, or the whole array when it is tiny): finish each with global passes
+                std::vector<uint64_t> h_big(n_big), h_end(n_big);
+                hipLaunchKernelGGL((segment_end_kernel<W>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
+                MGTA_HIP_CHECK(hipMemcpyAsync(h_big.data(), d_big, n_big * 8, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipMemcpyAsync(h_end.data(), d_big + big_cap, n_big * 8, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                (void)h_big; (void)h_end;
+                hipLaunchKernelGGL((segment_sort_kernel<W>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
+                                   (int)low.size());
+                S.n_big_segments += n_big;
             }
             S.ms_sort += t_ph.stop();
             // ---- 5. emit.  `src` holds the sorted keys; the other buffer is scratch.
