@@ -213,9 +213,17 @@ struct Digit {
 
 template <int W>
 __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
-    int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
-    uint32_t v = key.w[wi] >> off;
-    if (off + d.bits > 32 && wi > 0) v |= key.w[wi - 1] << (32 - off);
+    // the word is picked with compile-time indices + selects: a run-time index into key.w[] would push every
+    // register-resident key of the caller into scratch memory
+    const int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        if (j == wi) lo = key.w[j];
+        if (j == wi - 1) hi = key.w[j];
+    }
+    uint32_t v = lo >> off;
+    if (off + d.bits > 32) v |= hi << (32 - off);
     return v & ((1u << d.bits) - 1u);
 }
 
