@@ -112,10 +112,19 @@ def main():
     b0, b1 = mdist.bucket_share(rank, world)
 
     def step():
-        g = ctx.build_sdbg(rd, k, collect=(world > 1), bucket_range=(b0, b1))
+        g = ctx.build_sdbg(rd, k, collect=False, bucket_range=(b0, b1))
         if world > 1:
-            # the path's one exchange: every rank receives every shard of the edge stream (RCCL all-gather)
-            mdist.all_gather_edge_stream(g)
+            # the path's one exchange: every rank receives every shard of the edge stream (RCCL all-gather),
+            # device to device: the shard never visits the host
+            shard = api.export_records_to_torch(ctx)
+            n = torch.tensor([shard.numel()], device="cuda", dtype=torch.int64)
+            ns = [torch.zeros_like(n) for _ in range(world)]
+            dist.all_gather(ns, n)
+            mx = max(int(x.item()) for x in ns)
+            pad = torch.zeros(max(mx, 1), dtype=torch.uint8, device="cuda")
+            pad[: shard.numel()] = shard
+            out = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(out, pad)
         return g.stats
 
     def fence():

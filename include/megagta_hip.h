@@ -93,6 +93,9 @@ void mgta_reads_free(mgta_reads *);
 int mgta_sdbg_build_resident(mgta_ctx *, const mgta_reads *, uint64_t n_short_reads, int k, int min_count,
                              int need_mercy, int32_t bucket_begin, int32_t bucket_end /* this GPU's share of the 65536 buckets */,
                              mgta_edge_sink sink, void *user, mgta_build_stats *stats);
+/* Records of the LAST build pass are still on the device: copy them (device -> device) into a caller-owned device
+ * buffer (e.g. a torch tensor that is then all-gathered over RCCL).  d_dst = NULL only queries *n_records. */
+int mgta_sdbg_export_records_device(mgta_ctx *, void *d_dst, uint64_t capacity_bytes, uint64_t *n_records);
 /* convenience: upload + build + free */
 int mgta_sdbg_build(mgta_ctx *, const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx,
                     uint64_t n_reads, uint64_t n_short_reads, int k, int min_count, int need_mercy,

@@ -109,6 +109,16 @@ class Context:
                           bucket_tips=counts[:, 2].copy(), stats=st.as_dict())
 
 
+def export_records_to_torch(ctx: "Context"):
+    """records of the last build pass as a torch uint8 CUDA tensor (device -> device copy, no host round trip)"""
+    import torch
+    n = C.c_uint64()
+    check(ctx._L.mgta_sdbg_export_records_device(ctx.h, None, 0, C.byref(n)), "mgta_sdbg_export_records_device")
+    t = torch.empty(max(1, n.value * 2), dtype=torch.uint8, device="cuda")
+    check(ctx._L.mgta_sdbg_export_records_device(ctx.h, t.data_ptr(), t.numel(), C.byref(n)), "mgta_sdbg_export_records_device")
+    return t[: n.value * 2]
+
+
 class Graph:
     """Device-resident succinct de Bruijn graph (mgta_sdbg) <-> SuccinctDBG (succinct_dbg.h:32-247)."""
 

@@ -1066,6 +1066,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucke
             hipLaunchKernelGGL((emit_write_kernel<W>), dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sorted, sub_start, rec, m,
                                n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec, d_out_large, d_out_tips, d_first);
             S.ms_emit += t_ph.stop();
+            ctx->last_rec = d_out_rec; ctx->last_n_rec = n_edges; ctx->last_bucket_lo = b_lo; ctx->last_bucket_hi = b_hi;
             // ---- device -> host
             if (sink) {
                 t_ph.start();
@@ -1179,6 +1180,20 @@ int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_sho
         case 8: return build_impl<8>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
         default: return build_impl<9>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
         }
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_export_records_device(mgta_ctx *ctx, void *d_dst, uint64_t capacity_bytes, uint64_t *n_records) {
+    if (!ctx || !n_records) { set_error("mgta_sdbg_export_records_device: null argument"); return MGTA_EINVAL; }
+    *n_records = ctx->last_n_rec;
+    if (!ctx->last_rec && ctx->last_n_rec) { set_error("no device-resident build output"); return MGTA_EINVAL; }
+    if (!d_dst) return MGTA_OK;                                    // size query
+    if (capacity_bytes < ctx->last_n_rec * 2) { set_error("destination too small"); return MGTA_EINVAL; }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        if (ctx->last_n_rec) MGTA_HIP_CHECK(hipMemcpyAsync(d_dst, ctx->last_rec, ctx->last_n_rec * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MGTA_OK;
     } catch (const HipError &e) { return e.code; }
 }
 

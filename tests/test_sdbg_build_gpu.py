@@ -125,3 +125,21 @@ def test_no_device_path_is_loud():
     with pytest.raises(api.MegaGtaError):
         c.build_sdbg(rd, 29, min_count=2)
     c.close()
+
+
+def test_device_export_matches_host_collect(ctx, golden_dir):
+    """the device-resident record shard handed to the RCCL all-gather == what the host sink receives; bucket-range shards concatenate to the whole"""
+    import torch
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    whole = ctx.build_sdbg(rd, 44)
+    parts = []
+    for r in range(2):
+        b0, b1 = r * 32768, (r + 1) * 32768
+        g = ctx.build_sdbg(rd, 44, bucket_range=(b0, b1))
+        t = api.export_records_to_torch(ctx)
+        assert np.array_equal(t.cpu().numpy().view(np.uint16), g.records)
+        assert g.bucket_items[:b0].sum() == 0 and g.bucket_items[b1:].sum() == 0
+        parts.append(g.records)
+    assert np.array_equal(np.concatenate(parts), whole.records)
