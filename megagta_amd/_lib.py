@@ -2,6 +2,10 @@
 
 There is no CPU fallback: if the HIP library is missing or no device is usable every call fails
 loudly (MegaGtaError).
+
+Note: PyTorch wheels bundle their own copy of the HIP runtime.  A process that uses both this library
+and torch (bench.py, megagta_amd.dist) must `import torch` BEFORE the first call into this module so
+that one runtime serves both; the library itself never needs torch.
 """
 from __future__ import annotations
 

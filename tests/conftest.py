@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                      # PyTorch bundles its own HIP runtime: when a process uses both, torch must be loaded first
+    import torch          # noqa: F401  (the product itself does not need torch; bench.py / megagta_amd.dist do)
+except Exception:         # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
