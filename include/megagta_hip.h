@@ -86,13 +86,16 @@ int mgta_reads_adopt_device(mgta_ctx *, const uint32_t *d_packed_seq, uint64_t n
                             const uint64_t *d_start_idx, uint64_t n_reads, mgta_reads **out);
 void mgta_reads_free(mgta_reads *);
 
-/* a2-a6: reads resident -> edge stream.  min_count must be 1 (reference `-m 1`: every position solid);
- * min_count > 1 / need_mercy (stage 1, cx1_read2sdbg_s1.cpp) returns MGTA_EUNSUPPORTED.
+/* a2-a7: reads resident -> edge stream.  min_count = 1 (reference `-m 1`): every position solid.  min_count >= 2 runs
+ * stage 1 first (cx1_read2sdbg_s1.cpp: (k+1)-mer counting, solid marks; need_mercy adds mercy edges, s2.cpp:106-250).
  * n_short_reads: reads [n_short_reads, n_reads) are assist sequences (always solid, s2.cpp:276).
  * sink may be NULL (records stay on the device, e.g. for timing). */
 int mgta_sdbg_build_resident(mgta_ctx *, const mgta_reads *, uint64_t n_short_reads, int k, int min_count,
                              int need_mercy, int32_t bucket_begin, int32_t bucket_end /* this GPU's share of the 65536 buckets */,
                              mgta_edge_sink sink, void *user, mgta_build_stats *stats);
+/* (k+1)-mer multiplicity histogram of the last min_count >= 2 build: hist[i] = number of distinct (k+1)-mers seen i times
+ * (i = 65535: that or more) — what s1_post_proc accumulates into PREFIX.counting (cx1_read2sdbg_s1.cpp:905-930). */
+int mgta_sdbg_last_counting(mgta_ctx *, int64_t *hist /* [65536] */);
 /* Records of the LAST build pass are still on the device: copy them (device -> device) into a caller-owned device
  * buffer (e.g. a torch tensor that is then all-gathered over RCCL).  d_dst = NULL only queries *n_records. */
 int mgta_sdbg_export_records_device(mgta_ctx *, void *d_dst, uint64_t capacity_bytes, uint64_t *n_records);

@@ -62,6 +62,12 @@ class Context:
         """diagnostic: sort with global LSD passes only (no segment-local LDS finish)"""
         check(self._L.mgta_ctx_set_full_lsd(self.h, int(on)), "mgta_ctx_set_full_lsd")
 
+    def last_counting(self) -> np.ndarray:
+        """(k+1)-mer multiplicity histogram of the last min_count >= 2 build (int64[65536]); `counting_text` renders PREFIX.counting"""
+        h = np.zeros(65536, dtype=np.int64)
+        check(self._L.mgta_sdbg_last_counting(self.h, h.ctypes.data), "mgta_sdbg_last_counting")
+        return h
+
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 
@@ -219,6 +225,12 @@ def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str
     check(ctx._L.mgta_astar_batch(graph.h, fwd.h, rev.h, buf, ss.ctypes.data, n, prune_len, low_cov_penalty, cache_mode,
                                   _lib.CONTIG_SINK(sink), None, C.byref(st)), "mgta_astar_batch")
     return results, st.as_dict()
+
+
+def counting_text(hist: np.ndarray) -> str:
+    """PREFIX.counting as s1_post_proc writes it: one line `i cumulative_count` for i = 1..65535 (cx1_read2sdbg_s1.cpp:923-930)"""
+    acc = np.cumsum(hist[1:])
+    return "".join(f"{i} {int(a)}\n" for i, a in zip(range(1, 65536), acc))
 
 
 class Reads:

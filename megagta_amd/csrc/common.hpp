@@ -68,6 +68,7 @@ struct mgta_ctx {
     int num_cus = 256;
     hipDeviceProp_t prop;
     std::vector<mgta::DevBuf> pool;   // grow-only scratch kept between calls
+    std::vector<int64_t> edge_counting;   // (k+1)-mer multiplicity histogram of the last stage-1 run (.counting)
     const void *last_rec = nullptr;   // records of the last build pass, still resident in the pool
     uint64_t last_n_rec = 0;
     uint32_t last_bucket_lo = 0, last_bucket_hi = 0;

@@ -116,6 +116,15 @@ static int main_buildgraph(int argc, char **argv) {
     int rc = mgta_sdbg_build(ctx, pr.words.data(), pr.words.size(), pr.start.data(), pr.start.size() - 1, pr.n_short, k, min_count,
                              min_count > 1 ? need_mercy : 0, sink_collect, &s, &st);
     if (rc != MGTA_OK) die("mgta_sdbg_build: %s", mgta_last_error());
+    if (min_count > 1) {                                                 // PREFIX.counting (s1_post_proc, cx1_read2sdbg_s1.cpp:923-930)
+        std::vector<int64_t> hist(65536);
+        if (mgta_sdbg_last_counting(ctx, hist.data()) != MGTA_OK) die("%s", mgta_last_error());
+        FILE *cf = fopen((out_prefix + ".counting").c_str(), "w");
+        if (!cf) die("cannot write %s.counting", out_prefix.c_str());
+        long long acc = 0;
+        for (int i = 1; i <= 65535; ++i) { acc += hist[i]; fprintf(cf, "%d %lld\n", i, acc); }
+        fclose(cf);
+    }
     mgta_ctx_destroy(ctx);
     logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
          (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);

@@ -105,6 +105,9 @@ struct ScanArgs {
     const uint64_t *block_base;            // write mode
     void *out;                             // Key<W>*
     unsigned long long *n_kmers;           // count mode, sum over reads of max(0, len - k)
+    const unsigned long long *is_solid;    // stage-1 verdicts (bit num_k1_per_read*read + position), nullptr = every position solid
+    int num_k1_per_read;
+    uint64_t n_short;                      // reads >= n_short (assist sequences) are always solid (s2.cpp:276)
 };
 
 template <int W, bool WRITE>
@@ -132,6 +135,18 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
         for (int c0 = 0; c0 < npos; c0 += 64) {
             int p = c0 + lane;
             bool active = p < npos;
+            bool run_first = p == 0, run_last = p == npos - 1;
+            if (active && a.is_solid && r < a.n_short) {               // solid runs inside the read (s2.cpp:276,280,288)
+                auto sol = [&](int pp) {
+                    uint64_t bit = (uint64_t)a.num_k1_per_read * r + (uint64_t)pp;
+                    return (bool)((a.is_solid[bit >> 6] >> (bit & 63)) & 1);
+                };
+                active = sol(p);
+                if (active) {
+                    run_first = p == 0 || !sol(p - 1);
+                    run_last = p == npos - 1 || !sol(p + 1);
+                }
+            }
             Key<W> items[6];
             int cnt = 0;
             if (active) {
@@ -158,13 +173,13 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
                     uint32_t b = key.w[0] >> 16;                       // bucket = first 8 characters (s2.cpp:832)
                     if (b >= a.b_lo && b < a.b_hi) items[cnt++] = key;
                 };
-                if (p == 0) {                                          // left $  (s2.cpp:531-540)
+                if (run_first) {                                       // left $  (s2.cpp:531-540)
                     push(make_key<W>(e, 0, k, k, kDollar));
                     if (!pal) push(make_key<W>(rc, 2, k - 1, k, r1c));
                 }
                 push(make_key<W>(e, 1, k, k, e0));                     // solid   (s2.cpp:543-550)
                 if (!pal) push(make_key<W>(rc, 1, k, k, r0c));
-                if (p == npos - 1) {                                   // right $ (s2.cpp:553-562)
+                if (run_last) {                                        // right $ (s2.cpp:553-562)
                     push(make_key<W>(e, 2, k - 1, k, e1));
                     if (!pal) push(make_key<W>(rc, 0, k, k, kDollar));
                 }
@@ -817,6 +832,10 @@ __global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W>
     }
 }
 
+}  // namespace mgta
+#include "sdbg_solid.hpp"
+namespace mgta {
+
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
@@ -858,7 +877,7 @@ static std::vector<Digit> low_digit_plan(int k, int W, int P) {
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -876,9 +895,209 @@ static uint64_t pool_bytes(const mgta_ctx *ctx) {
     return t;
 }
 
+// Sort n keys of WT words ascending on the digits that matter: `max_top` leading bytes may be used for global passes;
+// low_plan_for(P) lists the remaining significant digits (least significant first).  Returns the buffer (a or b) that
+// holds the result, nullptr on an unsupported input (error set).
+template <int WT, class LowPlanFn>
+static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
+                            std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S) {
+    const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
+    uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
+    uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
+    Key<WT> *src = a, *dst = b;
+    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg) {
+        uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
+        hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, tiles, d_totals);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (scatter_ev) {
+            MGTA_HIP_CHECK(hipEventCreate(&e0));
+            MGTA_HIP_CHECK(hipEventCreate(&e1));
+            MGTA_HIP_CHECK(hipEventRecord(e0, stream));
+        }
+        hipLaunchKernelGGL((radix_scatter_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+                           d_totals);
+        if (scatter_ev) {
+            MGTA_HIP_CHECK(hipEventRecord(e1, stream));
+            scatter_ev->emplace_back(e0, e1);
+            if (S) S->n_sort_launches++;
+        }
+    };
+    // P: smallest number of leading bytes that leaves segments of ~<= 256 keys on average
+    int P = 0;
+    while (P < max_top && (double)n_items / std::pow(256.0, P) > 256.0) ++P;
+    if (ctx->force_full_lsd) P = 0;
+    for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(WT, i)); std::swap(src, dst); }
+    const std::vector<Digit> low = low_plan_for(P);
+    if (low.size() > 64) { set_error("too many sort digits"); return nullptr; }
+    Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
+    MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
+    const uint32_t big_cap = 1u << 16;
+    uint64_t *d_big = pool_get<uint64_t>(ctx, S_BIG, (2 * (uint64_t)big_cap + 2) * 8);
+    uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * big_cap);
+    MGTA_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 8, stream));
+    uint64_t l_blocks = (n_items + LocalCfg<WT>::kStride - 1) / LocalCfg<WT>::kStride;
+    hipEvent_t le0, le1;
+    MGTA_HIP_CHECK(hipEventCreate(&le0));
+    MGTA_HIP_CHECK(hipEventCreate(&le1));
+    MGTA_HIP_CHECK(hipEventRecord(le0, stream));
+    hipLaunchKernelGGL((local_sort_kernel<WT>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, P, d_plan, (int)low.size(),
+                       d_big, d_big_count, big_cap);
+    MGTA_HIP_CHECK(hipEventRecord(le1, stream));
+    uint32_t n_big = 0;
+    MGTA_HIP_CHECK(hipMemcpyAsync(&n_big, d_big_count, 4, hipMemcpyDeviceToHost, stream));
+    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+    {
+        float ms = 0;
+        MGTA_HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
+        if (S) S->ms_local_sort += ms;
+        (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
+    }
+    if (n_big > big_cap) { set_error("more than %u oversized key segments in one pass", big_cap); return nullptr; }
+    if (n_big > 0) {
+        // segments too long for LDS (hot k-mers, or the whole array when it is tiny): one workgroup each, global ping-pong
+        hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
+        hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
+                           (int)low.size());
+        if (S) S->n_big_segments += n_big;
+    }
+    return src;
+}
+
+// ---- stage 1 (min_count >= 2): fills the is_solid bit-vector (+ mercy edges) that stage 2 then honours -------------
 template <int W>
-static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucket_begin, uint32_t bucket_end, mgta_edge_sink sink,
-                      void *user, mgta_build_stats *st) {
+static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int k, int min_count, int need_mercy, uint64_t budget,
+                      unsigned long long **is_solid_out, int *num_k1_out, mgta_build_stats *S) {
+    constexpr int WT = W + 2;                                          // key words (= words_per_substring of s1, s1.cpp:248) + 64-bit payload
+    hipStream_t stream = ctx->stream;
+    const uint64_t n_reads = rd->n_reads;
+    const uint64_t n_blocks = (n_reads + kReadsPerBlock - 1) / kReadsPerBlock;
+    uint64_t *d_small = pool_get<uint64_t>(ctx, S_SMALL, 4096);
+    uint64_t *d_total = d_small;
+    unsigned int *d_maxlen = reinterpret_cast<unsigned int *>(d_small + 300);
+    unsigned long long *d_mercy_count = reinterpret_cast<unsigned long long *>(d_small + 302), *d_num_mercy = d_mercy_count + 1;
+    MGTA_HIP_CHECK(hipMemsetAsync(d_small + 300, 0, 64, stream));
+    if (n_short > n_reads) n_short = n_reads;
+    if (n_short) hipLaunchKernelGGL(max_len_kernel, dim3((unsigned)((n_short + 255) / 256)), dim3(256), 0, stream, rd->d_start, n_short, d_maxlen);
+    unsigned int max_len = 0;
+    MGTA_HIP_CHECK(hipMemcpyAsync(&max_len, d_maxlen, 4, hipMemcpyDeviceToHost, stream));
+    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (need_mercy && (int)max_len > kMercyMaxLen) {
+        set_error("mercy edges: reads longer than %d bases (%u) are not supported", kMercyMaxLen, max_len);
+        return MGTA_EUNSUPPORTED;
+    }
+    const int num_k1 = std::max<int>(0, (int)max_len - k);                 // num_k1_per_read, s1.cpp:152
+    const uint64_t n_bits = (uint64_t)num_k1 * n_short;
+    unsigned long long *d_solid = pool_get<unsigned long long>(ctx, S_SOLID, (n_bits / 64 + 2) * 8);
+    MGTA_HIP_CHECK(hipMemsetAsync(d_solid, 0, (n_bits / 64 + 2) * 8, stream));
+    unsigned long long *d_edge_count = pool_get<unsigned long long>(ctx, S_EDGE_COUNT, 65536 * 8);
+    MGTA_HIP_CHECK(hipMemsetAsync(d_edge_count, 0, 65536 * 8, stream));
+    uint32_t *d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
+    uint64_t *d_block_base = pool_get<uint64_t>(ctx, S_BLOCK_BASE, std::max<uint64_t>(1, n_blocks) * 8);
+
+    S1Args sa;
+    sa.packed = rd->d_packed; sa.n_words = rd->n_words; sa.start = rd->d_start; sa.n_reads = n_reads; sa.k = k;
+    sa.block_count = d_block_count; sa.block_base = d_block_base; sa.out = nullptr;
+    Key<2> *d_mercy = nullptr;
+    uint64_t mercy_cap = 0;
+    int n_pass = 1;
+    uint32_t b_lo = 0;
+    while (b_lo < MGTA_NUM_BUCKETS) {
+        uint32_t width = (MGTA_NUM_BUCKETS + n_pass - 1) / n_pass;
+        uint32_t b_hi = std::min<uint32_t>(MGTA_NUM_BUCKETS, b_lo + width);
+        sa.b_lo = b_lo; sa.b_hi = b_hi;
+        uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
+        if (n_blocks) hipLaunchKernelGGL((s1_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+        exclusive_scan_u32(stream, d_block_count, n_blocks, d_block_base, d_scan_tmp, d_total);
+        uint64_t n_items = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+        uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
+        uint64_t need = 2 * n_items * sizeof(Key<WT>) + n_tiles * 256 * 8 + (need_mercy ? n_items * 8 : 0) + (8u << 20);
+        uint64_t other = ctx->live_bytes - pool_bytes(ctx);
+        if (need + need / 8 > budget - std::min<uint64_t>(budget, other) && width > 1) { n_pass *= 2; continue; }
+        if (n_items > 0) {
+            Key<WT> *d_a = pool_get<Key<WT>>(ctx, S_KEYS_A, n_items * sizeof(Key<WT>));
+            Key<WT> *d_b = pool_get<Key<WT>>(ctx, S_KEYS_B, n_items * sizeof(Key<WT>));
+            if (need_mercy && (!d_mercy || mercy_cap < 2 * n_items)) {
+                // a candidate list that only grows: keep what earlier passes appended
+                uint64_t have = 0;
+                MGTA_HIP_CHECK(hipMemcpy(&have, d_mercy_count, 8, hipMemcpyDeviceToHost));
+                uint64_t new_cap = have + 2 * n_items;
+                DevBuf keep;
+                if (have) { keep.alloc(have * 8); MGTA_HIP_CHECK(hipMemcpy(keep.p, d_mercy, have * 8, hipMemcpyDeviceToDevice)); }
+                d_mercy = pool_get<Key<2>>(ctx, S_MERCY, new_cap * 8);
+                if (have) MGTA_HIP_CHECK(hipMemcpy(d_mercy, keep.p, have * 8, hipMemcpyDeviceToDevice));
+                mercy_cap = new_cap;
+            }
+            sa.out = d_a;
+            hipLaunchKernelGGL((s1_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+            // sort on: key characters + head/tail (key words), then prev/next (low 6 bits of the payload); positions are ignored
+            const int pad1 = 32 * W - 2 * (k - 1) - 6;
+            auto low_plan = [&](int P) {
+                std::vector<Digit> plan;
+                int top = 32 * WT - 8 * P;
+                plan.push_back(Digit{0, 6});
+                if (top > 64) plan.push_back(Digit{64, std::min(6, top - 64)});
+                for (int pos = 64 + 6 + pad1; pos < top; pos += 8) plan.push_back(Digit{pos, std::min(8, top - pos)});
+                return plan;
+            };
+            const int max_top = std::min(4, std::max(0, (2 * (k - 1)) / 8));
+            Key<WT> *sorted = device_sort<WT>(ctx, stream, d_a, d_b, n_items, max_top, low_plan, nullptr, nullptr);
+            if (!sorted) return MGTA_EUNSUPPORTED;
+            char *scratch = reinterpret_cast<char *>(sorted == d_a ? d_b : d_a);
+            uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
+            uint32_t *d_tile_heads = pool_get<uint32_t>(ctx, S_TILE_HEADS, e_tiles * 4);
+            uint64_t *d_tile_base = pool_get<uint64_t>(ctx, S_TILE_BASE, e_tiles * 8);
+            d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, e_tiles)) * 8);
+            hipLaunchKernelGGL((s1_mark_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, d_tile_heads);
+            exclusive_scan_u32(stream, d_tile_heads, e_tiles, d_tile_base, d_scan_tmp, d_total);
+            uint64_t m = 0;
+            MGTA_HIP_CHECK(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            uint64_t *run_start = reinterpret_cast<uint64_t *>(scratch);               // 12 bytes per run <= sizeof(Key<WT>) per key
+            uint16_t *run_info = reinterpret_cast<uint16_t *>(scratch + m * 8);
+            uint16_t *group_mask = reinterpret_cast<uint16_t *>(scratch + m * 10);
+            hipLaunchKernelGGL((s1_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k, d_tile_base,
+                               run_start, run_info);
+            unsigned rb = (unsigned)((m + 255) / 256);
+            hipLaunchKernelGGL(s1_group_kernel, dim3(rb), dim3(256), 0, stream, run_start, run_info, m, n_items, min_count, group_mask);
+            hipLaunchKernelGGL((s1_apply_kernel<W>), dim3(rb), dim3(256), 0, stream, sorted, run_start, run_info, group_mask, m, n_items, min_count,
+                               k, rd->d_start, n_reads, n_short, num_k1, d_solid, d_edge_count, d_mercy, d_mercy_count, mercy_cap, need_mercy);
+        }
+        b_lo = b_hi;
+    }
+    // .counting histogram (s1_post_proc, s1.cpp:905-930)
+    ctx->edge_counting.assign(65536, 0);
+    MGTA_HIP_CHECK(hipMemcpyAsync(ctx->edge_counting.data(), d_edge_count, 65536 * 8, hipMemcpyDeviceToHost, stream));
+    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (need_mercy) {
+        uint64_t n_cand = 0;
+        MGTA_HIP_CHECK(hipMemcpy(&n_cand, d_mercy_count, 8, hipMemcpyDeviceToHost));
+        if (n_cand > mercy_cap) { set_error("mercy candidate list overflow"); return MGTA_ENOMEM; }
+        if (n_cand > 0) {
+            Key<2> *d_tmp = pool_get<Key<2>>(ctx, S_KEYS_A, n_cand * 8);
+            auto low64 = [&](int P) {
+                std::vector<Digit> plan;
+                for (int pos = 0; pos < 64 - 8 * P; pos += 8) plan.push_back(Digit{pos, std::min(8, 64 - 8 * P - pos)});
+                return plan;
+            };
+            Key<2> *cs = device_sort<2>(ctx, stream, d_mercy, d_tmp, n_cand, 4, low64, nullptr, nullptr);
+            if (!cs) return MGTA_EUNSUPPORTED;
+            hipLaunchKernelGGL(mercy_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, stream, cs, n_cand, rd->d_start, n_reads, k, num_k1,
+                               d_solid, d_num_mercy);
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+    }
+    (void)S;
+    *is_solid_out = d_solid;
+    *num_k1_out = num_k1;
+    return MGTA_OK;
+}
+
+template <int W>
+static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int k, int min_count, int need_mercy, uint32_t bucket_begin,
+                      uint32_t bucket_end, mgta_edge_sink sink, void *user, mgta_build_stats *st) {
     hipStream_t stream = ctx->stream;
     MGTA_HIP_CHECK(hipSetDevice(ctx->device));
     const int words_per_tip = (2 * k + 31) / 32;                       // sdbg_multi_io.h:63
@@ -901,12 +1120,26 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucke
     uint32_t *d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
     uint64_t *d_block_base = pool_get<uint64_t>(ctx, S_BLOCK_BASE, std::max<uint64_t>(1, n_blocks) * 8);
     uint64_t *d_small = pool_get<uint64_t>(ctx, S_SMALL, 4096);       // [0] total, [1] kmers, [2..4] emit totals, [8..263] digit totals
-    uint64_t *d_total = d_small, *d_kmers = d_small + 1, *d_tot3 = d_small + 2, *d_totals = d_small + 8;
+    uint64_t *d_total = d_small, *d_kmers = d_small + 1, *d_tot3 = d_small + 2;
 
     ScanArgs sa;
     sa.packed = rd->d_packed; sa.n_words = rd->n_words; sa.start = rd->d_start; sa.n_reads = n_reads; sa.k = k;
     sa.block_count = d_block_count; sa.block_base = d_block_base; sa.out = nullptr;
     sa.n_kmers = (unsigned long long *)d_kmers;
+    sa.is_solid = nullptr; sa.num_k1_per_read = 0; sa.n_short = n_short;
+    if (min_count > 1) {
+        unsigned long long *sol = nullptr;
+        int nk1 = 0;
+        int rc1 = MGTA_EUNSUPPORTED;
+        if constexpr (W <= 7) rc1 = run_stage1<W>(ctx, rd, n_short, k, min_count, need_mercy, budget, &sol, &nk1, &S);
+        else set_error("min_count > 1 with k > 110 is not supported (sort record of %d words)", W + 2);
+        if (rc1 != MGTA_OK) return rc1;
+        sa.is_solid = sol; sa.num_k1_per_read = nk1;
+        // run_stage1 may have re-grown pool slots: refresh the small pointers
+        d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
+        d_block_base = pool_get<uint64_t>(ctx, S_BLOCK_BASE, std::max<uint64_t>(1, n_blocks) * 8);
+        sa.block_count = d_block_count; sa.block_base = d_block_base;
+    }
 
     t_all.start();
     const std::vector<Digit> plan = digit_plan(k, W);
@@ -956,7 +1189,6 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucke
         if (n_items > 0) {
             Key<W> *d_a = pool_get<Key<W>>(ctx, S_KEYS_A, n_items * sizeof(Key<W>));
             Key<W> *d_b = pool_get<Key<W>>(ctx, S_KEYS_B, key_b);
-            uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, n_tiles * 256 * 8);
             // ---- 3. write keys
             t_ph.start();
             sa.out = d_a;
@@ -964,68 +1196,10 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, int k, uint32_t bucke
             S.ms_gen += t_ph.stop();
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
-            Key<W> *src = d_a, *dst = d_b;
-            auto global_pass = [&](Key<W> *from, Key<W> *to, uint64_t cnt, const Digit &dg, bool timed) {
-                uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
-                hipLaunchKernelGGL((radix_census_kernel<W>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
-                hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, tiles, d_totals);
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (timed) {
-                    MGTA_HIP_CHECK(hipEventCreate(&e0));
-                    MGTA_HIP_CHECK(hipEventCreate(&e1));
-                    MGTA_HIP_CHECK(hipEventRecord(e0, stream));
-                }
-                hipLaunchKernelGGL((radix_scatter_kernel<W>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles,
-                                   d_hist, d_totals);
-                if (timed) {
-                    MGTA_HIP_CHECK(hipEventRecord(e1, stream));
-                    scatter_ev.emplace_back(e0, e1);
-                    S.n_sort_launches++;
-                }
-            };
-            // P: smallest number of leading bytes that leaves segments of ~<= 256 keys on average
             const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
-            int P = 0;
-            while (P < max_top && (double)n_items / std::pow(256.0, P) > 256.0) ++P;
-            if (ctx->force_full_lsd) P = 0;
-            for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(W, i), true); std::swap(src, dst); }
-            const std::vector<Digit> low = low_digit_plan(k, W, P);
-            Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
-            MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
-            const uint32_t big_cap = 1u << 16;
-            uint64_t *d_big = pool_get<uint64_t>(ctx, S_BIG, (2 * (uint64_t)big_cap + 2) * 8);
-            uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * big_cap);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 8, stream));
-            uint64_t l_blocks = (n_items + LocalCfg<W>::kStride - 1) / LocalCfg<W>::kStride;
-            hipEvent_t le0, le1;
-            MGTA_HIP_CHECK(hipEventCreate(&le0));
-            MGTA_HIP_CHECK(hipEventCreate(&le1));
-            MGTA_HIP_CHECK(hipEventRecord(le0, stream));
-            hipLaunchKernelGGL((local_sort_kernel<W>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, P, d_plan,
-                               (int)low.size(), d_big, d_big_count, big_cap);
-            MGTA_HIP_CHECK(hipEventRecord(le1, stream));
-            uint32_t n_big = 0;
-            MGTA_HIP_CHECK(hipMemcpyAsync(&n_big, d_big_count, 4, hipMemcpyDeviceToHost, stream));
-            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
-            {
-                float ms = 0;
-                MGTA_HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
-                S.ms_local_sort += ms;
-                (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
-            }
-            if (n_big > big_cap) { set_error("more than %u oversized key segments in one pass", big_cap); return MGTA_EUNSUPPORTED; }
-            if (n_big > 0) {
-                // segments too long for LDS (hot k-mers, or the whole array when it is tiny): finish each with global passes
-                std::vector<uint64_t> h_big(n_big), h_end(n_big);
-                hipLaunchKernelGGL((segment_end_kernel<W>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
-                MGTA_HIP_CHECK(hipMemcpyAsync(h_big.data(), d_big, n_big * 8, hipMemcpyDeviceToHost, stream));
-                MGTA_HIP_CHECK(hipMemcpyAsync(h_end.data(), d_big + big_cap, n_big * 8, hipMemcpyDeviceToHost, stream));
-                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
-                (void)h_big; (void)h_end;
-                hipLaunchKernelGGL((segment_sort_kernel<W>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
-                                   (int)low.size());
-                S.n_big_segments += n_big;
-            }
+            Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int P) { return low_digit_plan(k, W, P); }, &scatter_ev, &S);
+            if (!src) return MGTA_EUNSUPPORTED;
+            Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();
             // ---- 5. emit.  `src` holds the sorted keys; the other buffer is scratch.
             t_ph.start();
@@ -1156,31 +1330,37 @@ void mgta_reads_free(mgta_reads *r) {
 
 int mgta_sdbg_build_resident(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short_reads, int k, int min_count, int need_mercy,
                              int32_t bucket_begin, int32_t bucket_end, mgta_edge_sink sink, void *user, mgta_build_stats *stats) {
-    (void)n_short_reads;   // with min_count == 1 every position of every sequence is solid (s2.cpp:276)
     if (!ctx || !rd) { set_error("mgta_sdbg_build: null argument"); return MGTA_EINVAL; }
     if (k < 9 || k > 127) { set_error("k=%d out of range [9,127] (kMaxK, definitions.h:56)", k); return MGTA_EINVAL; }
     if (bucket_begin < 0 || bucket_end > MGTA_NUM_BUCKETS || bucket_begin >= bucket_end) {
         set_error("bucket range [%d,%d) invalid", bucket_begin, bucket_end);
         return MGTA_EINVAL;
     }
-    if (min_count != 1) {   // need_mercy only acts when min_count > 1 (s2_read_mercy_prepare, cx1_read2sdbg_s2.cpp:106-107)
-        set_error("min_count=%d need_mercy=%d: stage 1 (solid-edge counting, cx1_read2sdbg_s1.cpp) is not built yet", min_count, need_mercy);
-        return MGTA_EUNSUPPORTED;
+    if (min_count < 1) { set_error("min_count must be >= 1"); return MGTA_EINVAL; }
+    if (min_count > 1 && (bucket_begin != 0 || bucket_end != MGTA_NUM_BUCKETS) ) {
+        // stage 1 always covers every bucket (its verdicts feed every stage-2 bucket); a stage-2 shard is fine
     }
     try {
         int W = (2 * k + 4 + 31) / 32;                                 // words_per_substring, s2.cpp:331
         switch (W) {
-        case 1: return build_impl<1>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 2: return build_impl<2>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 3: return build_impl<3>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 4: return build_impl<4>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 5: return build_impl<5>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 6: return build_impl<6>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 7: return build_impl<7>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        case 8: return build_impl<8>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
-        default: return build_impl<9>(ctx, rd, k, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 1: return build_impl<1>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 2: return build_impl<2>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 3: return build_impl<3>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 4: return build_impl<4>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 5: return build_impl<5>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 6: return build_impl<6>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 7: return build_impl<7>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        case 8: return build_impl<8>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
+        default: return build_impl<9>(ctx, rd, n_short_reads, k, min_count, need_mercy, (uint32_t)bucket_begin, (uint32_t)bucket_end, sink, user, stats);
         }
     } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_last_counting(mgta_ctx *ctx, int64_t *hist) {
+    if (!ctx || !hist) { set_error("mgta_sdbg_last_counting: null argument"); return MGTA_EINVAL; }
+    if (ctx->edge_counting.size() != 65536) { set_error("no stage-1 run (min_count > 1) on this context yet"); return MGTA_EINVAL; }
+    std::copy(ctx->edge_counting.begin(), ctx->edge_counting.end(), hist);
+    return MGTA_OK;
 }
 
 int mgta_sdbg_export_records_device(mgta_ctx *ctx, void *d_dst, uint64_t capacity_bytes, uint64_t *n_records) {

@@ -41,9 +41,9 @@ def gz_write(path, data: bytes):
         f.write(data)
 
 
-def buildgraph(lib, prefix, k, extra=()):
+def buildgraph(lib, prefix, k, extra=(), m=1):
     os.makedirs(os.path.dirname(prefix), exist_ok=True)
-    run([f"{REF}/megagta", "buildgraph", "-k", str(k), "-m", "1", "--host_mem", "4000000000", "--mem_flag", "1",
+    run([f"{REF}/megagta", "buildgraph", "-k", str(k), "-m", str(m), "--host_mem", "4000000000", "--mem_flag", "1",
          "--gpu_mem", "0", "--output_prefix", prefix, "--num_cpu_threads", "4", "--num_output_threads", "1",
          "--read_lib_file", lib, *extra])
 
@@ -77,6 +77,16 @@ def main():
         buildgraph(f"{tmp}/reads.lib", f"{tmp}/k{k}/{k}", k)
         streams[str(k)] = stream_fixture(f"{tmp}/k{k}/{k}")
     json.dump(streams, open(f"{toy}/sdbg_streams.json", "w"), indent=0)
+    # stage 1 (solid-edge counting, -m >= 2) with and without mercy edges (cx1_read2sdbg_s1.cpp, s2.cpp:106-250)
+    solid = {}
+    for k, m, mercy in ((29, 2, False), (29, 2, True), (44, 2, False), (44, 2, True), (44, 3, True), (35, 4, True)):
+        tag = f"k{k}_m{m}_{'mercy' if mercy else 'nomercy'}"
+        buildgraph(f"{tmp}/reads.lib", f"{tmp}/s1_{tag}/{k}", k, extra=(("--need_mercy",) if mercy else ()), m=m)
+        fx = stream_fixture(f"{tmp}/s1_{tag}/{k}")
+        fx["counting_md5"] = hashlib.md5(open(f"{tmp}/s1_{tag}/{k}.counting", "rb").read()).hexdigest()
+        fx["counting_head"] = open(f"{tmp}/s1_{tag}/{k}.counting").read().splitlines()[:40]
+        solid[tag] = fx
+    json.dump(solid, open(f"{toy}/sdbg_streams_solid.json", "w"), indent=0)
     # parsed HMM tables + heuristic
     for tag in ("for", "rev"):
         gz_write(f"{toy}/hmm_{tag}.txt.gz", run([f"{REF}/probe", "hmm", f"{toy}/{tag}_enone.hmm"]).stdout)
@@ -141,6 +151,18 @@ def main():
         buildgraph(f"{tmp}/ragged.lib", f"{tmp}/rk{k}/{k}", k)
         streams[str(k)] = stream_fixture(f"{tmp}/rk{k}/{k}")
     json.dump(streams, open(f"{rag}/sdbg_streams.json", "w"), indent=0)
+    solid = {}
+    for k, m, mercy in ((21, 2, True), (29, 2, True), (31, 3, False), (47, 2, False), (47, 2, True)):
+        tag = f"k{k}_m{m}_{'mercy' if mercy else 'nomercy'}"
+        try:
+            buildgraph(f"{tmp}/ragged.lib", f"{tmp}/rs1_{tag}/{k}", k, extra=(("--need_mercy",) if mercy else ()), m=m)
+        except subprocess.CalledProcessError as e:      # the reference itself crashes on some ragged inputs with mercy edges
+            solid[tag] = {"reference_crashed": True, "returncode": e.returncode}
+            continue
+        fx = stream_fixture(f"{tmp}/rs1_{tag}/{k}")
+        fx["counting_md5"] = hashlib.md5(open(f"{tmp}/rs1_{tag}/{k}.counting", "rb").read()).hexdigest()
+        solid[tag] = fx
+    json.dump(solid, open(f"{rag}/sdbg_streams_solid.json", "w"), indent=0)
     # the reference loader's own view of two of these graphs (bit-vector digests + navigation answers):
     # pins the .sdbg/.sdbg_info decoder independently of the oracle's reader
     for k in (29, 47):

@@ -95,3 +95,21 @@ def test_error_behaviour():
     assert r.returncode == 1 and "Usage" in r.stderr                                   # search.cpp:72-75
     r = subprocess.run([BIN, "denovo"], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def test_buildgraph_min_count_2_with_mercy_matches_reference_binary(toy_inputs, oracle):
+    """`megagta buildgraph -m 2 --need_mercy` (what the driver issues for `-c 2`): our .sdbg files and .counting == the reference's"""
+    _need()
+    d = toy_inputs
+    w = d / "m2"
+    w.mkdir()
+    (w / "reads.lib").write_text(f"reads.fa\nse {d / 'reads.fa'}\n")
+    run = lambda cmd: subprocess.run(cmd, check=True, capture_output=True)
+    run([REF, "buildlib", str(w / "reads.lib"), str(w / "reads.lib")])
+    common = ["-k", "44", "-m", "2", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4",
+              "--num_output_threads", "1", "--read_lib_file", str(w / "reads.lib"), "--need_mercy"]
+    run([BIN, "buildgraph", "--output_prefix", str(w / "ours")] + common)
+    run([REF, "buildgraph", "--output_prefix", str(w / "ref")] + common)
+    a, b = oracle.Stream.read(str(w / "ours")).edges(), oracle.Stream.read(str(w / "ref")).edges()
+    assert a.md5() == b.md5() and a.records.size > 0
+    assert (w / "ours.counting").read_text() == (w / "ref.counting").read_text()

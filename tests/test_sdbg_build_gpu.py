@@ -117,13 +117,13 @@ def test_larger_synthetic_properties(ctx, oracle):
     assert (((g.records >> 4) & 1)[tip] == 0).all()
 
 
-def test_no_device_path_is_loud():
-    """min_count > 1 is not built yet: must fail loudly, never fall back"""
+def test_unsupported_is_loud():
+    """what is not supported fails loudly, never falls back: k out of range"""
     from megagta_amd import api
     c = api.Context(0)
     rd = c.upload_reads(np.zeros(4, np.uint32), np.array([0, 60], np.uint64))
     with pytest.raises(api.MegaGtaError):
-        c.build_sdbg(rd, 29, min_count=2)
+        c.build_sdbg(rd, 200)
     c.close()
 
 
@@ -143,3 +143,33 @@ def test_device_export_matches_host_collect(ctx, golden_dir):
         assert g.bucket_items[:b0].sum() == 0 and g.bucket_items[b1:].sum() == 0
         parts.append(g.records)
     assert np.array_equal(np.concatenate(parts), whole.records)
+
+
+def _solid_cases(golden_dir, sub):
+    d = json.load(open(os.path.join(golden_dir, sub, "sdbg_streams_solid.json")))
+    out = []
+    for tag, fx in d.items():
+        k, m, mercy = int(tag.split("_")[0][1:]), int(tag.split("_")[1][1:]), tag.endswith("_mercy")
+        out.append((tag, k, m, mercy, fx))
+    return out
+
+
+@pytest.mark.parametrize("sub", ["toy", "ragged"])
+def test_min_count_and_mercy_vs_reference(ctx, golden_dir, sub):
+    """-m >= 2: stage-1 solid-edge counting (+ mercy edges) then stage 2 == the reference's buildgraph -m M [--need_mercy]:
+    edge stream bit-exact and the .counting histogram identical"""
+    import hashlib
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, sub, "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    ran = 0
+    for tag, k, m, mercy, fx in _solid_cases(golden_dir, sub):
+        if fx.get("reference_crashed"):
+            continue                                         # the reference itself segfaults on this input (recorded in the fixture)
+        g = ctx.build_sdbg(rd, k, min_count=m, need_mercy=mercy)
+        assert int(g.records.size) == fx["num_edges"], tag
+        assert [int(x) for x in g.records[:256]] == fx["head_records"], tag
+        assert g.md5() == fx["md5"], tag
+        assert hashlib.md5(api.counting_text(ctx.last_counting()).encode()).hexdigest() == fx["counting_md5"], tag
+        ran += 1
+    assert ran >= 4
