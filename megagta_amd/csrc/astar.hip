@@ -781,7 +781,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         std::vector<int64_t> todo[2];
         for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
         std::vector<int32_t> h_status((size_t)n * 2);
-        uint32_t cap_nodes = 1u << 14;
+        uint32_t cap_nodes = 1u << 17;                                              // cold: searches that still overflow are re-run with 8x
         // warm modes: seeds must run in order in ONE launch (no re-runs), so the arenas are sized generously up front
         DevBuf d_cache[2], d_frontier, d_committed;
         a.window = cache_mode;
@@ -814,13 +814,20 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             blocks = std::max(2, blocks + (blocks & 1));
             uint64_t slots = (uint64_t)blocks * kAstarWaves;
             uint32_t cap_hash = cap_nodes * 2;
-            DevBuf d_nodes, d_heap, d_hash, d_tag;
-            d_nodes.alloc(slots * cap_nodes * sizeof(ANode), &ctx->live_bytes, &ctx->peak_bytes);
-            d_heap.alloc(slots * cap_nodes * sizeof(HeapEnt), &ctx->live_bytes, &ctx->peak_bytes);
-            d_hash.alloc(slots * cap_hash * sizeof(HashEnt), &ctx->live_bytes, &ctx->peak_bytes);
-            d_tag.alloc(slots * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_hash.p, 0, slots * cap_hash * sizeof(HashEnt), st));
-            MGTA_HIP_CHECK(hipMemsetAsync(d_tag.p, 0, slots * 4, st));
+            // per-search arenas live in the context between calls: hash entries are tag-versioned and the tag counters
+            // persist, so a re-used arena needs neither clearing nor re-allocation (only a geometry change does)
+            AstarArenas &ar = ctx->astar;
+            if (ar.slots != slots || ar.cap_nodes != cap_nodes || !ar.nodes.p) {
+                ar.nodes.release(); ar.heap.release(); ar.hash.release(); ar.tag.release();
+                ar.nodes.alloc(slots * cap_nodes * sizeof(ANode), &ctx->live_bytes, &ctx->peak_bytes);
+                ar.heap.alloc(slots * cap_nodes * sizeof(HeapEnt), &ctx->live_bytes, &ctx->peak_bytes);
+                ar.hash.alloc(slots * cap_hash * sizeof(HashEnt), &ctx->live_bytes, &ctx->peak_bytes);
+                ar.tag.alloc(slots * 4, &ctx->live_bytes, &ctx->peak_bytes);
+                MGTA_HIP_CHECK(hipMemsetAsync(ar.hash.p, 0, slots * cap_hash * sizeof(HashEnt), st));
+                MGTA_HIP_CHECK(hipMemsetAsync(ar.tag.p, 0, slots * 4, st));
+                ar.slots = slots; ar.cap_nodes = cap_nodes;
+            }
+            DevBuf &d_nodes = ar.nodes, &d_heap = ar.heap, &d_hash = ar.hash, &d_tag = ar.tag;
             MGTA_HIP_CHECK(hipMemsetAsync(d_queue.p, 0, 16, st));
             for (int d = 0; d < 2; ++d) {
                 d_todo[d].alloc(std::max<size_t>(1, todo[d].size()) * 8);

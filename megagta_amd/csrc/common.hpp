@@ -58,6 +58,14 @@ struct DevBuf {
 
 }  // namespace mgta
 
+namespace mgta {
+struct AstarArenas {           // grow-by-replacement A* work memory kept between mgta_astar_batch calls
+    DevBuf nodes, heap, hash, tag;
+    uint64_t slots = 0;
+    uint32_t cap_nodes = 0;
+};
+}  // namespace mgta
+
 struct mgta_ctx {
     int refs = 1;                 // the handle itself + every reads / graph / hmm object created from it
     int device = 0;
@@ -68,6 +76,7 @@ struct mgta_ctx {
     int num_cus = 256;
     hipDeviceProp_t prop;
     std::vector<mgta::DevBuf> pool;   // grow-only scratch kept between calls
+    mgta::AstarArenas astar;
     std::vector<int64_t> edge_counting;   // (k+1)-mer multiplicity histogram of the last stage-1 run (.counting)
     const void *last_rec = nullptr;   // records of the last build pass, still resident in the pool
     uint64_t last_n_rec = 0;

@@ -171,7 +171,10 @@ static int main_search(int argc, char **argv) {
     }
     int prune = atoi(argv[5]);
     double pen = atof(argv[6]);
-    // argv[7] (num_threads) is accepted and ignored: the batch runs on the device
+    // argv[7] (num_threads) is accepted and ignored: the batch runs on the device.  The shared term_nodes cache (search.cpp:182)
+    // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
+    int cache_window = 4096;
+    if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
     double t0 = now_s();
     logf("Loading SdBG...");
     EdgeStream s;
@@ -209,7 +212,7 @@ static int main_search(int argc, char **argv) {
         }
         FastaOut fo{out, &gene.name, &kmers};
         mgta_astar_stats st;
-        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, 0, sink_contig, &fo, &st) != MGTA_OK)
+        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, cache_window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
