@@ -37,7 +37,7 @@ struct mgta_hmm {
 
 namespace mgta {
 
-constexpr int kAstarWaves = 8;
+constexpr int kAstarWaves = 12;
 constexpr int kAstarThreads = kAstarWaves * 64;
 constexpr uint32_t kNone = 0x7FFFFFFFu;
 constexpr int kMaxKmer = 160;
@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 // The sift sequences are libstdc++'s (bits/stl_heap.h __push_heap / __adjust_heap) so nodes of equal priority leave
 // the list in the reference's order; they are executed by the whole wave: a pop prefetches five levels of the subtree
 // under the hole with 62 lanes (one memory round trip per five levels), a push loads every ancestor at once.
-constexpr uint32_t kLdsHeap = 511;
+constexpr uint32_t kLdsHeap = 255;
 
 __device__ __forceinline__ uint64_t ent_prio(const HeapEnt &e) {   // AStarNode::operator< (a_star_node.h:34-82) as one integer
     int st = (int)(e.key & 3) - 1;
