@@ -213,9 +213,9 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
 // ---------------------------------------------------------------------------------------------
 // 4. LSD radix sort (8-bit digits)
 // ---------------------------------------------------------------------------------------------
-constexpr int kSortThreads = 512;                    // 8 waves
+constexpr int kSortThreads = 1024;                   // 16 waves
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kItemsPerThread = 8;
+constexpr int kItemsPerThread = 4;
 constexpr int kSubTile = kSortThreads * kItemsPerThread;   // 4096 keys staged in LDS at a time
 constexpr int kSubTilesPerBlock = 8;
 constexpr int kBlockTile = kSubTile * kSubTilesPerBlock;   // 32768 keys per workgroup
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uin
 template <int W>
 struct ScatterShared {
     Key<W> keys[kSubTile];
-    uint32_t whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile
+    uint16_t whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile (<= kSubTile: 16 bits)
     uint32_t start[256];               // first position of each digit value inside the sorted sub-tile
     uint32_t total[256];
     uint64_t gbase[256];               // global destination of the next key of each digit value
@@ -301,7 +301,7 @@ template <int W>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const uint64_t ltmask = lanemask_lt();
-    volatile uint32_t *whist = &sh.whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
+    volatile uint16_t *whist = &sh.whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
     for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
     __syncthreads();
     for (uint64_t sub_base = 0; sub_base < n; sub_base += kSubTile) {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
             uint32_t prev = 0;
             if (valid) {
                 prev = whist[wv * 256 + dg];
-                if (rank == cnt - 1) whist[wv * 256 + dg] = prev + cnt;   // highest peer lane publishes the new count
+                if (rank == cnt - 1) whist[wv * 256 + dg] = (uint16_t)(prev + cnt);   // highest peer lane publishes the new count
             }
             dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
         }
@@ -340,7 +340,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 #pragma unroll
             for (int w = 0; w < kSortWaves; ++w) {
                 uint32_t c = sh.whist[w][tid];
-                sh.whist[w][tid] = tot;
+                sh.whist[w][tid] = (uint16_t)tot;
                 tot += c;
             }
             sh.total[tid] = tot;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, 
     constexpr uint32_t kLocalStride = LocalCfg<W>::kStride;
     __shared__ Key<W> s_keys[kTile];
     __shared__ uint16_t s_seg[kTile];
-    __shared__ uint32_t s_whist[kSortWaves][256];
+    __shared__ uint16_t s_whist[kSortWaves][256];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_scratch[kSortThreads / 64 + 1];
     __shared__ unsigned long long s_first, s_lasthead, s_end;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, 
     const int n_seg_pass = nseg <= 1 ? 0 : (nseg <= 256 ? 1 : 2);
 
     // 4. LSD passes: the low key digits, then the segment rank
-    volatile uint32_t *whist = &s_whist[0][0];
+    volatile uint16_t *whist = &s_whist[0][0];
     for (int pass = 0; pass < n_low + n_seg_pass; ++pass) {
         for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
         __syncthreads();
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, 
             uint32_t rank = (uint32_t)__popcll(peers & ltmask), cnt = (uint32_t)__popcll(peers), prev = 0;
             if (valid) {
                 prev = whist[wv * 256 + dg];
-                if (rank == cnt - 1) whist[wv * 256 + dg] = prev + cnt;
+                if (rank == cnt - 1) whist[wv * 256 + dg] = (uint16_t)(prev + cnt);
             }
             dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
         }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, 
         uint32_t tot = 0;
         if (tid < 256) {
 #pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = tot; tot += c; }
+            for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = (uint16_t)tot; tot += c; }
         }
         uint32_t ex = block_excl_scan<kSortThreads>(tot, s_scratch, nullptr);
         if (tid < 256) s_start[tid] = ex;
