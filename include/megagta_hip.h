@@ -43,7 +43,9 @@ mgta_ctx *mgta_ctx_create(int device_id);            /* NULL on failure (see mgt
 void mgta_ctx_destroy(mgta_ctx *);
 /* memory the build may use on the device; 0 = 90 % of what is free (cf. --host_mem/--mem_flag, build_graph.cpp:40-47) */
 int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
-/* diagnostic switch: 1 = sort every key with global LSD passes only (the round-1 path; also the fallback for oversized segments) */
+/* diagnostic switch (bit mask): 1 = sort every key with global LSD passes only (also the fallback for oversized segments);
+ * 2 = the segment-local sort runs LSD passes over every remaining digit instead of finishing short runs by comparison
+ *     (also the fallback for tiles whose runs are long) */
 int mgta_ctx_set_full_lsd(mgta_ctx *, int on);
 
 /* ------------------------------------------------------------------------------------------------
@@ -72,7 +74,8 @@ typedef struct mgta_build_stats {
     double ms_count, ms_gen, ms_sort, ms_emit, ms_d2h;
     double ms_sort_scatter;          /* summed duration of the radix scatter launches (HIP events) */
     double ms_local_sort;            /* duration of the segment-local (LDS) finishing sort */
-    int64_t n_big_segments;          /* key segments too long for LDS, finished by global passes */
+    int64_t n_big_segments;          /* key segments deferred by the tiled LDS sort (sorted alone in LDS, or by global passes) */
+    int64_t n_lsd_tiles;             /* LDS tiles whose runs were too long to finish by comparison (LSD passes over every digit) */
     uint64_t bytes_peak;             /* device bytes allocated at the peak */
 } mgta_build_stats;
 

@@ -58,8 +58,8 @@ class Context:
 
     __del__ = close
 
-    def set_full_lsd(self, on: bool):
-        """diagnostic: sort with global LSD passes only (no segment-local LDS finish)"""
+    def set_full_lsd(self, on: int):
+        """diagnostic bit mask: 1 = global LSD passes only (no segment-local LDS finish); 2 = LDS finish by LSD passes only (no comparison route)"""
         check(self._L.mgta_ctx_set_full_lsd(self.h, int(on)), "mgta_ctx_set_full_lsd")
 
     def last_counting(self) -> np.ndarray:

@@ -50,7 +50,8 @@ void mgta_ctx_destroy(mgta_ctx *ctx) {
 
 int mgta_ctx_set_full_lsd(mgta_ctx *ctx, int on) {
     if (!ctx) return MGTA_EINVAL;
-    ctx->force_full_lsd = on;
+    ctx->force_full_lsd = on & 1;
+    ctx->force_lsd_tiles = on >> 1;
     return MGTA_OK;
 }
 

@@ -41,6 +41,34 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
+// Lanes of the wave holding the same digit value (gfx950 has no match-any instruction: one ballot per digit bit).
+// rank = peers in lower lanes, cnt = all peers (self included); lanes with !valid are nobody's peer.
+// Per bit: sign-extend the bit, ballot it, peers &= xnor(ballot, sign) — 4 VALU ops.
+__device__ __forceinline__ void wave_match(uint32_t dg, int nbits, bool valid, uint32_t &rank, uint32_t &cnt) {
+    const uint64_t v = __ballot(valid);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto step = [&](int b) {
+        const int sx = (int)(dg << (31 - b)) >> 31;
+        const uint64_t bal = __ballot(sx < 0);
+        lo &= ~((uint32_t)bal ^ (uint32_t)sx);
+        hi &= ~((uint32_t)(bal >> 32) ^ (uint32_t)sx);
+    };
+    step(0); step(1); step(2); step(3);
+    if (nbits > 4) { step(4); step(5); step(6); step(7); }          // wave-uniform
+    rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+    cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+}
+
+// a value every lane of the wave holds identically (read from LDS, say) moved to scalar registers
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+    return ((uint64_t)wave_uniform((uint32_t)(v >> 32)) << 32) | wave_uniform((uint32_t)v);
+}
+
+// orders the LDS accesses of one wave as written (lane-to-lane hand-over through LDS inside a wave: the hardware
+// executes a wave's LDS instructions in order, the compiler must not cache or reorder them)
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
 // Block-wide exclusive scan of one uint32 per thread (blockDim.x = NT, multiple of 64, <= 1024).
 // `scratch` needs NT/64 + 1 words of LDS.  Returns the exclusive prefix; *total = block sum.
 template <int NT>

@@ -228,18 +228,20 @@ struct Digit {
 
 template <int W>
 __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
-    // the word is picked with compile-time indices + selects: a run-time index into key.w[] would push every
-    // register-resident key of the caller into scratch memory
+    // the word is picked by a wave-uniform branch on compile-time indices: a run-time index into key.w[] would push every
+    // register-resident key of the caller into scratch memory, and a chain of selects costs 2W VALU ops per key
+    // (the empty asm keeps the compiler from turning the branches back into selects)
     const int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        if (j == wi) lo = key.w[j];
-        if (j == wi - 1) hi = key.w[j];
+        if (j == wi) {
+            lo = key.w[j];
+            hi = j > 0 ? key.w[j - 1] : 0u;
+            asm volatile("" : "+v"(lo), "+v"(hi));
+        }
     }
-    uint32_t v = lo >> off;
-    if (off + d.bits > 32) v |= hi << (32 - off);
-    return v & ((1u << d.bits) - 1u);
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)off) & ((1u << d.bits) - 1u);
 }
 
 // census: hist[digit * n_tiles + tile]
@@ -300,9 +302,8 @@ struct ScatterShared {
 template <int W>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const uint64_t ltmask = lanemask_lt();
-    volatile uint16_t *whist = &sh.whist[0][0];   // wave-private rows, updated lane-to-lane inside a wave
-    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
+    uint16_t *whist = sh.whist[wv];               // wave-private row, updated lane-to-lane inside the wave
+    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
     __syncthreads();
     for (uint64_t sub_base = 0; sub_base < n; sub_base += kSubTile) {
         uint32_t n_valid = (uint32_t)((n - sub_base) < (uint64_t)kSubTile ? (n - sub_base) : (uint64_t)kSubTile);
@@ -310,27 +311,23 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
         Key<W> key[kItemsPerThread];
         uint32_t dr[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
 #pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {                    // all loads in flight before the first use
+            uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
+            if (j < n_valid) key[it] = in[sub_base + j];
+        }
+#pragma unroll
         for (int it = 0; it < kItemsPerThread; ++it) {
             uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
             bool valid = j < n_valid;
             uint32_t dg = 0;
+            if (valid) dg = get_digit<W>(key[it], d);
+            uint32_t rank, cnt, prev = 0;
+            wave_match(dg, d.bits, valid, rank, cnt);
             if (valid) {
-                key[it] = in[sub_base + j];
-                dg = get_digit<W>(key[it], d);
+                prev = whist[dg];
+                if (rank == cnt - 1) whist[dg] = (uint16_t)(prev + cnt);   // highest peer lane publishes the new count
             }
-            uint64_t peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                uint64_t bal = __ballot((dg >> b) & 1u);
-                peers &= ((dg >> b) & 1u) ? bal : ~bal;
-            }
-            uint32_t rank = (uint32_t)__popcll(peers & ltmask);
-            uint32_t cnt = (uint32_t)__popcll(peers);
-            uint32_t prev = 0;
-            if (valid) {
-                prev = whist[wv * 256 + dg];
-                if (rank == cnt - 1) whist[wv * 256 + dg] = (uint16_t)(prev + cnt);   // highest peer lane publishes the new count
-            }
+            wave_lds_fence();
             dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
         }
         __syncthreads();
@@ -370,14 +367,14 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
         __syncthreads();
         // phase 5: advance the global bases, clear the wave counters
         if (tid < 256) sh.gbase[tid] += sh.total[tid];
-        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
+        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
         __syncthreads();
     }
 }
 
 // stable scatter of one 32768-key tile by the current digit
-template <int W>
-__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
+template <int W, int MINW = 8>
+__global__ __launch_bounds__(kSortThreads, MINW) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
                                                                       const uint64_t *totals) {
     __shared__ ScatterShared<W> sh;
@@ -398,12 +395,13 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const Key<W
 // every pass inside the same launch, ping-ponging between the two key buffers (the range is private to the workgroup).
 template <int W>
 __global__ __launch_bounds__(kSortThreads) void segment_sort_kernel(Key<W> *buf_a, Key<W> *buf_b, const uint64_t *big, const uint64_t *big_end,
-                                                                     const Digit *low_plan, int n_low) {
+                                                                     const Digit *low_plan, int n_low, uint32_t lds_cap) {
     __shared__ ScatterShared<W> sh;
     __shared__ uint64_t s64[kSortThreads / 64 + 1];
     __shared__ uint32_t s_cnt[256];
     const int tid = threadIdx.x;
     const uint64_t s0 = big[blockIdx.x], cnt = big_end[blockIdx.x] - s0;
+    if (cnt <= (uint64_t)lds_cap) return;                           // sorted in LDS by local_deferred_kernel
     Key<W> *x = buf_a + s0, *y = buf_b + s0;
     for (int pass = 0; pass < n_low; ++pass) {
         const Digit d = low_plan[pass];
@@ -427,72 +425,78 @@ __global__ __launch_bounds__(kSortThreads) void segment_sort_kernel(Key<W> *buf_
 // ---------------------------------------------------------------------------------------------
 // 4b. segment-local finish.  After P global passes on the P most significant key bytes the array is
 // partitioned into segments of equal 8P-bit prefix (in arbitrary inner order).  Each workgroup takes
-// the whole segments that START in its stride of the array (<= LocalCfg<W>::kTile keys), sorts them on the
-// remaining bits entirely in LDS/registers (LSD, same wave-match ranking as the global scatter; the
-// segment rank is the most significant digit so segments keep their order) and writes them back in
-// place: these keys cross HBM once more instead of once per remaining digit.  A segment that does
-// not fit is reported in `big` and finished by global passes over just that range.
+// the whole segments that START in its stride of the array (<= LocalCfg<W>::kTile keys) and sorts
+// them in LDS, so these keys cross HBM once more instead of once per remaining digit:
+//   local_sort_kernel  two or three stable LSD passes in LDS (the 8 key bits below the prefix, then the rank of the
+//                      segment inside the tile) leave runs of equal leading 8P+8 bits — a handful of keys unless the
+//                      input is highly redundant; every key then finds its rank inside its run by comparing itself
+//                      with the run's other keys and goes straight to its final place.
+//   local_lsd_kernel   tiles whose runs are too long for that (reported by the first kernel), and single segments
+//                      that did not fit a tile next to their neighbours: LSD passes in LDS over every remaining digit.
+//   segment_sort_kernel (above)  segments longer than a tile: global passes over just that range.
 // ---------------------------------------------------------------------------------------------
 template <int W> struct LocalCfg {
     static constexpr int kTile = W <= 4 ? 4096 : 2048;           // keys sorted in LDS by one workgroup (LDS budget: kTile * 4W bytes)
     static constexpr int kIpt = kTile / kSortThreads;
     static constexpr int kChunk = kTile / kSortWaves;
-    static constexpr uint32_t kStride = kTile / 2;                // a workgroup owns the segments that START in its stride
-    static constexpr int kThreads = kSortThreads;
-    static constexpr uint64_t kItemsPerBlockStride = kStride;
+    static constexpr uint32_t kStride = kTile - kTile / 8;        // a workgroup owns the segments that START in its stride; the last one
+                                                                  // may hang over by kTile/8 keys before it is deferred
+};
+
+template <int W>
+struct LocalShared {
+    Key<W> keys[LocalCfg<W>::kTile];
+    uint16_t seg[LocalCfg<W>::kTile];
+    uint16_t whist[kSortWaves][256];
+    uint32_t start[256];
+    uint32_t scratch[kSortThreads / 64 + 1];
+    uint32_t wheads[kSortWaves + 1];
+    uint32_t flags[2];                                              // runs in the tile, "a run is too long"
+    uint64_t masks[LocalCfg<W>::kTile / 64];                         // segment / run heads, one bit per key
 };
 
 template <int W>
 __device__ __forceinline__ uint32_t key_prefix(const Key<W> &key, int P) { return P == 0 ? 0u : (key.w[0] >> (32 - 8 * P)); }
 
-template <int W>
-__global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, uint64_t n, int P, const Digit *low_plan, int n_low,
-                                                                  uint64_t *big, uint32_t *big_count, uint32_t big_cap) {
-    constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
-    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride;
-    __shared__ Key<W> s_keys[kTile];
-    __shared__ uint16_t s_seg[kTile];
-    __shared__ uint16_t s_whist[kSortWaves][256];
-    __shared__ uint32_t s_start[256];
-    __shared__ uint32_t s_scratch[kSortThreads / 64 + 1];
-    __shared__ unsigned long long s_first, s_lasthead, s_end;
-    __shared__ uint32_t s_wheads[kSortWaves + 1];
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const uint64_t ltmask = lanemask_lt();
-    const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
-    const uint64_t hi = lo + kLocalStride < n ? lo + kLocalStride : n;
-    const unsigned long long NONE = ~0ull;
-    if (tid == 0) { s_first = NONE; s_lasthead = 0; s_end = NONE; }
-    __syncthreads();
-    auto is_head = [&](uint64_t idx) { return idx == 0 || key_prefix<W>(keys[idx], P) != key_prefix<W>(keys[idx - 1], P); };
-    // 1. first / last segment head inside [lo, hi)
-    for (uint64_t idx = lo + tid; idx < hi; idx += kSortThreads)
-        if (is_head(idx)) { atomicMin(&s_first, (unsigned long long)idx); atomicMax(&s_lasthead, (unsigned long long)idx); }
-    __syncthreads();
-    const uint64_t first = s_first;
-    if (first == NONE) return;                                       // the stride lies inside one long segment
-    // 2. end of the tile: the first head at or after hi, as long as the tile stays <= kTile keys
-    const uint64_t limit = first + kTile < n ? first + kTile : n;
-    for (uint64_t idx = hi + tid; idx <= limit && idx < n; idx += kSortThreads)
-        if (is_head(idx)) atomicMin(&s_end, (unsigned long long)idx);
-    __syncthreads();
-    uint64_t end = s_end;
-    if (end == NONE) {
-        if (limit == n) end = n;
-        else {                                                       // the last segment starting here is too long for LDS
-            end = s_lasthead;
-            if (tid == 0) {
-                uint32_t q = atomicAdd(big_count, 1u);
-                if (q < big_cap) big[q] = end;
-            }
-        }
-    }
-    const uint32_t nt = (uint32_t)(end - first);
-    if (nt == 0) return;
+// What the segment-local kernels need besides the keys (host-built, passed by value)
+struct LocalPlan {
+    const Digit *low_plan;   // every significant digit below the 8P-bit prefix, least significant first
+    int n_low;
+    int P;
+    Digit upper;             // the (<= 8) key bits right below the prefix, all inside word 0
+    uint32_t mask_last2;     // significant bits of key word W-2 / W-1 (stage 1 carries a payload there that must not be compared);
+    uint32_t mask_last;      // the digits of low_plan never look at a masked-out bit
+    uint64_t *lsd_list;      // [2 * lsd_cap]: (first, end) of the tiles left to local_lsd_kernel
+    uint32_t *lsd_count;
+    uint32_t lsd_cap;
+    int debug;               // timing experiments only
+};
 
-    // 3. load in (wave chunk, round, lane) order + rank of the segment inside the tile
-    Key<W> key[kIpt];
-    uint32_t seg[kIpt];
+constexpr uint32_t kMaxAvgRun = 40;    // finish by comparison when the runs of equal (prefix, upper digit) are short on average ...
+constexpr uint32_t kMaxRun = 256;      // ... and none of them is longer than this
+
+// a < b on the significant bits of words FIRST..W-1
+template <int W, int FIRST>
+__device__ __forceinline__ bool key_less(const Key<W> &a, const Key<W> &b, uint32_t m2, uint32_t m1) {
+    bool lt = false;
+#pragma unroll
+    for (int j = W - 1; j >= FIRST; --j) {
+        uint32_t x = a.w[j], y = b.w[j];
+        if (j == W - 1) { x &= m1; y &= m1; }
+        if (j == W - 2) { x &= m2; y &= m2; }
+        lt = x < y || (x == y && lt);
+    }
+    return lt;
+}
+
+// loads the tile keys[first, first + nt) in (wave chunk, round, lane) order and ranks the segments inside the tile;
+// returns the number of LSD passes the segment rank needs (0: one segment).  All threads call.
+template <int W>
+__device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys, uint64_t first, uint32_t nt, int P, Key<W> (&key)[LocalCfg<W>::kIpt],
+                                         uint32_t (&seg)[LocalCfg<W>::kIpt]) {
+    constexpr int kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t le_mask = lanemask_lt() | (1ull << lane);
     uint32_t running = 0;
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
@@ -503,80 +507,234 @@ __global__ __launch_bounds__(kSortThreads) void local_sort_kernel(Key<W> *keys, 
             head = j == 0 || key_prefix<W>(key[it], P) != key_prefix<W>(keys[first + j - 1], P);
         }
         uint64_t bal = __ballot(head);
-        seg[it] = running + (uint32_t)__popcll(bal & (ltmask | (1ull << lane)));   // heads at positions <= j inside this wave chunk
+        seg[it] = running + (uint32_t)__popcll(bal & le_mask);         // heads at positions <= j inside this wave chunk
         running += (uint32_t)__popcll(bal);
     }
-    if (lane == 0) s_wheads[wv] = running;
+    if (lane == 0) sh.wheads[wv] = running;
     __syncthreads();
     uint32_t before = 0, nseg = 0;
-    for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_wheads[w]; if (w < wv) before += c; nseg += c; }
+    for (int w = 0; w < kSortWaves; ++w) { uint32_t c = sh.wheads[w]; if (w < wv) before += c; nseg += c; }
+    before = wave_uniform(before);
+    nseg = wave_uniform(nseg);
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) seg[it] = seg[it] + before - 1;
-    const int n_seg_pass = nseg <= 1 ? 0 : (nseg <= 256 ? 1 : 2);
+    return nseg <= 1 ? 0 : (nseg <= 256 ? 1 : 2);
+}
 
-    // 4. LSD passes: the low key digits, then the segment rank
-    volatile uint16_t *whist = &s_whist[0][0];
-    for (int pass = 0; pass < n_low + n_seg_pass; ++pass) {
-        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) whist[i] = 0;
-        __syncthreads();
-        const bool by_seg = pass >= n_low;
-        Digit d;
-        d.pos = 0; d.bits = 8;
-        if (!by_seg) d = low_plan[pass];
-        const int seg_shift = by_seg ? 8 * (pass - n_low) : 0;
-        uint32_t dr[kIpt];
+// one stable LSD pass over the tile: keys (+ segment ranks) go from registers (wave-chunk order) to their sorted LDS positions;
+// with `reload` they come back into registers in position order.  All threads call.
+template <int W>
+__device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[LocalCfg<W>::kIpt], uint32_t (&seg)[LocalCfg<W>::kIpt], uint32_t nt,
+                                         Digit d, bool by_seg, int seg_shift, bool reload) {
+    constexpr int kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    uint16_t *whist = sh.whist[wv];
+    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t dr[kIpt];
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+        bool valid = j < nt;
+        uint32_t dg = 0;
+        if (valid) dg = by_seg ? ((seg[it] >> seg_shift) & 255u) : get_digit<W>(key[it], d);
+        uint32_t rank, cnt, prev = 0;
+        wave_match(dg, by_seg ? 8 : d.bits, valid, rank, cnt);
+        if (valid) {
+            prev = whist[dg];
+            if (rank == cnt - 1) whist[dg] = (uint16_t)(prev + cnt);
+        }
+        wave_lds_fence();
+        dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) { uint32_t c = sh.whist[w][tid]; sh.whist[w][tid] = (uint16_t)tot; tot += c; }
+    }
+    uint32_t ex = block_excl_scan<kSortThreads>(tot, sh.scratch, nullptr);
+    if (tid < 256) sh.start[tid] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        if (dr[it] >> 31) {
+            uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
+            uint32_t pos = sh.start[dg] + whist[dg] + rk;
+            sh.keys[pos] = key[it];
+            sh.seg[pos] = (uint16_t)seg[it];
+        }
+    }
+    __syncthreads();
+    if (reload) {
 #pragma unroll
         for (int it = 0; it < kIpt; ++it) {
             uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
-            bool valid = j < nt;
-            uint32_t dg = 0;
-            if (valid) dg = by_seg ? ((seg[it] >> seg_shift) & 255u) : get_digit<W>(key[it], d);
-            uint64_t peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                uint64_t bal = __ballot((dg >> b) & 1u);
-                peers &= ((dg >> b) & 1u) ? bal : ~bal;
-            }
-            uint32_t rank = (uint32_t)__popcll(peers & ltmask), cnt = (uint32_t)__popcll(peers), prev = 0;
-            if (valid) {
-                prev = whist[wv * 256 + dg];
-                if (rank == cnt - 1) whist[wv * 256 + dg] = (uint16_t)(prev + cnt);
-            }
-            dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
+            if (j < nt) { key[it] = sh.keys[j]; seg[it] = sh.seg[j]; }
         }
         __syncthreads();
-        uint32_t tot = 0;
-        if (tid < 256) {
+    }
+}
+
+// Last step of local_sort_kernel.  The tile lies in sh.keys sorted by (segment, upper digit): runs of equal leading
+// `32 - run_shift` bits.  Run heads are balloted per 64-key window and the masks shared through LDS, so every key reads its
+// run [rs, re) off a few masks; it then finds its rank among the run's keys by comparing words FIRST..W-1 (equal keys keep
+// their order) and goes to its final place in global memory.  Returns false (nothing written) when the runs are longer than
+// kMaxAvgRun on average or one of them is longer than kMaxRun.
+template <int W, int FIRST>
+__device__ __forceinline__ bool finish_by_comparison(LocalShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_shift, uint32_t m2,
+                                                     uint32_t m1, bool skip_compare) {
+    constexpr int kIpt = LocalCfg<W>::kIpt, kWindows = LocalCfg<W>::kTile / 64;
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t le_mask = lanemask_lt() | (1ull << lane);
+    uint32_t heads = 0;
 #pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = (uint16_t)tot; tot += c; }
-        }
-        uint32_t ex = block_excl_scan<kSortThreads>(tot, s_scratch, nullptr);
-        if (tid < 256) s_start[tid] = ex;
-        __syncthreads();
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t win = (uint32_t)it * kSortWaves + (uint32_t)wv, j = win * 64 + (uint32_t)lane;
+        const bool head = j < nt && (j == 0 || ((sh.keys[j - 1].w[0] ^ sh.keys[j].w[0]) >> run_shift) != 0);
+        const uint64_t hm = __ballot(head);
+        if (lane == 0) sh.masks[win] = hm;
+        heads += (uint32_t)__popcll(hm);
+    }
+    if (lane == 0 && heads) atomicAdd(&sh.flags[0], heads);
+    __syncthreads();
+    if (nt > wave_uniform(sh.flags[0]) * kMaxAvgRun) return false;
+    uint32_t run[kIpt];                                               // rs | (re - rs) << 16
+    bool over = false;
 #pragma unroll
-        for (int it = 0; it < kIpt; ++it) {
-            if (dr[it] >> 31) {
-                uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
-                uint32_t pos = s_start[dg] + s_whist[wv][dg] + rk;
-                s_keys[pos] = key[it];
-                s_seg[pos] = (uint16_t)seg[it];
-            }
-        }
-        __syncthreads();
-        if (pass + 1 < n_low + n_seg_pass) {                         // back into registers in position order
-#pragma unroll
-            for (int it = 0; it < kIpt; ++it) {
-                uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
-                if (j < nt) { key[it] = s_keys[j]; seg[it] = s_seg[j]; }
-            }
-            __syncthreads();
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t win = (uint32_t)it * kSortWaves + (uint32_t)wv, j = win * 64 + (uint32_t)lane;
+        run[it] = 0;
+        if (j < nt) {
+            const uint64_t hm = sh.masks[win];
+            // last head at or before j: window 0 holds the head of key 0, so the walk back ends there at the latest
+            uint64_t m = hm & le_mask;
+            uint32_t w = win;
+            while (m == 0 && win - w <= kMaxRun / 64) m = sh.masks[--w];
+            const uint32_t rs = m ? w * 64 + 63u - (uint32_t)__clzll((long long)m) : j;
+            over = over || m == 0;                                                 // no head within kMaxRun keys
+            // first head behind j (masks beyond nt are 0: the last run ends with the tile)
+            m = hm & ~le_mask;
+            w = win;
+            while (m == 0 && w + 1 < (uint32_t)kWindows && w - win <= kMaxRun / 64) m = sh.masks[++w];
+            const uint32_t re = m ? w * 64 + (uint32_t)__ffsll((long long)m) - 1u : nt;
+            over = over || re - rs > kMaxRun;
+            run[it] = rs | ((re - rs) << 16);
         }
     }
-    // 5. write back (coalesced).  With zero passes (a single segment of identical low bits cannot happen: n_low >= 1) LDS holds the result.
+    if (__ballot(over) && lane == 0) sh.flags[1] = 1;
+    __syncthreads();
+    if (wave_uniform(sh.flags[1])) return false;
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t j = ((uint32_t)it * kSortWaves + (uint32_t)wv) * 64 + (uint32_t)lane;
+        if (j < nt) {
+            const Key<W> mine = sh.keys[j];
+            const uint32_t rs = run[it] & 0xFFFFu, re = rs + (run[it] >> 16);
+            uint32_t r = j - rs;
+            if (!skip_compare) {
+                r = 0;
+#pragma unroll 2
+                for (uint32_t t = rs; t < j; ++t) r += key_less<W, FIRST>(mine, sh.keys[t], m2, m1) ? 0u : 1u;
+#pragma unroll 2
+                for (uint32_t t = j + 1; t < re; ++t) r += key_less<W, FIRST>(sh.keys[t], mine, m2, m1) ? 1u : 0u;
+            }
+            keys[first + rs + r] = mine;
+        }
+    }
+    return true;
+}
+
+template <int W>
+__global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *keys, uint64_t n, LocalPlan lp, uint64_t *big, uint32_t *big_count,
+                                                                     uint32_t big_cap) {
+    constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
+    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride;
+    __shared__ LocalShared<W> sh;
+    __shared__ unsigned long long s_first, s_lasthead, s_end;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), P = lp.P;
+    const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
+    const uint64_t hi = lo + kLocalStride < n ? lo + kLocalStride : n;
+    const unsigned long long NONE = ~0ull;
+    if (tid == 0) { s_first = NONE; s_lasthead = 0; s_end = NONE; sh.flags[0] = 0; sh.flags[1] = 0; }
+    __syncthreads();
+    auto is_head = [&](uint64_t idx) { return idx == 0 || key_prefix<W>(keys[idx], P) != key_prefix<W>(keys[idx - 1], P); };
+    // 1. first / last segment head inside [lo, hi)
+    for (uint64_t idx = lo + tid; idx < hi; idx += kSortThreads)
+        if (is_head(idx)) { atomicMin(&s_first, (unsigned long long)idx); atomicMax(&s_lasthead, (unsigned long long)idx); }
+    __syncthreads();
+    const uint64_t first = wave_uniform((uint64_t)s_first);
+    if (first == NONE) return;                                       // the stride lies inside one long segment
+    // 2. end of the tile: the first head at or after hi, as long as the tile stays <= kTile keys
+    const uint64_t limit = first + kTile < n ? first + kTile : n;
+    for (uint64_t idx = hi + tid; idx <= limit && idx < n; idx += kSortThreads)
+        if (is_head(idx)) atomicMin(&s_end, (unsigned long long)idx);
+    __syncthreads();
+    uint64_t end = wave_uniform((uint64_t)s_end);
+    if (end == NONE) {
+        if (limit == n) end = n;
+        else {                                                       // the last segment starting here does not fit: deferred
+            end = wave_uniform((uint64_t)s_lasthead);
+            if (tid == 0) {
+                uint32_t q = atomicAdd(big_count, 1u);
+                if (q < big_cap) big[q] = end;
+            }
+        }
+    }
+    const uint32_t nt = (uint32_t)(end - first);
+    if (nt == 0) return;
+    auto leave_to_lsd = [&]() {
+        if (tid == 0) {
+            uint32_t q = atomicAdd(lp.lsd_count, 1u);
+            if (q < lp.lsd_cap) { lp.lsd_list[2 * q] = first; lp.lsd_list[2 * q + 1] = end; }
+        }
+    };
+    if (lp.upper.bits == 0) { leave_to_lsd(); return; }
+    // 3. LSD passes in LDS: upper digit, then the segment rank
+    {
+        Key<W> key[kIpt];
+        uint32_t seg[kIpt];
+        const int n_seg_pass = tile_load<W>(sh, keys, first, nt, P, key, seg);
+        if (lp.debug & 2) return;
+        lds_pass<W>(sh, key, seg, nt, lp.upper, false, 0, n_seg_pass > 0);
+        for (int sp = 0; sp < n_seg_pass; ++sp) lds_pass<W>(sh, key, seg, nt, lp.upper, true, 8 * sp, sp + 1 < n_seg_pass);
+    }
+    // 4. runs of equal (prefix, upper digit): every key ranks itself inside its run
+    const int run_shift = 32 - (8 * P + lp.upper.bits);
+    const bool skip = (lp.debug & 1) != 0;
+    const bool done = run_shift == 0 && W > 1 ? finish_by_comparison<W, (W > 1 ? 1 : 0)>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
+                                              : finish_by_comparison<W, 0>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
+    if (!done) leave_to_lsd();                                        // global memory still holds the tile as it was
+    (void)kChunk; (void)wv;
+}
+
+// one workgroup per listed range [start[b], end[b]) of whole segments (<= kTile keys, longer ones are skipped: segment_sort_kernel):
+// stable LSD passes in LDS over every significant digit below the prefix, then the segment rank
+template <int W>
+__global__ __launch_bounds__(kSortThreads, 8) void local_lsd_kernel(Key<W> *keys, const uint64_t *start, const uint64_t *end, int stride,
+                                                                    LocalPlan lp) {
+    constexpr int kIpt = LocalCfg<W>::kIpt;
+    __shared__ LocalShared<W> sh;
+    const int tid = threadIdx.x;
+    const uint64_t first = wave_uniform(start[(uint64_t)blockIdx.x * stride]), cnt = wave_uniform(end[(uint64_t)blockIdx.x * stride]) - first;
+    if (cnt > (uint64_t)LocalCfg<W>::kTile || cnt == 0) return;
+    const uint32_t nt = (uint32_t)cnt;
+    Key<W> key[kIpt];
+    uint32_t seg[kIpt];
+    const int n_seg_pass = tile_load<W>(sh, keys, first, nt, lp.P, key, seg);
+    const int n_pass = lp.n_low + n_seg_pass;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        const bool by_seg = pass >= lp.n_low;
+        Digit d;
+        d.pos = 0; d.bits = 8;
+        if (!by_seg) d = lp.low_plan[pass];
+        lds_pass<W>(sh, key, seg, nt, d, by_seg, by_seg ? 8 * (pass - lp.n_low) : 0, pass + 1 < n_pass);
+    }
+    // write back (coalesced); n_low >= 1, so LDS holds the result
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
-        if (j < nt) keys[first + j] = s_keys[j];
+        if (j < nt) keys[first + j] = sh.keys[j];
     }
 }
 
@@ -877,7 +1035,7 @@ static std::vector<Digit> low_digit_plan(int k, int W, int P) {
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -900,7 +1058,8 @@ static uint64_t pool_bytes(const mgta_ctx *ctx) {
 // holds the result, nullptr on an unsupported input (error set).
 template <int WT, class LowPlanFn>
 static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
-                            std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S) {
+                            std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, uint32_t mask_last2 = ~0u,
+                            uint32_t mask_last = ~0u) {
     const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
     uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
     uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
@@ -915,7 +1074,11 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             MGTA_HIP_CHECK(hipEventCreate(&e1));
             MGTA_HIP_CHECK(hipEventRecord(e0, stream));
         }
-        hipLaunchKernelGGL((radix_scatter_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+        if (ctx->force_lsd_tiles & 8)
+            hipLaunchKernelGGL((radix_scatter_kernel<WT, 4>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+                               d_totals);
+        else
+        hipLaunchKernelGGL((radix_scatter_kernel<WT, 8>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
                            d_totals);
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
@@ -937,29 +1100,55 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * big_cap);
     MGTA_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 8, stream));
     uint64_t l_blocks = (n_items + LocalCfg<WT>::kStride - 1) / LocalCfg<WT>::kStride;
+    uint64_t *d_lsd = pool_get<uint64_t>(ctx, S_LSD, 2 * l_blocks * 8);
     hipEvent_t le0, le1;
     MGTA_HIP_CHECK(hipEventCreate(&le0));
     MGTA_HIP_CHECK(hipEventCreate(&le1));
     MGTA_HIP_CHECK(hipEventRecord(le0, stream));
-    hipLaunchKernelGGL((local_sort_kernel<WT>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, P, d_plan, (int)low.size(),
-                       d_big, d_big_count, big_cap);
+    LocalPlan lp;
+    lp.low_plan = d_plan;
+    lp.n_low = (int)low.size();
+    lp.P = P;
+    // the comparison route is skipped for a few sorts after one that found mostly long runs (highly redundant input)
+    const bool skip_a = ctx->lsd_skip_left > 0;
+    if (skip_a) --ctx->lsd_skip_left;
+    const int ub = ((ctx->force_lsd_tiles & 1) || skip_a) ? 0 : std::min(8, 32 - 8 * P);
+    lp.upper = Digit{32 * WT - 8 * P - ub, ub};
+    lp.mask_last2 = mask_last2;
+    lp.mask_last = mask_last;
+    lp.lsd_list = d_lsd;
+    lp.lsd_count = d_big_count + 1;
+    lp.lsd_cap = (uint32_t)l_blocks;
+    lp.debug = ctx->force_lsd_tiles >> 1;
+    hipLaunchKernelGGL((local_sort_kernel<WT>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, lp, d_big, d_big_count, big_cap);
     MGTA_HIP_CHECK(hipEventRecord(le1, stream));
-    uint32_t n_big = 0;
+    uint32_t n_big = 0, n_lsd_tiles = 0;
+    MGTA_HIP_CHECK(hipMemcpyAsync(&n_lsd_tiles, d_big_count + 1, 4, hipMemcpyDeviceToHost, stream));
     MGTA_HIP_CHECK(hipMemcpyAsync(&n_big, d_big_count, 4, hipMemcpyDeviceToHost, stream));
     MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms_local = 0;
+    MGTA_HIP_CHECK(hipEventElapsedTime(&ms_local, le0, le1));
+    if (n_big > big_cap) { set_error("more than %u oversized key segments in one pass", big_cap); return nullptr; }
+    if (n_lsd_tiles > lp.lsd_cap) { set_error("internal: tile list overflow"); return nullptr; }
+    if (ub > 0 && l_blocks >= 64 && 2 * (uint64_t)n_lsd_tiles > l_blocks) ctx->lsd_skip_left = 7;   // then look again
+    MGTA_HIP_CHECK(hipEventRecord(le0, stream));
+    if (n_lsd_tiles > 0 && !(lp.debug & 2))
+        hipLaunchKernelGGL((local_lsd_kernel<WT>), dim3(n_lsd_tiles), dim3(kSortThreads), 0, stream, src, d_lsd, d_lsd + 1, 2, lp);
+    if (n_big > 0) {
+        // segments that did not fit a tile next to their neighbours: alone in LDS if they fit, else (hot k-mers, or the whole array
+        // when it is tiny) one workgroup each with global ping-pong passes
+        hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
+        hipLaunchKernelGGL((local_lsd_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, d_big, d_big + big_cap, 1, lp);
+        hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
+                           (int)low.size(), (uint32_t)LocalCfg<WT>::kTile);
+    }
+    MGTA_HIP_CHECK(hipEventRecord(le1, stream));
+    MGTA_HIP_CHECK(hipEventSynchronize(le1));
     {
         float ms = 0;
         MGTA_HIP_CHECK(hipEventElapsedTime(&ms, le0, le1));
-        if (S) S->ms_local_sort += ms;
+        if (S) { S->ms_local_sort += ms_local + ms; S->n_lsd_tiles += n_lsd_tiles; S->n_big_segments += n_big; }
         (void)hipEventDestroy(le0); (void)hipEventDestroy(le1);
-    }
-    if (n_big > big_cap) { set_error("more than %u oversized key segments in one pass", big_cap); return nullptr; }
-    if (n_big > 0) {
-        // segments too long for LDS (hot k-mers, or the whole array when it is tiny): one workgroup each, global ping-pong
-        hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
-        hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
-                           (int)low.size());
-        if (S) S->n_big_segments += n_big;
     }
     return src;
 }
@@ -1043,7 +1232,7 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                 return plan;
             };
             const int max_top = std::min(4, std::max(0, (2 * (k - 1)) / 8));
-            Key<WT> *sorted = device_sort<WT>(ctx, stream, d_a, d_b, n_items, max_top, low_plan, nullptr, nullptr);
+            Key<WT> *sorted = device_sort<WT>(ctx, stream, d_a, d_b, n_items, max_top, low_plan, nullptr, nullptr, 0u, 0x3Fu);
             if (!sorted) return MGTA_EUNSUPPORTED;
             char *scratch = reinterpret_cast<char *>(sorted == d_a ? d_b : d_a);
             uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;

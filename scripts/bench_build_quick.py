@@ -9,6 +9,8 @@ packed, start = synth.pack_reads_for_build(mg.reads)
 print("gen", time.time() - t, flush=True)
 ctx = api.Context(0)
 rd = ctx.upload_reads(packed, start)
+if len(sys.argv) > 3:
+    ctx.set_full_lsd(int(sys.argv[3]))
 for it in range(3):
     g = ctx.build_sdbg(rd, k, collect=False)
     s = g.stats

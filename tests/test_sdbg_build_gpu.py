@@ -173,3 +173,41 @@ def test_min_count_and_mercy_vs_reference(ctx, golden_dir, sub):
         assert hashlib.md5(api.counting_text(ctx.last_counting()).encode()).hexdigest() == fx["counting_md5"], tag
         ran += 1
     assert ran >= 4
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("k", [31, 44, 79])
+def test_sort_routes_agree(ctx, oracle, golden_dir, k, mode):
+    """the three ways a key can get sorted (global LSD only / LDS LSD passes / LDS passes + finish by comparison) give one stream"""
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    base = ctx.build_sdbg(rd, k)
+    ctx.set_full_lsd(mode)
+    try:
+        g = ctx.build_sdbg(rd, k)
+    finally:
+        ctx.set_full_lsd(0)
+    _same(g, base)
+    o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    _same(base, o)
+
+
+@pytest.mark.parametrize("k", [21, 44])
+def test_redundant_reads_long_runs(ctx, oracle, k):
+    """highly redundant input: runs of equal keys far longer than the comparison route accepts (per-tile fallback), next to
+    unique reads (comparison route), next to a k-mer so frequent that its segment leaves LDS (deferred / global fallback)"""
+    rng = np.random.default_rng(7 + k)
+    reads = []
+    for i in range(40):
+        r = rng.integers(0, 4, 120).astype(np.uint8)
+        reads += [r.copy() for _ in range(int(rng.integers(2, 400)))]
+    for i in range(3000):
+        r = rng.integers(0, 4, int(rng.integers(k + 1, 140))).astype(np.uint8)
+        reads.append(r)
+    reads += [np.zeros(150, np.uint8) for _ in range(300)]            # poly-A: one (k+1)-mer, 300 * (150 - k) copies
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    _same(g, o)
