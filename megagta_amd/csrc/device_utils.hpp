@@ -35,6 +35,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);

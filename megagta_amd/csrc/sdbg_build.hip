@@ -244,6 +244,29 @@ __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
     return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)off) & ((1u << d.bits) - 1u);
 }
 
+// the same digit of N register-resident keys: one wave-uniform branch chain for all of them
+template <int W, int N>
+__device__ __forceinline__ void get_digits(const Key<W> (&key)[N], Digit d, uint32_t (&dg)[N]) {
+    const int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
+    uint32_t lo[N], hi[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { lo[i] = 0; hi[i] = 0; }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        if (j == wi) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                lo[i] = key[i].w[j];
+                hi[i] = j > 0 ? key[i].w[j - 1] : 0u;
+                asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
+            }
+        }
+    }
+    const uint32_t mask = (1u << d.bits) - 1u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) dg[i] = __builtin_amdgcn_alignbit(hi[i], lo[i], (uint32_t)off) & mask;
+}
+
 // census: hist[digit * n_tiles + tile]
 template <int W>
 __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W> *keys, uint64_t n, Digit d, uint64_t n_tiles,
@@ -451,6 +474,18 @@ struct LocalShared {
     uint32_t start[256];
     uint32_t scratch[kSortThreads / 64 + 1];
     uint32_t wheads[kSortWaves + 1];
+};
+
+// LDS of local_sort_kernel: the tile, one 16-bit counter per (segment, upper digit) bin, head masks
+template <int W>
+struct CompareShared {
+    // two workgroups per CU (80 KB each) where the keys leave room for >= 2048 counters, else one
+    static constexpr int kRoom = (80 * 1024 - 1024 - LocalCfg<W>::kTile * 4 * W) / 2;
+    static constexpr int kBins = kRoom >= 2048 ? (kRoom / 2048 * 2048 < 16384 ? kRoom / 2048 * 2048 : 16384) : 16384;
+    static_assert(kBins >= LocalCfg<W>::kTile || kBins == 16384, "a bin per segment at least");
+    Key<W> keys[LocalCfg<W>::kTile];
+    uint32_t hist[kBins / 2];                                        // bin b: bits [16 (b & 1), +16) of word b >> 1
+    uint32_t scratch[kSortThreads / 64 + 1];
     uint32_t flags[2];                                              // runs in the tile, "a run is too long"
     uint64_t masks[LocalCfg<W>::kTile / 64];                         // segment / run heads, one bit per key
 };
@@ -521,58 +556,80 @@ __device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys,
     return nseg <= 1 ? 0 : (nseg <= 256 ? 1 : 2);
 }
 
-// one stable LSD pass over the tile: keys (+ segment ranks) go from registers (wave-chunk order) to their sorted LDS positions;
-// with `reload` they come back into registers in position order.  All threads call.
+// one stable LSD pass over the tile: keys (+ segment ranks) go from registers (wave-chunk order) to their sorted LDS positions
+// [0, nt); with `reload` they come back into registers in position order.  All threads call; every wave's row of sh.whist
+// must be zero on entry (tile_zero_counts) and is zero again on return.  Four workgroup barriers.
+template <int W>
+__device__ __forceinline__ void tile_zero_counts(LocalShared<W> &sh) {
+    uint16_t *whist = sh.whist[wave_id()];
+    for (int i = lane_id(); i < 256; i += 64) whist[i] = 0;             // wave-private: no barrier needed before the wave counts
+}
+
 template <int W>
 __device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[LocalCfg<W>::kIpt], uint32_t (&seg)[LocalCfg<W>::kIpt], uint32_t nt,
-                                         Digit d, bool by_seg, int seg_shift, bool reload) {
+                                         Digit d, bool by_seg, int seg_shift, bool reload, uint32_t off = 0) {
     constexpr int kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];
-    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
-    __syncthreads();
-    uint32_t dr[kIpt];
+    uint32_t dr[kIpt], cnt[kIpt];
+    // digit + peers of every key first (independent work the compiler can interleave) ...
+    if (by_seg) {
+#pragma unroll
+        for (int it = 0; it < kIpt; ++it) dr[it] = (seg[it] >> seg_shift) & 255u;
+    } else {
+        get_digits<W, kIpt>(key, d, dr);
+    }
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
-        bool valid = j < nt;
-        uint32_t dg = 0;
-        if (valid) dg = by_seg ? ((seg[it] >> seg_shift) & 255u) : get_digit<W>(key[it], d);
-        uint32_t rank, cnt, prev = 0;
-        wave_match(dg, by_seg ? 8 : d.bits, valid, rank, cnt);
-        if (valid) {
-            prev = whist[dg];
-            if (rank == cnt - 1) whist[dg] = (uint16_t)(prev + cnt);
+        bool valid = j - off < nt;                                        // the registers hold positions [off, off + nt) of what was loaded
+        uint32_t dg = valid ? dr[it] : 0u, rank;
+        wave_match(dg, by_seg ? 8 : d.bits, valid, rank, cnt[it]);
+        dr[it] = dg | (rank << 8) | ((uint32_t)valid << 31);
+    }
+    // ... then the wave's running counts, round by round (lane-to-lane hand-over through LDS)
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        if (dr[it] >> 31) {
+            const uint32_t dg = dr[it] & 255u, rank = (dr[it] >> 8) & 0xFFu, prev = whist[dg];
+            if (rank == cnt[it] - 1) whist[dg] = (uint16_t)(prev + cnt[it]);
+            dr[it] += prev << 8;
         }
         wave_lds_fence();
-        dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
     }
     __syncthreads();
-    uint32_t tot = 0;
-    if (tid < 256) {
+    // per digit value (threads 0..255 = waves 0..3): total over the waves, scan over the values, base of every wave
+    uint32_t tot = 0, inc = 0;
+    if (wv < 4) {
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) { uint32_t c = sh.whist[w][tid]; sh.whist[w][tid] = (uint16_t)tot; tot += c; }
+        for (int w = 0; w < kSortWaves; ++w) tot += sh.whist[w][tid];
+        inc = wave_incl_scan(tot);
+        if (lane == 63) sh.scratch[wv] = inc;
     }
-    uint32_t ex = block_excl_scan<kSortThreads>(tot, sh.scratch, nullptr);
-    if (tid < 256) sh.start[tid] = ex;
+    __syncthreads();
+    if (wv < 4) {
+        uint32_t running = inc - tot;
+        for (int w = 0; w < wv; ++w) running += sh.scratch[w];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) { uint32_t c = sh.whist[w][tid]; sh.whist[w][tid] = (uint16_t)running; running += c; }
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         if (dr[it] >> 31) {
-            uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
-            uint32_t pos = sh.start[dg] + whist[dg] + rk;
+            uint32_t pos = whist[dr[it] & 255u] + ((dr[it] >> 8) & 0x7FFFFFu);
             sh.keys[pos] = key[it];
             sh.seg[pos] = (uint16_t)seg[it];
         }
     }
     __syncthreads();
+    tile_zero_counts<W>(sh);                                              // own row, read by this wave only since the last barrier
     if (reload) {
 #pragma unroll
         for (int it = 0; it < kIpt; ++it) {
             uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
             if (j < nt) { key[it] = sh.keys[j]; seg[it] = sh.seg[j]; }
         }
-        __syncthreads();
     }
 }
 
@@ -582,7 +639,7 @@ __device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[Local
 // their order) and goes to its final place in global memory.  Returns false (nothing written) when the runs are longer than
 // kMaxAvgRun on average or one of them is longer than kMaxRun.
 template <int W, int FIRST>
-__device__ __forceinline__ bool finish_by_comparison(LocalShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_shift, uint32_t m2,
+__device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_shift, uint32_t m2,
                                                      uint32_t m1, bool skip_compare) {
     constexpr int kIpt = LocalCfg<W>::kIpt, kWindows = LocalCfg<W>::kTile / 64;
     const int lane = lane_id(), wv = wave_id();
@@ -645,67 +702,142 @@ __device__ __forceinline__ bool finish_by_comparison(LocalShared<W> &sh, Key<W> 
     return true;
 }
 
-template <int W>
+template <int W, bool WANT_KEYS>   // !WANT_KEYS: only the tile bounds are wanted (every tile goes to local_lsd_kernel)
 __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *keys, uint64_t n, LocalPlan lp, uint64_t *big, uint32_t *big_count,
                                                                      uint32_t big_cap) {
-    constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
-    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride;
-    __shared__ LocalShared<W> sh;
-    __shared__ unsigned long long s_first, s_lasthead, s_end;
+    constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk, kWindows = kTile / 64;
+    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride, NONE = ~0u;
+    static_assert(kLocalStride % 64 == 0 && kWindows <= 64, "tile bounds are read off one 64-bit head mask per lane");
+    __shared__ CompareShared<W> sh;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), P = lp.P;
     const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
-    const uint64_t hi = lo + kLocalStride < n ? lo + kLocalStride : n;
-    const unsigned long long NONE = ~0ull;
-    if (tid == 0) { s_first = NONE; s_lasthead = 0; s_end = NONE; sh.flags[0] = 0; sh.flags[1] = 0; }
+    const uint32_t loaded = (uint32_t)(n - lo < (uint64_t)kTile ? n - lo : (uint64_t)kTile);   // the window [lo, lo + loaded)
+    constexpr bool want_keys = WANT_KEYS;
+    if (tid == 0) { sh.flags[0] = 0; sh.flags[1] = 0; }
+    // 1. one read of the window, in (wave chunk, round, lane) order; segment heads balloted per 64 keys
+    Key<W> key[kIpt];
+    uint32_t seg[kIpt];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+        const bool inw = j < loaded;
+        uint32_t p = 0;
+        if (inw) {
+            if (want_keys) key[it] = keys[lo + j];
+            else key[it].w[0] = keys[lo + j].w[0];
+            p = key_prefix<W>(key[it], P);
+        }
+        uint32_t pp = __shfl_up(p, 1, 64);
+        if (lane == 0) pp = it == 0 ? ((inw && lo + j > 0) ? key_prefix<W>(keys[lo + j - 1], P) : 0u) : carry;
+        carry = __shfl(p, 63, 64);
+        const uint64_t hm = __ballot(inw && (lo + j == 0 || p != pp));
+        if (lane == 0) sh.masks[wv * kIpt + it] = hm;                 // window m = positions [64m, 64m + 64)
+    }
     __syncthreads();
-    auto is_head = [&](uint64_t idx) { return idx == 0 || key_prefix<W>(keys[idx], P) != key_prefix<W>(keys[idx - 1], P); };
-    // 1. first / last segment head inside [lo, hi)
-    for (uint64_t idx = lo + tid; idx < hi; idx += kSortThreads)
-        if (is_head(idx)) { atomicMin(&s_first, (unsigned long long)idx); atomicMax(&s_lasthead, (unsigned long long)idx); }
-    __syncthreads();
-    const uint64_t first = wave_uniform((uint64_t)s_first);
-    if (first == NONE) return;                                       // the stride lies inside one long segment
-    // 2. end of the tile: the first head at or after hi, as long as the tile stays <= kTile keys
-    const uint64_t limit = first + kTile < n ? first + kTile : n;
-    for (uint64_t idx = hi + tid; idx <= limit && idx < n; idx += kSortThreads)
-        if (is_head(idx)) atomicMin(&s_end, (unsigned long long)idx);
-    __syncthreads();
-    uint64_t end = wave_uniform((uint64_t)s_end);
-    if (end == NONE) {
-        if (limit == n) end = n;
-        else {                                                       // the last segment starting here does not fit: deferred
-            end = wave_uniform((uint64_t)s_lasthead);
+    // 2. the tile: from the first head in the stride to the first head behind it (every wave computes the same scalars)
+    const uint64_t hmask = lane < kWindows ? sh.masks[lane] : 0ull;
+    const bool in_stride = (uint32_t)lane < kLocalStride / 64;
+    const uint32_t first_off = wave_uniform(wave_min(in_stride && hmask ? (uint32_t)lane * 64 + (uint32_t)__ffsll((long long)hmask) - 1u : NONE));
+    if (first_off == NONE) return;                                    // the stride lies inside one long segment
+    uint32_t end_off = wave_uniform(wave_min(!in_stride && hmask ? (uint32_t)lane * 64 + (uint32_t)__ffsll((long long)hmask) - 1u : NONE));
+    if (end_off == NONE) {
+        if (lo + loaded == n) end_off = loaded;
+        else {                                                        // the last segment starting here does not fit: deferred
+            end_off = wave_uniform(wave_max(in_stride && hmask ? (uint32_t)lane * 64 + 63u - (uint32_t)__clzll((long long)hmask) : 0u));
             if (tid == 0) {
                 uint32_t q = atomicAdd(big_count, 1u);
-                if (q < big_cap) big[q] = end;
+                if (q < big_cap) big[q] = lo + end_off;
             }
         }
     }
-    const uint32_t nt = (uint32_t)(end - first);
+    const uint32_t nt = end_off - first_off;
     if (nt == 0) return;
+    const uint64_t first = lo + first_off;
     auto leave_to_lsd = [&]() {
         if (tid == 0) {
             uint32_t q = atomicAdd(lp.lsd_count, 1u);
-            if (q < lp.lsd_cap) { lp.lsd_list[2 * q] = first; lp.lsd_list[2 * q + 1] = end; }
+            if (q < lp.lsd_cap) { lp.lsd_list[2 * q] = first; lp.lsd_list[2 * q + 1] = lo + end_off; }
         }
     };
-    if (lp.upper.bits == 0) { leave_to_lsd(); return; }
-    // 3. LSD passes in LDS: upper digit, then the segment rank
+    if (!want_keys) { leave_to_lsd(); return; }
+    // rank of every key's segment inside the tile: heads in [first_off, its position]
+    uint32_t nseg;
     {
-        Key<W> key[kIpt];
-        uint32_t seg[kIpt];
-        const int n_seg_pass = tile_load<W>(sh, keys, first, nt, P, key, seg);
-        if (lp.debug & 2) return;
-        lds_pass<W>(sh, key, seg, nt, lp.upper, false, 0, n_seg_pass > 0);
-        for (int sp = 0; sp < n_seg_pass; ++sp) lds_pass<W>(sh, key, seg, nt, lp.upper, true, 8 * sp, sp + 1 < n_seg_pass);
+        uint64_t in_tile = hmask;                                     // heads of window `lane` inside [first_off, end_off)
+        const uint32_t w0 = (uint32_t)lane * 64;
+        if (w0 + 64 <= first_off || w0 >= end_off) in_tile = 0;
+        else {
+            if (first_off > w0) in_tile &= ~0ull << (first_off - w0);
+            if (end_off < w0 + 64) in_tile &= ~0ull >> (w0 + 64 - end_off);
+        }
+        const uint32_t c = (uint32_t)__popcll(in_tile), inc = wave_incl_scan(c);
+        nseg = wave_uniform((uint32_t)__shfl(inc, 63, 64));
+        const uint64_t le_mask = lanemask_lt() | (1ull << lane);
+#pragma unroll
+        for (int it = 0; it < kIpt; ++it) {
+            const int m = wv * kIpt + it;
+            const uint32_t before = (uint32_t)__shfl(inc - c, m, 64);
+            const uint64_t mm = (uint64_t)__shfl((unsigned long long)in_tile, m, 64);
+            seg[it] = before + (uint32_t)__popcll(mm & le_mask) - 1u;       // only read for positions inside the tile
+        }
     }
+    if (lp.debug & 2) return;
+    // 3. one counting pass on (segment rank, upper digit): the order inside a bin is left to step 4, so plain LDS atomics rank the keys.
+    //    The digit shrinks when the tile holds many (then short) segments: nseg << ub bins fit the counter array.
+    constexpr int kBins = CompareShared<W>::kBins, kWordsPerThread = kBins / 2 / kSortThreads;
+    int ub = 31 - __clz((int)((uint32_t)kBins / nseg));
+    if (ub > lp.upper.bits) ub = lp.upper.bits;
+    const uint32_t n_words = ((nseg << ub) + 1u) >> 1;
+    for (uint32_t i = tid; i < n_words; i += kSortThreads) sh.hist[i] = 0;
+    __syncthreads();
+    const int run_shift = 32 - (8 * P + ub);
+    uint32_t br[kIpt];                                                // bin | rank inside the bin << 16
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+        br[it] = ~0u;
+        if (j - first_off < nt) {
+            const uint32_t dg = ub ? (key[it].w[0] << (8 * P)) >> (32 - ub) : 0u;
+            const uint32_t bin = (seg[it] << ub) | dg, sh16 = (bin & 1u) * 16u;
+            const uint32_t old = atomicAdd(&sh.hist[bin >> 1], 1u << sh16);
+            br[it] = bin | (((old >> sh16) & 0xFFFFu) << 16);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the counters, in place (a tile holds <= 4096 keys: 16 bits never overflow)
+        uint32_t wds[kWordsPerThread], run = 0;
+#pragma unroll
+        for (int i = 0; i < kWordsPerThread; ++i) {
+            const uint32_t wi = (uint32_t)tid * kWordsPerThread + i;
+            const uint32_t x = wi < n_words ? sh.hist[wi] : 0u;
+            wds[i] = run | ((run + (x & 0xFFFFu)) << 16);
+            run += (x & 0xFFFFu) + (x >> 16);
+        }
+        const uint32_t base = block_excl_scan<kSortThreads>(run, sh.scratch, nullptr);
+#pragma unroll
+        for (int i = 0; i < kWordsPerThread; ++i) {
+            const uint32_t wi = (uint32_t)tid * kWordsPerThread + i;
+            if (wi < n_words) sh.hist[wi] = wds[i] + base * 0x00010001u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        if (br[it] != ~0u) {
+            const uint32_t bin = br[it] & 0xFFFFu;
+            const uint32_t pos = ((sh.hist[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu) + (br[it] >> 16);
+#pragma unroll
+            for (int w = 0; w < W; ++w) sh.keys[pos].w[w] = key[it].w[w];
+        }
+    }
+    __syncthreads();
+    if (lp.debug & 4) return;
     // 4. runs of equal (prefix, upper digit): every key ranks itself inside its run
-    const int run_shift = 32 - (8 * P + lp.upper.bits);
     const bool skip = (lp.debug & 1) != 0;
     const bool done = run_shift == 0 && W > 1 ? finish_by_comparison<W, (W > 1 ? 1 : 0)>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
                                               : finish_by_comparison<W, 0>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
     if (!done) leave_to_lsd();                                        // global memory still holds the tile as it was
-    (void)kChunk; (void)wv;
 }
 
 // one workgroup per listed range [start[b], end[b]) of whole segments (<= kTile keys, longer ones are skipped: segment_sort_kernel):
@@ -723,6 +855,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_lsd_kernel(Key<W> *keys
     uint32_t seg[kIpt];
     const int n_seg_pass = tile_load<W>(sh, keys, first, nt, lp.P, key, seg);
     const int n_pass = lp.n_low + n_seg_pass;
+    tile_zero_counts<W>(sh);
     for (int pass = 0; pass < n_pass; ++pass) {
         const bool by_seg = pass >= lp.n_low;
         Digit d;
@@ -1120,7 +1253,12 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     lp.lsd_count = d_big_count + 1;
     lp.lsd_cap = (uint32_t)l_blocks;
     lp.debug = ctx->force_lsd_tiles >> 1;
-    hipLaunchKernelGGL((local_sort_kernel<WT>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, lp, d_big, d_big_count, big_cap);
+    if (ub > 0)
+        hipLaunchKernelGGL((local_sort_kernel<WT, true>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, lp, d_big, d_big_count,
+                           big_cap);
+    else
+        hipLaunchKernelGGL((local_sort_kernel<WT, false>), dim3((unsigned)l_blocks), dim3(kSortThreads), 0, stream, src, n_items, lp, d_big, d_big_count,
+                           big_cap);
     MGTA_HIP_CHECK(hipEventRecord(le1, stream));
     uint32_t n_big = 0, n_lsd_tiles = 0;
     MGTA_HIP_CHECK(hipMemcpyAsync(&n_lsd_tiles, d_big_count + 1, 4, hipMemcpyDeviceToHost, stream));
