@@ -510,16 +510,25 @@ struct LocalPlan {
 constexpr uint32_t kMaxAvgRun = 40;    // finish by comparison when the runs of equal (prefix, upper digit) are short on average ...
 constexpr uint32_t kMaxRun = 256;      // ... and none of them is longer than this
 
-// a < b on the significant bits of words FIRST..W-1
-template <int W, int FIRST>
+// a < b on words FIRST..W-1, two words per comparison; MASKED: only the bits m2 / m1 of words W-2 / W-1 count
+template <int W, int FIRST, bool MASKED>
 __device__ __forceinline__ bool key_less(const Key<W> &a, const Key<W> &b, uint32_t m2, uint32_t m1) {
     bool lt = false;
+    auto word = [&](const Key<W> &k, int j) {
+        uint32_t x = k.w[j];
+        if (MASKED && j == W - 1) x &= m1;
+        if (MASKED && j == W - 2) x &= m2;
+        return x;
+    };
 #pragma unroll
-    for (int j = W - 1; j >= FIRST; --j) {
-        uint32_t x = a.w[j], y = b.w[j];
-        if (j == W - 1) { x &= m1; y &= m1; }
-        if (j == W - 2) { x &= m2; y &= m2; }
-        lt = x < y || (x == y && lt);
+    for (int j = W - 1; j >= FIRST; j -= 2) {                          // least significant pair first
+        if (j - 1 >= FIRST) {
+            const uint64_t x = ((uint64_t)word(a, j - 1) << 32) | word(a, j), y = ((uint64_t)word(b, j - 1) << 32) | word(b, j);
+            lt = x < y || (x == y && lt);
+        } else {
+            const uint32_t x = word(a, j), y = word(b, j);
+            lt = x < y || (x == y && lt);
+        }
     }
     return lt;
 }
@@ -638,7 +647,7 @@ __device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[Local
 // run [rs, re) off a few masks; it then finds its rank among the run's keys by comparing words FIRST..W-1 (equal keys keep
 // their order) and goes to its final place in global memory.  Returns false (nothing written) when the runs are longer than
 // kMaxAvgRun on average or one of them is longer than kMaxRun.
-template <int W, int FIRST>
+template <int W, int FIRST, bool MASKED>
 __device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_shift, uint32_t m2,
                                                      uint32_t m1, bool skip_compare) {
     constexpr int kIpt = LocalCfg<W>::kIpt, kWindows = LocalCfg<W>::kTile / 64;
@@ -692,9 +701,9 @@ __device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W
             if (!skip_compare) {
                 r = 0;
 #pragma unroll 2
-                for (uint32_t t = rs; t < j; ++t) r += key_less<W, FIRST>(mine, sh.keys[t], m2, m1) ? 0u : 1u;
+                for (uint32_t t = rs; t < j; ++t) r += key_less<W, FIRST, MASKED>(mine, sh.keys[t], m2, m1) ? 0u : 1u;
 #pragma unroll 2
-                for (uint32_t t = j + 1; t < re; ++t) r += key_less<W, FIRST>(sh.keys[t], mine, m2, m1) ? 1u : 0u;
+                for (uint32_t t = j + 1; t < re; ++t) r += key_less<W, FIRST, MASKED>(sh.keys[t], mine, m2, m1) ? 1u : 0u;
             }
             keys[first + rs + r] = mine;
         }
@@ -835,8 +844,14 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
     if (lp.debug & 4) return;
     // 4. runs of equal (prefix, upper digit): every key ranks itself inside its run
     const bool skip = (lp.debug & 1) != 0;
-    const bool done = run_shift == 0 && W > 1 ? finish_by_comparison<W, (W > 1 ? 1 : 0)>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
-                                              : finish_by_comparison<W, 0>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
+    const bool masked = (lp.mask_last2 & lp.mask_last) != ~0u;
+    bool done;
+    if (run_shift == 0 && W > 1)
+        done = masked ? finish_by_comparison<W, (W > 1 ? 1 : 0), true>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
+                      : finish_by_comparison<W, (W > 1 ? 1 : 0), false>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
+    else
+        done = masked ? finish_by_comparison<W, 0, true>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
+                      : finish_by_comparison<W, 0, false>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
     if (!done) leave_to_lsd();                                        // global memory still holds the tile as it was
 }
 
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_mark_kernel(const Key<W> *k
     }
 }
 
-// E2: write one descriptor per run: start index + (a | b<<3 | group_head<<6)
+// E2: write one descriptor per run: start index + (a | b<<3 | group_head<<6 | bucket_head<<7)
 template <int W>
 __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, const uint64_t *tile_base,
                                                                      uint64_t *sub_start, uint8_t *sub_info) {
@@ -971,14 +986,15 @@ __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W>
         info[it] = 0;
         if (idx < n) {
             Key<W> cur = keys[idx];
-            bool ghead = true;
+            bool ghead = true, bhead = true;
             if (idx == 0) head = true;
             else {
                 Key<W> prv = keys[idx - 1];
                 head = !keys_equal<W>(cur, prv);
                 ghead = !same_km1<W>(cur, prv, k);
+                bhead = (cur.w[0] >> 16) != (prv.w[0] >> 16);             // first key of its bucket
             }
-            info[it] = (uint8_t)(key_a<W>(cur, k) | (key_b<W>(cur) << 3) | ((int)ghead << 6));
+            info[it] = (uint8_t)(key_a<W>(cur, k) | (key_b<W>(cur) << 3) | ((int)ghead << 6) | ((int)bhead << 7));
         }
         uint64_t bal = __ballot(head);
         rank_in_wave[it] = (uint32_t)__popcll(bal & lanemask_lt());
@@ -1075,7 +1091,7 @@ __global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(const uint6
 
 // E5: order-preserving compaction into the output stream + per-bucket boundaries
 template <int W>
-__global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W> *keys, const uint64_t *sub_start, const uint16_t *rec,
+__global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W> *keys, const uint64_t *sub_start, const uint8_t *sub_info, const uint16_t *rec,
                                                                      uint64_t m, uint64_t n_items, const uint64_t *base_e,
                                                                      const uint64_t *base_l, const uint64_t *base_t, int words_per_tip,
                                                                      uint32_t b_lo, uint16_t *out_rec, uint16_t *out_large,
@@ -1105,10 +1121,8 @@ __global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W>
         uint64_t s = s0 + q;
         if (s >= m) break;
         uint64_t first_item = sub_start[s];
-        uint32_t bucket = keys[first_item].w[0] >> 16;
-        bool boundary = s == 0;
-        if (s > 0) boundary = (keys[sub_start[s - 1]].w[0] >> 16) != bucket;
-        if (boundary) {                                            // number of records/large/tips before this bucket
+        if (sub_info[s] & 128) {                                   // number of records/large/tips before this bucket
+            uint32_t bucket = keys[first_item].w[0] >> 16;
             int64_t *bf = bucket_first + (uint64_t)(bucket - b_lo) * 3;
             bf[0] = (int64_t)ie; bf[1] = (int64_t)il; bf[2] = (int64_t)it;
         }
@@ -1564,7 +1578,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             uint16_t *d_out_rec = pool_get<uint16_t>(ctx, S_OUT_REC, n_edges * 2);
             uint16_t *d_out_large = pool_get<uint16_t>(ctx, S_OUT_LARGE, n_large * 2);
             uint32_t *d_out_tips = pool_get<uint32_t>(ctx, S_OUT_TIPS, n_tips * words_per_tip * 4);
-            hipLaunchKernelGGL((emit_write_kernel<W>), dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sorted, sub_start, rec, m,
+            hipLaunchKernelGGL((emit_write_kernel<W>), dim3((unsigned)d_tiles), dim3(kDecideThreads), 0, stream, sorted, sub_start, info, rec, m,
                                n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec, d_out_large, d_out_tips, d_first);
             S.ms_emit += t_ph.stop();
             ctx->last_rec = d_out_rec; ctx->last_n_rec = n_edges; ctx->last_bucket_lo = b_lo; ctx->last_bucket_hi = b_hi;
