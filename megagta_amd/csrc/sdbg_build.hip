@@ -314,84 +314,111 @@ __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uin
 template <int W>
 struct ScatterShared {
     Key<W> keys[kSubTile];
-    uint16_t whist[kSortWaves][256];   // per wave: running count, then base of the wave inside the sub-tile (<= kSubTile: 16 bits)
-    uint32_t start[256];               // first position of each digit value inside the sorted sub-tile
-    uint32_t total[256];
+    uint16_t whist[kSortWaves][256];   // per wave: running count, then position of the wave's first key of the digit value in the sorted sub-tile
     uint64_t gbase[256];               // global destination of the next key of each digit value
+    uint64_t gdelta[256];              // global destination minus position in the sorted sub-tile
     uint32_t scratch[kSortThreads / 64 + 1];
 };
 
-// stable scatter of in[0..n) by digit d to out[gbase[digit]++...], sub-tile by sub-tile (gbase must be set; all threads call)
+// stable scatter of in[0..n) by digit d to out[gbase[digit]++...], sub-tile by sub-tile (gbase must be set and visible; all threads
+// call).  Four workgroup barriers per sub-tile; the next sub-tile's keys are on their way while the current one is placed.
 template <int W>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];               // wave-private row, updated lane-to-lane inside the wave
-    for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
-    __syncthreads();
+    for (int i = lane; i < 256; i += 64) whist[i] = 0;
+    constexpr bool kPrefetch = W <= 4;            // wider keys: the registers are better spent on the keys in flight
+    Key<W> key[kItemsPerThread], nxt[kItemsPerThread];
+    auto load = [&](Key<W> (&dst)[kItemsPerThread], uint64_t sub_base) {   // wave w owns keys [w*512, w*512+512) of the sub-tile, 64 at a time
+#pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            uint64_t idx = sub_base + (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
+            if (idx < n) dst[it] = in[idx];
+        }
+    };
+    load(key, 0);
     for (uint64_t sub_base = 0; sub_base < n; sub_base += kSubTile) {
         uint32_t n_valid = (uint32_t)((n - sub_base) < (uint64_t)kSubTile ? (n - sub_base) : (uint64_t)kSubTile);
-        // phase 1: load (wave w owns keys [w*512, w*512+512) of the sub-tile, 64 at a time) + rank inside the wave chunk
-        Key<W> key[kItemsPerThread];
-        uint32_t dr[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
-#pragma unroll
-        for (int it = 0; it < kItemsPerThread; ++it) {                    // all loads in flight before the first use
-            uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
-            if (j < n_valid) key[it] = in[sub_base + j];
-        }
+        // phase 1: rank inside the wave chunk: digit + peers of every key, then the wave's running counts round by round
+        uint32_t dr[kItemsPerThread], cnt[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
+        get_digits<W, kItemsPerThread>(key, d, dr);
 #pragma unroll
         for (int it = 0; it < kItemsPerThread; ++it) {
             uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
             bool valid = j < n_valid;
-            uint32_t dg = 0;
-            if (valid) dg = get_digit<W>(key[it], d);
-            uint32_t rank, cnt, prev = 0;
-            wave_match(dg, d.bits, valid, rank, cnt);
-            if (valid) {
-                prev = whist[dg];
-                if (rank == cnt - 1) whist[dg] = (uint16_t)(prev + cnt);   // highest peer lane publishes the new count
+            uint32_t dg = valid ? dr[it] : 0u, rank;
+            wave_match(dg, d.bits, valid, rank, cnt[it]);
+            dr[it] = dg | (rank << 8) | ((uint32_t)valid << 31);
+        }
+#pragma unroll
+        for (int it = 0; it < kItemsPerThread; ++it) {
+            if (dr[it] >> 31) {
+                const uint32_t dg = dr[it] & 255u, rank = (dr[it] >> 8) & 0xFFu, prev = whist[dg];
+                if (rank == cnt[it] - 1) whist[dg] = (uint16_t)(prev + cnt[it]);   // highest peer lane publishes the new count
+                dr[it] += prev << 8;
             }
             wave_lds_fence();
-            dr[it] = dg | ((prev + rank) << 8) | ((uint32_t)valid << 31);
+        }
+        if (kPrefetch && sub_base + kSubTile < n) load(nxt, sub_base + kSubTile);
+        __syncthreads();
+        // phase 2: per digit value (threads 0..255 = waves 0..3): total over the waves, scan over the values, wave bases, global bases
+        uint32_t tot = 0, inc = 0;
+        if (wv < 4) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) tot += sh.whist[w][tid];
+            inc = wave_incl_scan(tot);
+            if (lane == 63) sh.scratch[wv] = inc;
         }
         __syncthreads();
-        // phase 2: per digit value: wave bases + sub-tile totals, then exclusive scan over the 256 values
-        uint32_t tot = 0;
-        if (tid < 256) {
+        if (wv < 4) {
+            uint32_t running = inc - tot;
+            for (int w = 0; w < wv; ++w) running += sh.scratch[w];
+            const uint64_t g = sh.gbase[tid];
+            sh.gdelta[tid] = g - running;
+            sh.gbase[tid] = g + tot;
 #pragma unroll
-            for (int w = 0; w < kSortWaves; ++w) {
-                uint32_t c = sh.whist[w][tid];
-                sh.whist[w][tid] = (uint16_t)tot;
-                tot += c;
-            }
-            sh.total[tid] = tot;
+            for (int w = 0; w < kSortWaves; ++w) { uint32_t c = sh.whist[w][tid]; sh.whist[w][tid] = (uint16_t)running; running += c; }
         }
-        uint32_t ex = block_excl_scan<kSortThreads>(tot, sh.scratch, nullptr);
-        if (tid < 256) sh.start[tid] = ex;
         __syncthreads();
         // phase 3: place the keys in sorted order in LDS
 #pragma unroll
         for (int it = 0; it < kItemsPerThread; ++it) {
             if (dr[it] >> 31) {
-                uint32_t dg = dr[it] & 255u, rk = (dr[it] >> 8) & 0x7FFFFFu;
-                sh.keys[sh.start[dg] + sh.whist[wv][dg] + rk] = key[it];
-            }
-        }
-        __syncthreads();
-        // phase 4: stream the sorted sub-tile out; consecutive threads hit consecutive addresses inside a run
+                const uint32_t pos = whist[dr[it] & 255u] + ((dr[it] >> 8) & 0x7FFFFFu);
 #pragma unroll
-        for (int it = 0; it < kItemsPerThread; ++it) {
-            uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
-            if (j < n_valid) {
-                Key<W> kk = sh.keys[j];
-                uint32_t dg = get_digit<W>(kk, d);
-                out[sh.gbase[dg] + (j - sh.start[dg])] = kk;
+                for (int w = 0; w < W; ++w) sh.keys[pos].w[w] = key[it].w[w];
             }
         }
         __syncthreads();
-        // phase 5: advance the global bases, clear the wave counters
-        if (tid < 256) sh.gbase[tid] += sh.total[tid];
-        for (int i = tid; i < kSortWaves * 256; i += kSortThreads) (&sh.whist[0][0])[i] = 0;
-        __syncthreads();
+        for (int i = lane; i < 256; i += 64) whist[i] = 0;                // own row, read by this wave only since the last barrier
+        // phase 4: stream the sorted sub-tile out; consecutive threads hit consecutive addresses inside a run
+        if (kPrefetch) {
+            Key<W> kk[kItemsPerThread];
+            uint32_t dg[kItemsPerThread];
+#pragma unroll
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+                if (j < n_valid) kk[it] = sh.keys[j];
+            }
+            get_digits<W, kItemsPerThread>(kk, d, dg);
+#pragma unroll
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+                if (j < n_valid) out[sh.gdelta[dg[it]] + j] = kk[it];
+            }
+#pragma unroll
+            for (int it = 0; it < kItemsPerThread; ++it) key[it] = nxt[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+                if (j < n_valid) {
+                    Key<W> kk = sh.keys[j];
+                    out[sh.gdelta[get_digit<W>(kk, d)] + j] = kk;
+                }
+            }
+            if (sub_base + kSubTile < n) load(key, sub_base + kSubTile);
+        }
     }
 }
 
@@ -1221,11 +1248,11 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             MGTA_HIP_CHECK(hipEventCreate(&e1));
             MGTA_HIP_CHECK(hipEventRecord(e0, stream));
         }
-        if (ctx->force_lsd_tiles & 8)
+        if (false)
             hipLaunchKernelGGL((radix_scatter_kernel<WT, 4>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
                                d_totals);
         else
-        hipLaunchKernelGGL((radix_scatter_kernel<WT, 8>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+        hipLaunchKernelGGL((radix_scatter_kernel<WT, 4>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
                            d_totals);
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
