@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--k", type=int, default=45, help="CLI k (graph k = k-1, megagta.py:815-816)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--seeds", type=int, default=2000, help="seed k-mers of the A* leg (0 = skip the search leg)")
+    ap.add_argument("--seeds", type=int, default=8000, help="seed k-mers of the A* leg (0 = skip the search leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
