@@ -28,6 +28,7 @@ extern "C" {
 #define MGTA_EUNSUPPORTED (-4)/* feature of the reference not built yet (fails loudly, never silently) */
 #define MGTA_ESINK (-5)       /* caller's sink returned non-zero */
 #define MGTA_EOVERFLOW (-6)   /* per-search arena exhausted after all retries */
+#define MGTA_EINTERNAL (-7)   /* a device-side protocol gave up (bounded wait expired); the call produced nothing */
 
 #define MGTA_NUM_BUCKETS 65536 /* kNumBuckets, cx1_read2sdbg.h:64 (8-character key prefix) */
 

@@ -120,4 +120,55 @@ __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t *scra
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Chained scan across workgroups (decoupled look-back): tile t publishes its aggregate, then walks back over its predecessors
+// until it meets one whose inclusive prefix is known.  state[t] = flag << 62 | value (flag 0 empty, 1 aggregate, 2 inclusive), zeroed
+// by the host before the launch; tiles are numbered by an atomic ticket so every predecessor of a running tile has started.
+// All loads/stores are agent-scope atomics: the L2s of the eight XCDs are not coherent with each other for plain accesses.
+// The walk is bounded: after kChainSpinLimit fruitless polls the tile raises *error and returns (the host fails the call).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr unsigned long long kChainAggregate = 1ull << 62, kChainInclusive = 2ull << 62, kChainValue = (1ull << 62) - 1ull;
+constexpr uint32_t kChainSpinLimit = 1u << 19;   // ~0.5 s of polling
+
+__device__ __forceinline__ uint32_t chain_ticket(uint32_t *ticket, uint32_t *s_slot) {   // all threads call; one barrier
+    if (threadIdx.x == 0) *s_slot = atomicAdd(ticket, 1u);
+    __syncthreads();
+    return wave_uniform(*s_slot);
+}
+
+// one full wave calls with the same (tile, agg); returns the sum of the aggregates of the tiles before `tile`
+__device__ __forceinline__ uint64_t chain_exclusive(unsigned long long *state, uint32_t tile, uint64_t agg, uint32_t *error) {
+    const int lane = lane_id();
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&state[0], kChainInclusive | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&state[tile], kChainAggregate | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    long long base = (long long)tile - 1;                             // the nearest predecessor not summed yet
+    uint32_t spins = 0;
+    for (;;) {
+        const long long t = base - lane;
+        const unsigned long long v = t >= 0 ? __hip_atomic_load(&state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kChainInclusive;
+        const uint32_t flag = (uint32_t)(v >> 62);
+        const uint64_t empty = __ballot(flag == 0), incl = __ballot(flag == 2);
+        const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+        const uint64_t need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);   // lanes up to the first inclusive one
+        if (empty & need) {
+            ++spins;
+            if (spins > kChainSpinLimit || ((spins & 255u) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (lane == 0) atomicExch(error, 1u);                 // give up; every tile still waiting follows within 256 polls
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        excl += wave_sum64(lane <= first_incl ? (uint64_t)(v & kChainValue) : 0ull);
+        if (first_incl < 64) break;
+        base -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&state[tile], kChainInclusive | ((excl + agg) & kChainValue), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 }  // namespace mgta

@@ -210,6 +210,25 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     }
 }
 
+// Items per workgroup of item_scan_kernel in closed form.  With k+1 odd no (k+1)-mer equals its reverse complement, so when
+// every position is solid and every bucket is wanted a read with npos = len - k >= 1 positions yields exactly
+// 2 npos + 4 items (two per position, two more at each end of the read): no edge has to be built to count them.
+__global__ __launch_bounds__(64) void item_count_closed_kernel(const uint64_t *start, uint64_t n_reads, int k, uint32_t *block_count,
+                                                               unsigned long long *n_kmers) {
+    const uint64_t r = (uint64_t)blockIdx.x * kReadsPerBlock + threadIdx.x;
+    uint32_t items = 0, npos = 0;
+    if (r < n_reads) {
+        const int len = (int)(start[r + 1] - start[r]);
+        if (len >= k + 1) { npos = (uint32_t)(len - k); items = 2 * npos + 4; }
+    }
+    items = wave_sum(items);
+    npos = wave_sum(npos);
+    if (threadIdx.x == 0) {
+        block_count[blockIdx.x] = items;
+        if (n_kmers && npos) atomicAdd(n_kmers, (unsigned long long)npos);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 4. LSD radix sort (8-bit digits)
 // ---------------------------------------------------------------------------------------------
@@ -995,13 +1014,24 @@ __global__ __launch_bounds__(kEmitThreads) void emit_mark_kernel(const Key<W> *k
     }
 }
 
-// E2: write one descriptor per run: start index + (a | b<<3 | group_head<<6 | bucket_head<<7)
+// E1+E2: one descriptor per run (distinct key): start index + (a | b<<3 | group_head<<6 | bucket_head<<7), compacted in key order.
+// The keys are read once: the number of runs before a tile comes from a chained scan across the workgroups (device_utils.hpp).
+struct EmitChain {
+    unsigned long long *state;   // [n_tiles], zeroed
+    uint32_t *ticket;            // zeroed
+    uint32_t *error;
+    unsigned long long *total;   // number of runs, written by the last tile
+};
+
 template <int W>
-__global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, const uint64_t *tile_base,
+__global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, EmitChain chain, uint32_t n_tiles,
                                                                      uint64_t *sub_start, uint8_t *sub_info) {
     __shared__ uint32_t s_cnt[kEmitPerThread * (kEmitThreads / 64)];
     __shared__ uint32_t s_scr[kEmitThreads / 64 + 1];
-    uint64_t base = (uint64_t)blockIdx.x * kEmitTile;
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_base;
+    const uint32_t tile = chain_ticket(chain.ticket, &s_tile);
+    uint64_t base = (uint64_t)tile * kEmitTile;
     const int lane = lane_id(), wv = wave_id();
     uint32_t headbits = 0;
     uint32_t rank_in_wave[kEmitPerThread];
@@ -1030,12 +1060,19 @@ __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W>
     }
     __syncthreads();
     // exclusive scan of the 64 (iteration, wave) counts: order of keys = iteration-major, wave, lane
-    uint32_t v = threadIdx.x < kEmitPerThread * (kEmitThreads / 64) ? s_cnt[threadIdx.x] : 0;
-    uint32_t ex = block_excl_scan<kEmitThreads>(v, s_scr, nullptr);
+    uint32_t v = threadIdx.x < kEmitPerThread * (kEmitThreads / 64) ? s_cnt[threadIdx.x] : 0, tile_total = 0;
+    uint32_t ex = block_excl_scan<kEmitThreads>(v, s_scr, &tile_total);
     __syncthreads();
     if (threadIdx.x < kEmitPerThread * (kEmitThreads / 64)) s_cnt[threadIdx.x] = ex;
+    if (wv == 0) {
+        const uint64_t before = chain_exclusive(chain.state, tile, tile_total, chain.error);
+        if (lane == 0) {
+            s_base = before;
+            if (tile + 1 == n_tiles) *chain.total = before + tile_total;
+        }
+    }
     __syncthreads();
-    uint64_t tb = tile_base[blockIdx.x];
+    uint64_t tb = s_base;
 #pragma unroll
     for (int it = 0; it < kEmitPerThread; ++it) {
         if ((headbits >> it) & 1u) {
@@ -1529,7 +1566,12 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         if (first_pass) MGTA_HIP_CHECK(hipMemsetAsync(d_kmers, 0, 8, stream));
         else sa.n_kmers = nullptr;
         uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
-        if (n_blocks) hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+        static_assert(kReadsPerBlock == 64, "item_count_closed_kernel: one lane per read of a workgroup");
+        const bool closed_form = ((k + 1) & 1) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
+        if (n_blocks && closed_form)
+            hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)n_blocks), dim3(64), 0, stream, sa.start, sa.n_reads, k, sa.block_count, sa.n_kmers);
+        else if (n_blocks)
+            hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
         exclusive_scan_u32(stream, d_block_count, n_blocks, d_block_base, d_scan_tmp, d_total);
         uint64_t n_items = 0;
         MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, stream));
@@ -1574,20 +1616,27 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             const Key<W> *sorted = src;
             char *scratch = reinterpret_cast<char *>(dst);
             uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
-            uint32_t *d_tile_heads = pool_get<uint32_t>(ctx, S_TILE_HEADS, e_tiles * 4);
-            uint64_t *d_tile_base = pool_get<uint64_t>(ctx, S_TILE_BASE, e_tiles * 8);
             d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(std::max(n_blocks, e_tiles), n_items / kDecideTile + 1)) * 8);
-            hipLaunchKernelGGL((emit_mark_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, d_tile_heads);
-            exclusive_scan_u32(stream, d_tile_heads, e_tiles, d_tile_base, d_scan_tmp, d_total);
-            uint64_t m = 0;
-            MGTA_HIP_CHECK(hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, stream));
-            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
-            // scratch layout (<= 12 bytes per run <= 12 bytes per key): sub_start u64 | rec u16 | info u8
+            // run descriptors, compacted in key order in one read of the keys (chained scan over the tiles).  Scratch layout for up to
+            // n_items runs (<= 11 bytes per key of a >= 12-byte-per-key buffer): sub_start u64 | rec u16 | info u8
+            if (e_tiles > 0xFFFFFFFFull) { set_error("too many emit tiles"); return MGTA_EUNSUPPORTED; }
+            unsigned long long *d_chain = pool_get<unsigned long long>(ctx, S_TILE_BASE, (e_tiles + 4) * 8);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_chain, 0, (e_tiles + 4) * 8, stream));
+            EmitChain chain;
+            chain.state = d_chain;
+            chain.total = d_chain + e_tiles;
+            chain.ticket = reinterpret_cast<uint32_t *>(d_chain + e_tiles + 1);
+            chain.error = reinterpret_cast<uint32_t *>(d_chain + e_tiles + 2);
             uint64_t *sub_start = reinterpret_cast<uint64_t *>(scratch);
-            uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + m * 8);
-            uint8_t *info = reinterpret_cast<uint8_t *>(scratch + m * 10);
-            hipLaunchKernelGGL((emit_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k,
-                               d_tile_base, sub_start, info);
+            uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + n_items * 8);
+            uint8_t *info = reinterpret_cast<uint8_t *>(scratch + n_items * 10);
+            hipLaunchKernelGGL((emit_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k, chain,
+                               (uint32_t)e_tiles, sub_start, info);
+            unsigned long long chain_out[3] = {0, 0, 0};                   // total, ticket, error
+            MGTA_HIP_CHECK(hipMemcpyAsync(chain_out, d_chain + e_tiles, 24, hipMemcpyDeviceToHost, stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            if ((uint32_t)chain_out[2] != 0) { set_error("internal: chained scan of the emitter timed out"); return MGTA_EINTERNAL; }
+            const uint64_t m = chain_out[0];
             uint64_t d_tiles = (m + kDecideTile - 1) / kDecideTile;
             uint32_t *ce = pool_get<uint32_t>(ctx, S_CNT, d_tiles * 4 * 3), *cl = ce + d_tiles, *ct = cl + d_tiles;
             uint64_t *be = pool_get<uint64_t>(ctx, S_BASE, d_tiles * 8 * 3), *bl = be + d_tiles, *bt = bl + d_tiles;
