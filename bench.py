@@ -152,10 +152,12 @@ def main():
     if args.seeds > 0:
         import tempfile
         from megagta_amd import hmm as hmmlib
-        g = ctx.build_sdbg(rd, k, collect=True, bucket_range=(b0, b1))
         if world > 1:
-            g = mdist.all_gather_edge_stream(g)
-        graph = api.Graph(ctx, g)
+            g = ctx.build_sdbg(rd, k, collect=True, bucket_range=(b0, b1))
+            graph = api.Graph(ctx, mdist.all_gather_edge_stream(g))
+        else:
+            ctx.build_sdbg(rd, k, collect=False)
+            graph = api.Graph(ctx, None, k)                 # row f-4: the stream stays on the device between build and search
         td = tempfile.mkdtemp(prefix="mgta_bench_")
         synth.write_gene_models(mg.genes, td)
         fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))

@@ -115,6 +115,10 @@ int mgta_sdbg_build(mgta_ctx *, const uint32_t *packed_seq, uint64_t n_words, co
 /* From the logical edge stream (all buckets): recs[size], bucket_items[65536], tip labels. */
 int mgta_sdbg_load(mgta_ctx *, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items,
                    const uint32_t *tips, int64_t n_tip_words, int words_per_tip, mgta_sdbg **out);
+/* row f-4 (succinct_dbg.cpp:595-723 without the disk round trip): the graph of the edge stream the LAST
+ * mgta_sdbg_build* call of this context left on the device (one pass over all 65536 buckets), read where it lies — the records
+ * never visit the host.  MGTA_EINVAL when there is no such stream (no build yet, a bucket sub-range, several passes). */
+int mgta_sdbg_load_resident(mgta_ctx *, mgta_sdbg **out);
 void mgta_sdbg_free(mgta_sdbg *);
 int64_t mgta_sdbg_size(const mgta_sdbg *);
 /* batched navigation (test hook + building block of the search): for each edge id the valid

@@ -128,7 +128,15 @@ def export_records_to_torch(ctx: "Context"):
 class Graph:
     """Device-resident succinct de Bruijn graph (mgta_sdbg) <-> SuccinctDBG (succinct_dbg.h:32-247)."""
 
-    def __init__(self, ctx: Context, stream: EdgeStream):
+    def __init__(self, ctx: Context, stream: "EdgeStream | None", k: int = 0):
+        """stream = None: the edge stream the last build of `ctx` left on the device (mgta_sdbg_load_resident; k = that build's k)"""
+        if stream is None:
+            self.ctx, self.k = ctx, k
+            out = C.c_void_p()
+            check(ctx._L.mgta_sdbg_load_resident(ctx.h, C.byref(out)), "mgta_sdbg_load_resident")
+            self.h = out
+            self.size = ctx._L.mgta_sdbg_size(self.h)
+            return
         self.ctx, self.k = ctx, stream.k
         recs = np.ascontiguousarray(stream.records, dtype=np.uint16)
         bi = np.ascontiguousarray(stream.bucket_items, dtype=np.int64)

@@ -83,6 +83,10 @@ struct mgta_ctx {
     const void *last_rec = nullptr;   // records of the last build pass, still resident in the pool
     uint64_t last_n_rec = 0;
     uint32_t last_bucket_lo = 0, last_bucket_hi = 0;
+    const void *last_tips = nullptr;  // tip labels of that pass (words_per_tip words each), and where every bucket starts ([nb][3], -1 = empty)
+    const void *last_first = nullptr;
+    uint64_t last_n_tips = 0;
+    int last_k = 0, last_words_per_tip = 0;
 };
 
 namespace mgta {

@@ -160,7 +160,7 @@ __device__ __forceinline__ uint64_t chain_exclusive(unsigned long long *state, u
                 if (lane == 0) atomicExch(error, 1u);                 // give up; every tile still waiting follows within 256 polls
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(16);
             continue;
         }
         excl += wave_sum64(lane <= first_incl ? (uint64_t)(v & kChainValue) : 0ull);

@@ -5,6 +5,9 @@
 // and RankAndSelect{4Bits,1Bit}::Build (rank_and_select.h:80-150,430-500).
 #include <memory>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "graph.hpp"
@@ -117,9 +120,9 @@ using namespace mgta;
 
 extern "C" {
 
-int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
-                   int64_t n_tip_words, int words_per_tip, mgta_sdbg **out) {
-    if (!ctx || !out || size < 0 || (size > 0 && !recs) || !bucket_items) { set_error("mgta_sdbg_load: bad argument"); return MGTA_EINVAL; }
+// records / tip labels in host memory (`resident` false) or still on the device where the build left them (true: no copy of the records)
+static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
+                      int64_t n_tip_words, int words_per_tip, bool resident, mgta_sdbg **out) {
     try {
         MGTA_HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
@@ -138,18 +141,23 @@ int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, con
         g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
         MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
         g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
-        if (n_tip_words) MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, hipMemcpyHostToDevice, st));
+        if (n_tip_words)
+            MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         d.lines = g->lines.as<GLine>();
         d.tip_labels = g->tips.as<uint32_t>();
         if (size > 0) {
             DevBuf d_recs, d_cnt, d_base, d_tmp, d_tot;
-            d_recs.alloc((size_t)size * 2, &ctx->live_bytes, &ctx->peak_bytes);
-            MGTA_HIP_CHECK(hipMemcpyAsync(d_recs.p, recs, (size_t)size * 2, hipMemcpyHostToDevice, st));
+            const uint16_t *dev_recs = recs;
+            if (!resident) {
+                d_recs.alloc((size_t)size * 2, &ctx->live_bytes, &ctx->peak_bytes);
+                MGTA_HIP_CHECK(hipMemcpyAsync(d_recs.p, recs, (size_t)size * 2, hipMemcpyHostToDevice, st));
+                dev_recs = d_recs.as<uint16_t>();
+            }
             d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
             d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
             d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
             d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, d_recs.as<uint16_t>(), size,
+            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, dev_recs, size,
                                g->lines.as<GLine>(), n_lines, d_cnt.as<uint32_t>());
             uint64_t tot[6];
             for (int c = 0; c < 6; ++c)
@@ -177,6 +185,42 @@ int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, con
         ctx_retain(ctx);
         *out = g.release();
         return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
+                   int64_t n_tip_words, int words_per_tip, mgta_sdbg **out) {
+    if (!ctx || !out || size < 0 || (size > 0 && !recs) || !bucket_items) { set_error("mgta_sdbg_load: bad argument"); return MGTA_EINVAL; }
+    return load_graph(ctx, k, recs, size, bucket_items, tips, n_tip_words, words_per_tip, false, out);
+}
+
+int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
+    if (!ctx || !out) { set_error("mgta_sdbg_load_resident: bad argument"); return MGTA_EINVAL; }
+    if (ctx->last_k == 0 || ctx->last_bucket_lo != 0 || ctx->last_bucket_hi != (uint32_t)MGTA_NUM_BUCKETS || (ctx->last_n_rec && !ctx->last_rec)) {
+        set_error("mgta_sdbg_load_resident: the last build of this context did not leave a whole edge stream on the device "
+                  "(none yet, a bucket sub-range, or several memory-bound passes)");
+        return MGTA_EINVAL;
+    }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        // records before every bucket (-1 = empty bucket) -> records per bucket
+        std::vector<int64_t> first((size_t)MGTA_NUM_BUCKETS * 3), items(MGTA_NUM_BUCKETS);
+        if (ctx->last_n_rec) {
+            MGTA_HIP_CHECK(hipMemcpyAsync(first.data(), ctx->last_first, first.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            std::fill(first.begin(), first.end(), (int64_t)-1);
+        }
+        int64_t nxt = (int64_t)ctx->last_n_rec;
+        for (int64_t b = MGTA_NUM_BUCKETS - 1; b >= 0; --b) {
+            int64_t f = first[(size_t)b * 3];
+            if (f < 0) f = nxt;
+            items[(size_t)b] = nxt - f;
+            nxt = f;
+        }
+        return load_graph(ctx, ctx->last_k, static_cast<const uint16_t *>(ctx->last_rec), (int64_t)ctx->last_n_rec, items.data(),
+                          static_cast<const uint32_t *>(ctx->last_tips), (int64_t)ctx->last_n_tips * ctx->last_words_per_tip,
+                          ctx->last_words_per_tip, true, out);
     } catch (const HipError &e) { return e.code; }
 }
 

@@ -1023,14 +1023,16 @@ struct EmitChain {
     unsigned long long *total;   // number of runs, written by the last tile
 };
 
-template <int W>
+// TICKET = false numbers the tiles by blockIdx (workgroups are dispatched in that order on this hardware, which nothing guarantees):
+// if a tile ever waits in vain the bounded walk raises chain.error and the host repeats the launch with TICKET = true.
+template <int W, bool TICKET>
 __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, EmitChain chain, uint32_t n_tiles,
                                                                      uint64_t *sub_start, uint8_t *sub_info) {
     __shared__ uint32_t s_cnt[kEmitPerThread * (kEmitThreads / 64)];
     __shared__ uint32_t s_scr[kEmitThreads / 64 + 1];
     __shared__ uint32_t s_tile;
     __shared__ unsigned long long s_base;
-    const uint32_t tile = chain_ticket(chain.ticket, &s_tile);
+    const uint32_t tile = TICKET ? chain_ticket(chain.ticket, &s_tile) : blockIdx.x;
     uint64_t base = (uint64_t)tile * kEmitTile;
     const int lane = lane_id(), wv = wave_id();
     uint32_t headbits = 0;
@@ -1621,7 +1623,6 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             // n_items runs (<= 11 bytes per key of a >= 12-byte-per-key buffer): sub_start u64 | rec u16 | info u8
             if (e_tiles > 0xFFFFFFFFull) { set_error("too many emit tiles"); return MGTA_EUNSUPPORTED; }
             unsigned long long *d_chain = pool_get<unsigned long long>(ctx, S_TILE_BASE, (e_tiles + 4) * 8);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_chain, 0, (e_tiles + 4) * 8, stream));
             EmitChain chain;
             chain.state = d_chain;
             chain.total = d_chain + e_tiles;
@@ -1630,11 +1631,19 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             uint64_t *sub_start = reinterpret_cast<uint64_t *>(scratch);
             uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + n_items * 8);
             uint8_t *info = reinterpret_cast<uint8_t *>(scratch + n_items * 10);
-            hipLaunchKernelGGL((emit_compact_kernel<W>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k, chain,
-                               (uint32_t)e_tiles, sub_start, info);
             unsigned long long chain_out[3] = {0, 0, 0};                   // total, ticket, error
-            MGTA_HIP_CHECK(hipMemcpyAsync(chain_out, d_chain + e_tiles, 24, hipMemcpyDeviceToHost, stream));
-            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                MGTA_HIP_CHECK(hipMemsetAsync(d_chain, 0, (e_tiles + 4) * 8, stream));
+                if (attempt == 0 && !ctx->force_full_lsd)
+                    hipLaunchKernelGGL((emit_compact_kernel<W, false>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k, chain,
+                                       (uint32_t)e_tiles, sub_start, info);
+                else
+                    hipLaunchKernelGGL((emit_compact_kernel<W, true>), dim3((unsigned)e_tiles), dim3(kEmitThreads), 0, stream, sorted, n_items, k, chain,
+                                       (uint32_t)e_tiles, sub_start, info);
+                MGTA_HIP_CHECK(hipMemcpyAsync(chain_out, d_chain + e_tiles, 24, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                if ((uint32_t)chain_out[2] == 0) break;
+            }
             if ((uint32_t)chain_out[2] != 0) { set_error("internal: chained scan of the emitter timed out"); return MGTA_EINTERNAL; }
             const uint64_t m = chain_out[0];
             uint64_t d_tiles = (m + kDecideTile - 1) / kDecideTile;
@@ -1658,6 +1667,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                                n_items, be, bl, bt, words_per_tip, b_lo, d_out_rec, d_out_large, d_out_tips, d_first);
             S.ms_emit += t_ph.stop();
             ctx->last_rec = d_out_rec; ctx->last_n_rec = n_edges; ctx->last_bucket_lo = b_lo; ctx->last_bucket_hi = b_hi;
+            ctx->last_tips = d_out_tips; ctx->last_n_tips = n_tips; ctx->last_first = d_first; ctx->last_k = k; ctx->last_words_per_tip = words_per_tip;
             // ---- device -> host
             if (sink) {
                 t_ph.start();
@@ -1680,6 +1690,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             }
         } else {
             h_rec.clear(); h_large.clear(); h_tips.clear();
+            ctx->last_rec = nullptr; ctx->last_n_rec = 0; ctx->last_bucket_lo = b_lo; ctx->last_bucket_hi = b_hi;
+            ctx->last_tips = nullptr; ctx->last_n_tips = 0; ctx->last_first = nullptr; ctx->last_k = k; ctx->last_words_per_tip = words_per_tip;
         }
         S.n_edges += (int64_t)n_edges; S.n_large += (int64_t)n_large; S.n_tips += (int64_t)n_tips;
         if (sink) {

@@ -88,3 +88,29 @@ def test_empty_graph(ctx):
     g = api.Graph(ctx, s)
     assert g.size == 0
     assert g.index_edges(["A" * 30]).tolist() == [-1]
+
+
+@pytest.mark.parametrize("case,k", [("toy", 44), ("ragged", 29)])
+def test_graph_from_device_resident_stream(ctx, golden_dir, case, k):
+    """row f-4: the graph built from the edge stream where the build left it (no host round trip) answers like the one loaded from host
+    records, on every edge; and it is refused when the last build did not leave a whole stream"""
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, case, "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    stream = ctx.build_sdbg(rd, k)
+    g_host = api.Graph(ctx, stream)
+    ctx.build_sdbg(rd, k, collect=False)                   # nothing handed to the host at all
+    g_dev = api.Graph(ctx, None, k)
+    assert g_dev.size == g_host.size == stream.records.size
+    ids = np.arange(g_host.size)
+    d0, o0 = g_host.outgoing(ids)
+    d1, o1 = g_dev.outgoing(ids)
+    assert np.array_equal(d0, d1) and np.array_equal(o0, o1)
+    # index lookups go through the tip labels, which also stayed on the device
+    _, qs = H.parse_probe_graph(H.gz_lines(os.path.join(golden_dir, case, f"graph_k{k}.txt.gz")))
+    deg, out = g_dev.outgoing([q["e"] for q in qs])
+    for q, d, o in zip(qs, deg.tolist(), out.tolist()):
+        assert d == q["od"] and o[:max(d, 0)] == q["out"]
+    ctx.build_sdbg(rd, k, collect=False, bucket_range=(0, 30000))
+    with pytest.raises(api.MegaGtaError):
+        api.Graph(ctx, None, k)
