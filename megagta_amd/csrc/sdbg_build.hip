@@ -213,20 +213,24 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
 // Items per workgroup of item_scan_kernel in closed form.  With k+1 odd no (k+1)-mer equals its reverse complement, so when
 // every position is solid and every bucket is wanted a read with npos = len - k >= 1 positions yields exactly
 // 2 npos + 4 items (two per position, two more at each end of the read): no edge has to be built to count them.
-__global__ __launch_bounds__(64) void item_count_closed_kernel(const uint64_t *start, uint64_t n_reads, int k, uint32_t *block_count,
-                                                               unsigned long long *n_kmers) {
-    const uint64_t r = (uint64_t)blockIdx.x * kReadsPerBlock + threadIdx.x;
-    uint32_t items = 0, npos = 0;
-    if (r < n_reads) {
-        const int len = (int)(start[r + 1] - start[r]);
-        if (len >= k + 1) { npos = (uint32_t)(len - k); items = 2 * npos + 4; }
+__global__ __launch_bounds__(256) void item_count_closed_kernel(const uint64_t *start, uint64_t n_reads, uint64_t n_blocks, int k,
+                                                                uint32_t *block_count, unsigned long long *n_kmers) {
+    // a wave per 16 consecutive workgroups of item_scan_kernel (64 reads each), one lane per read
+    unsigned long long kmers = 0;
+    for (int q = 0; q < 16; ++q) {
+        const uint64_t blk = ((uint64_t)blockIdx.x * 4 + wave_id()) * 16 + q;
+        if (blk >= n_blocks) break;
+        const uint64_t r = blk * kReadsPerBlock + lane_id();
+        uint32_t items = 0, npos = 0;
+        if (r < n_reads) {
+            const int len = (int)(start[r + 1] - start[r]);
+            if (len >= k + 1) { npos = (uint32_t)(len - k); items = 2 * npos + 4; }
+        }
+        items = wave_sum(items);
+        kmers += wave_sum(npos);
+        if (lane_id() == 0) block_count[blk] = items;
     }
-    items = wave_sum(items);
-    npos = wave_sum(npos);
-    if (threadIdx.x == 0) {
-        block_count[blockIdx.x] = items;
-        if (n_kmers && npos) atomicAdd(n_kmers, (unsigned long long)npos);
-    }
+    if (lane_id() == 0 && n_kmers && kmers) atomicAdd(n_kmers, kmers);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1571,7 +1575,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         static_assert(kReadsPerBlock == 64, "item_count_closed_kernel: one lane per read of a workgroup");
         const bool closed_form = ((k + 1) & 1) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
         if (n_blocks && closed_form)
-            hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)n_blocks), dim3(64), 0, stream, sa.start, sa.n_reads, k, sa.block_count, sa.n_kmers);
+            hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(256), 0, stream, sa.start, sa.n_reads, n_blocks, k,
+                               sa.block_count, sa.n_kmers);
         else if (n_blocks)
             hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
         exclusive_scan_u32(stream, d_block_count, n_blocks, d_block_base, d_scan_tmp, d_total);
