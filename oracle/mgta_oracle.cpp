@@ -125,15 +125,19 @@ void emit_bucket(const std::array<uint32_t, W> *it, int64_t n, int k, int words_
 
 // Enumerate the sort items of one read (stage 2, every position solid).
 // s2_lv0_calc_bucket_size / s2_lv1_fill_offset / s2_lv2_extract_substr_, cx1_read2sdbg_s2.cpp:252-315,475-677
+// `solid` (may be null = every position solid, the -m 1 case): one flag per (k+1)-mer position of the read; items are generated for the
+// solid positions only and the `$` items at the ends of every RUN of solid positions (s2.cpp:276-297,528-565).
 template <int W, class F>
-inline void for_each_item(const uint8_t *r, int len, int k, F &&f) {
+inline void for_each_item(const uint8_t *r, int len, int k, F &&f, const uint8_t *solid = nullptr) {
     if (len < k + 1) return;                                     // s2.cpp:262-264
     std::vector<uint8_t> rc(k + 1);
+    const int npos = len - k;
     for (int p = 0; p + k < len; ++p) {
+        if (solid && !solid[p]) continue;
         const uint8_t *e = r + p;                                // edge = (k+1)-mer
         for (int i = 0; i <= k; ++i) rc[i] = 3 - e[k - i];
         bool pal = std::equal(e, e + k + 1, rc.begin());         // s2.cpp:278
-        bool first = (p == 0), last = (p + k == len - 1);
+        bool first = (p == 0) || (solid && !solid[p - 1]), last = (p == npos - 1) || (solid && !solid[p + 1]);
         if (first) {                                             // left $   (s2.cpp:531-540)
             f(make_key<W>(e, k, k, kDollar));
             if (!pal) f(make_key<W>(rc.data() + 2, k - 1, k, rc[1]));
@@ -147,8 +151,10 @@ inline void for_each_item(const uint8_t *r, int len, int k, F &&f) {
     }
 }
 
+using SolidFlags = std::vector<std::vector<uint8_t>>;           // [read][(k+1)-mer position]; an empty row = every position solid
+
 template <int W>
-Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, int k, int n_threads) {
+Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, int k, int n_threads, const SolidFlags *solid = nullptr) {
     using Key = std::array<uint32_t, W>;
     auto *s = new Stream;
     s->k = k;
@@ -162,10 +168,11 @@ Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t
         for (int i = 0; i < len; ++i) buf[i] = (uint8_t)base_at(packed, start_idx[r] + i);
         return len;
     };
+    auto solid_of = [&](uint64_t r) -> const uint8_t * { return (solid && !(*solid)[r].empty()) ? (*solid)[r].data() : nullptr; };
     // pass 1: bucket sizes (bucket = first 8 characters of the key, s2.cpp:832 `key[0] >> 16`)
     for (uint64_t r = 0; r < n_reads; ++r) {
         int len = decode(r);
-        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { ++cnt[(key[0] >> 16) + 1]; });
+        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { ++cnt[(key[0] >> 16) + 1]; }, solid_of(r));
     }
     for (int b = 0; b < kBuckets; ++b) cnt[b + 1] += cnt[b];
     int64_t total = cnt[kBuckets];
@@ -175,7 +182,7 @@ Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t
     // pass 2: materialise the keys bucket by bucket
     for (uint64_t r = 0; r < n_reads; ++r) {
         int len = decode(r);
-        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { items[(size_t)fill[key[0] >> 16]++] = key; });
+        for_each_item<W>(buf.data(), len, k, [&](const Key &key) { items[(size_t)fill[key[0] >> 16]++] = key; }, solid_of(r));
     }
     // per bucket: sort ascending as W big-endian words (lv2_cpu_sort.h:87-150) and emit
     std::vector<BucketOut> outs(kBuckets);
@@ -193,6 +200,168 @@ Stream *build_stream(const uint32_t *packed, const uint64_t *start_idx, uint64_t
         s->tips.insert(s->tips.end(), outs[b].tips.begin(), outs[b].tips.end());
     }
     return s;
+}
+
+// =================================================================================================
+// 1b. stage 1 (-m >= 2): which (k+1)-mer positions of which read are solid, mercy edges, the .counting histogram
+//     cx1_read2sdbg_s1.cpp:177-229,408-596 (items), :671-830 (s1_lv2_output_), :905-951 (s1_post_proc);
+//     cx1_read2sdbg_s2.cpp:106-250 (s2_read_mercy_prepare)
+// Plain restatement: every (k-1)-mer S of every read is listed once, in its smaller orientation, with the characters around
+// it:  prev head [S] tail next.  The multiplicity of (head S tail) is the multiplicity of that (k+1)-mer.
+// =================================================================================================
+struct S1Item {
+    std::string S;                 // k-1 characters 0..3
+    uint8_t head, tail, prev, next;   // 0..3 or kDollar
+    uint64_t abs;                  // absolute base index of S[0] in the concatenated reads (start_idx[read] + offset)
+    uint8_t strand;
+};
+
+struct Stage1Out {
+    SolidFlags solid;
+    std::vector<int64_t> counting = std::vector<int64_t>(65536, 0);   // [m] = number of distinct (k+1)-mers seen m times (m capped at 65535)
+    int64_t n_mercy = 0;
+};
+
+static Stage1Out stage1(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, uint64_t n_short, int k, int threshold,
+                        bool need_mercy) {
+    Stage1Out out;
+    out.solid.resize(n_reads);
+    const int km1 = k - 1;
+    std::vector<S1Item> items;
+    auto comp = [](int c) { return c == kDollar ? kDollar : 3 - c; };
+    std::vector<uint8_t> buf;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        const int len = int(start_idx[r + 1] - start_idx[r]);
+        if (len < k + 1) continue;                                                    // s1.cpp:187-189
+        if (r < n_short) out.solid[r].assign(len - k, 0);                             // assist sequences stay "all solid" (empty row), s2.cpp:276
+        buf.resize(len);
+        for (int i = 0; i < len; ++i) buf[i] = (uint8_t)base_at(packed, start_idx[r] + i);
+        const int n_off = len - k + 2;                                                // (k-1)-mers of the read
+        for (int o = 0; o < n_off; ++o) {
+            std::string f(buf.begin() + o, buf.begin() + o + km1), rc(km1, 0);
+            for (int i = 0; i < km1; ++i) rc[i] = (char)(3 - f[km1 - 1 - i]);
+            const int head = o > 0 ? buf[o - 1] : kDollar, prev = o > 1 ? buf[o - 2] : kDollar;            // s1.cpp:534-563
+            const int tail = o + km1 < len ? buf[o + km1] : kDollar, next = o + k < len ? buf[o + k] : kDollar;
+            bool fwd, rev;
+            if (o == 0 || o == n_off - 1) fwd = rev = true;                           // the first / last (k-1)-mer goes in both strands (s1.cpp:470-472,503-506)
+            else if (f != rc) { fwd = f < rc; rev = !fwd; }
+            else { fwd = head <= 3 - tail; rev = !fwd; }                              // palindrome (s1.cpp:488-497)
+            const uint64_t abs = start_idx[r] + (uint64_t)o;
+            if (fwd) items.push_back(S1Item{f, (uint8_t)head, (uint8_t)tail, (uint8_t)prev, (uint8_t)next, abs, 0});
+            if (rev)                                                                  // s1.cpp:575-582
+                items.push_back(S1Item{rc, (uint8_t)comp(tail), (uint8_t)comp(head), (uint8_t)comp(next), (uint8_t)comp(prev), abs, 1});
+        }
+    }
+    std::sort(items.begin(), items.end(), [](const S1Item &a, const S1Item &b) {
+        if (a.S != b.S) return a.S < b.S;
+        if (a.head != b.head) return a.head < b.head;
+        return a.tail < b.tail;
+    });
+    std::vector<uint64_t> cand;                                                      // mercy candidates: (absolute k-mer index << 2) | code
+    auto read_of = [&](uint64_t abs) {                                               // SequencePackage::get_id, sequence_package.h:164-188
+        return (uint64_t)(std::upper_bound(start_idx, start_idx + n_reads, abs) - start_idx) - 1;
+    };
+    for (size_t g0 = 0; g0 < items.size();) {
+        size_t g1 = g0;
+        while (g1 < items.size() && items[g1].S == items[g0].S) ++g1;
+        // 5 x 5 count tables of the group (s1.cpp:716-748); '$' never counts towards a mask
+        int64_t cph[4][4] = {}, ctn[4][4] = {}, cht[4][4] = {};
+        for (size_t i = g0; i < g1; ++i) {
+            const S1Item &it = items[i];
+            if (it.prev < 4 && it.head < 4) ++cph[it.prev][it.head];
+            if (it.tail < 4 && it.next < 4) ++ctn[it.tail][it.next];
+            if (it.head < 4 && it.tail < 4) ++cht[it.head][it.tail];
+        }
+        int has_in = 0, has_out = 0, l_has_out = 0, r_has_in = 0;
+        for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 4; ++q) {
+                if (cph[q][j] >= threshold) has_in |= 1 << j;
+                if (ctn[j][q] >= threshold) has_out |= 1 << j;
+                if (cht[j][q] >= threshold) { l_has_out |= 1 << j; r_has_in |= 1 << q; }
+            }
+        for (size_t h0 = g0; h0 < g1;) {                                             // sub-groups of equal (head, tail): one (k+1)-mer each
+            size_t h1 = h0;
+            while (h1 < g1 && items[h1].head == items[h0].head && items[h1].tail == items[h0].tail) ++h1;
+            const int hd = items[h0].head, tl = items[h0].tail;
+            const bool real = hd != kDollar && tl != kDollar;
+            const int64_t cnt = (int64_t)(h1 - h0);
+            if (real) ++out.counting[(size_t)std::min<int64_t>(cnt, 65535)];           // s1.cpp:756-758
+            const bool solid = real && cnt >= threshold;
+            for (size_t i = h0; i < h1; ++i) {                                         // s1.cpp:750-828
+                const S1Item &it = items[i];
+                const uint64_t read_id = read_of(it.abs);
+                if (read_id >= n_short) continue;
+                const uint64_t st = start_idx[read_id];
+                const int64_t offset = (int64_t)(it.abs - st) - 1;                     // position of the (k+1)-mer head S tail in the read
+                const int64_t l_off = it.strand == 0 ? offset : offset + 1, r_off = it.strand == 0 ? offset + 1 : offset;
+                auto add = [&](int64_t off, int code) { if (need_mercy) cand.push_back(((st + (uint64_t)off) << 2) | (uint64_t)code); };
+                if (solid) {
+                    out.solid[read_id][(size_t)offset] = 1;
+                    if (!((has_in >> hd) & 1)) add(l_off, 1 + it.strand);
+                    if (!((has_out >> tl) & 1)) add(r_off, 2 - it.strand);
+                } else {
+                    if (hd < 4) {
+                        if ((l_has_out >> hd) & 1) add(l_off, ((has_in >> hd) & 1) ? 0 : 1 + it.strand);
+                        else if ((has_in >> hd) & 1) add(l_off, 2 - it.strand);
+                    }
+                    if (tl < 4) {
+                        if ((r_has_in >> tl) & 1) add(r_off, ((has_out >> tl) & 1) ? 0 : 2 - it.strand);
+                        else if ((has_out >> tl) & 1) add(r_off, 1 + it.strand);
+                    }
+                }
+            }
+            h0 = h1;
+        }
+        g0 = g1;
+    }
+    // mercy edges: a stretch of non-solid positions between a k-mer with no solid out-edge and a later one with no solid in-edge
+    // of the same read is made solid (s2.cpp:164-231)
+    std::sort(cand.begin(), cand.end());
+    for (size_t i = 0; i < cand.size();) {
+        const uint64_t read_id = read_of(cand[i] >> 2), st = start_idx[read_id];
+        const int len = int(start_idx[read_id + 1] - st);
+        std::vector<uint8_t> no_in(len + 2, 0), no_out(len + 2, 0), has_solid_kmer(len + 2, 0);
+        int first_0_out = 1 << 30, last_0_in = -1;
+        for (; i < cand.size() && read_of(cand[i] >> 2) == read_id; ++i) {
+            const int off = int((cand[i] >> 2) - st), code = int(cand[i] & 3);
+            if (code == 2) { no_out[off] = 1; first_0_out = std::min(first_0_out, off); }
+            else if (code == 1) { no_in[off] = 1; last_0_in = std::max(last_0_in, off); }
+            has_solid_kmer[off] = 1;
+        }
+        if (last_0_in < first_0_out) continue;
+        std::vector<uint8_t> &sol = out.solid[read_id];
+        for (int p = 0; p + k < len; ++p)
+            if (sol[p]) has_solid_kmer[p] = has_solid_kmer[p + 1] = 1;
+        int last_no_out = -1;
+        for (int p = 0; p + k <= len; ++p) {
+            if (no_in[p] && last_no_out != -1) {
+                for (int j = last_no_out; j < p; ++j) sol[j] = 1;
+                out.n_mercy += p - last_no_out;
+            }
+            if (has_solid_kmer[p]) last_no_out = -1;
+            if (no_out[p]) last_no_out = p;
+        }
+    }
+    return out;
+}
+
+template <int W>
+static Stream *build_dispatch(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, int k, int n_threads, const SolidFlags *solid) {
+    return build_stream<W>(packed, start_idx, n_reads, k, n_threads, solid);
+}
+static Stream *build_any(const uint32_t *packed, const uint64_t *start_idx, uint64_t n_reads, int k, int n_threads, const SolidFlags *solid) {
+    const int W = (2 * k + 4 + 31) / 32;                          // words_per_substring, s2.cpp:331
+    switch (W) {
+    case 1: return build_dispatch<1>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 2: return build_dispatch<2>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 3: return build_dispatch<3>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 4: return build_dispatch<4>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 5: return build_dispatch<5>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 6: return build_dispatch<6>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 7: return build_dispatch<7>(packed, start_idx, n_reads, k, n_threads, solid);
+    case 8: return build_dispatch<8>(packed, start_idx, n_reads, k, n_threads, solid);
+    default: return build_dispatch<9>(packed, start_idx, n_reads, k, n_threads, solid);
+    }
 }
 
 // =================================================================================================
@@ -885,6 +1054,22 @@ orc_stream *orc_sdbg_build(const uint32_t *packed, uint64_t n_words, const uint6
     default: s = build_stream<9>(packed, start_idx, n_reads, k, n_threads); break;
     }
     return static_cast<orc_stream *>(s);
+}
+
+orc_stream *orc_sdbg_build_solid(const uint32_t *packed, uint64_t n_words, const uint64_t *start_idx, uint64_t n_reads, uint64_t n_short,
+                                 int k, int min_count, int need_mercy, int n_threads, int64_t *counting, int64_t *n_mercy) {
+    (void)n_words;
+    if (k < 9 || k > 127 || min_count < 1) return nullptr;
+    if (n_short > n_reads) n_short = n_reads;
+    if (min_count == 1) {                                           // build_graph.cpp:96-118: stage 1 is skipped
+        if (counting) std::fill(counting, counting + 65536, 0);
+        if (n_mercy) *n_mercy = 0;
+        return static_cast<orc_stream *>(build_any(packed, start_idx, n_reads, k, n_threads, nullptr));
+    }
+    Stage1Out s1 = stage1(packed, start_idx, n_reads, n_short, k, min_count, need_mercy != 0);
+    if (counting) std::copy(s1.counting.begin(), s1.counting.end(), counting);
+    if (n_mercy) *n_mercy = s1.n_mercy;
+    return static_cast<orc_stream *>(build_any(packed, start_idx, n_reads, k, n_threads, &s1.solid));
 }
 
 orc_stream *orc_sdbg_read(const char *prefix) {                    // SdbgReader, sdbg_multi_io.h:240-382

@@ -24,6 +24,12 @@ typedef struct orc_stream orc_stream;
 /* stage-2 build, -c 1 semantics (every position solid)  [cx1_read2sdbg_s2.cpp:252-315,475-677,742-835] */
 orc_stream *orc_sdbg_build(const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx,
                            uint64_t n_reads, int k, int n_threads);
+/* -m min_count [--need_mercy]: stage 1 (solid (k+1)-mers per read position, mercy edges) then stage 2 over the solid runs
+ * [cx1_read2sdbg_s1.cpp:177-951, cx1_read2sdbg_s2.cpp:106-250,276-297].  Reads >= n_short (assist sequences) are always solid.
+ * counting[65536] (optional): number of distinct (k+1)-mers per multiplicity, what s1_post_proc turns into PREFIX.counting. */
+orc_stream *orc_sdbg_build_solid(const uint32_t *packed_seq, uint64_t n_words, const uint64_t *start_idx, uint64_t n_reads,
+                                 uint64_t n_short, int k, int min_count, int need_mercy, int n_threads, int64_t *counting,
+                                 int64_t *n_mercy);
 /* decode <prefix>.sdbg_info + <prefix>.sdbg.N into the logical stream  [sdbg_multi_io.h:240-382] */
 orc_stream *orc_sdbg_read(const char *prefix);
 void orc_stream_free(orc_stream *);

@@ -39,6 +39,7 @@ def lib():
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
     sig = {
         "orc_sdbg_build": (vp, [vp, C.c_uint64, vp, C.c_uint64, i32, i32]),
+        "orc_sdbg_build_solid": (vp, [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, i32, i32, i32, i32, vp, vp]),
         "orc_sdbg_read": (vp, [C.c_char_p]),
         "orc_stream_free": (None, [vp]),
         "orc_stream_k": (i32, [vp]), "orc_stream_words_per_tip": (i32, [vp]),
@@ -111,6 +112,21 @@ class Stream:
         packed = np.ascontiguousarray(packed, dtype=np.uint32)
         start_idx = np.ascontiguousarray(start_idx, dtype=np.uint64)
         return cls(lib().orc_sdbg_build(packed.ctypes.data, packed.size, start_idx.ctypes.data, start_idx.size - 1, k, threads))
+
+    @classmethod
+    def build_solid(cls, packed: np.ndarray, start_idx: np.ndarray, k: int, min_count: int, need_mercy: bool, n_short: int | None = None,
+                    threads: int = 1) -> "Stream":
+        """`buildgraph -m min_count [--need_mercy]`; .counting (int64[65536], per-multiplicity counts) and .n_mercy are attached"""
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        start_idx = np.ascontiguousarray(start_idx, dtype=np.uint64)
+        n_reads = start_idx.size - 1
+        counting = np.zeros(65536, dtype=np.int64)
+        n_mercy = C.c_int64(0)
+        st = cls(lib().orc_sdbg_build_solid(packed.ctypes.data, packed.size, start_idx.ctypes.data, n_reads,
+                                            n_reads if n_short is None else n_short, k, min_count, int(need_mercy), threads,
+                                            counting.ctypes.data, C.byref(n_mercy)))
+        st.counting, st.n_mercy = counting, n_mercy.value
+        return st
 
     @classmethod
     def read(cls, prefix: str) -> "Stream":

@@ -44,6 +44,31 @@ def test_sdbg_stream_ragged(oracle, golden_dir, k):
         assert fx["num_large"] > 0      # the >254 path is really exercised
 
 
+def _counting_md5(hist) -> str:
+    """PREFIX.counting as s1_post_proc writes it (cx1_read2sdbg_s1.cpp:923-930): `i cumulative_count` for i = 1..65535"""
+    acc = np.cumsum(hist[1:])
+    return hashlib.md5("".join(f"{i} {int(a)}\n" for i, a in zip(range(1, 65536), acc)).encode()).hexdigest()
+
+
+@pytest.mark.parametrize("sub", ["toy", "ragged"])
+def test_sdbg_stream_min_count_and_mercy(oracle, golden_dir, sub):
+    """Stage 1 of the oracle (solid (k+1)-mers, mercy edges, .counting) + stage 2 over the solid runs == the reference's
+    `buildgraph -m M [--need_mercy]` (cx1_read2sdbg_s1.cpp, cx1_read2sdbg_s2.cpp:106-250)."""
+    import json
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, sub, "reads.lib"))
+    cases = json.load(open(os.path.join(golden_dir, sub, "sdbg_streams_solid.json")))
+    ran = 0
+    for tag, fx in cases.items():
+        if fx.get("reference_crashed"):
+            continue
+        k, m, mercy = int(tag.split("_")[0][1:]), int(tag.split("_")[1][1:]), tag.endswith("_mercy")
+        st = oracle.Stream.build_solid(packed, start, k, m, mercy, threads=4)
+        _stream_matches(st.edges(), fx)
+        assert _counting_md5(st.counting) == fx["counting_md5"], tag
+        ran += 1
+    assert ran >= 4
+
+
 def _check_graph(oracle, stream, lines):
     g = oracle.Graph(stream)
     hdr, qs = H.parse_probe_graph(lines)

@@ -211,3 +211,31 @@ def test_redundant_reads_long_runs(ctx, oracle, k):
     g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
     o = oracle.Stream.build(packed, start, k, threads=4).edges()
     _same(g, o)
+
+
+@pytest.mark.parametrize("k,m,mercy,assist", [(21, 2, True, 0), (31, 3, False, 12), (44, 2, True, 12), (63, 2, True, 0)])
+def test_min_count_vs_oracle_seeded(ctx, oracle, k, m, mercy, assist):
+    """stage 1 + stage 2 against the oracle's restatement on seeded reads no golden covers: coverage ~8x with substitution errors
+    (solid and non-solid stretches, mercy gaps), ragged lengths, optional assist sequences (always solid, reads >= n_short)"""
+    rng = np.random.default_rng(100 * k + m)
+    genome = rng.integers(0, 4, 6000).astype(np.uint8)
+    reads = []
+    for _ in range(700):
+        L = int(rng.integers(k - 2, 200))
+        p = int(rng.integers(0, genome.size - L))
+        r = genome[p:p + L].copy()
+        err = rng.random(L) < 0.01
+        r[err] = (r[err] + rng.integers(1, 4, int(err.sum()))) & 3
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    for _ in range(assist):
+        p = int(rng.integers(0, genome.size - 400))
+        reads.append(genome[p:p + 400].copy())
+    packed, start = readlib.pack_for_build(reads)
+    n_short = len(reads) - assist
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k, min_count=m, need_mercy=mercy, n_short_reads=n_short)
+    o = oracle.Stream.build_solid(packed, start, k, m, mercy, n_short=n_short, threads=4)
+    _same(g, o.edges())
+    assert np.array_equal(ctx.last_counting(), o.counting)
+    assert 0 < g.records.size < oracle.Stream.build(packed, start, k, threads=4).edges().records.size    # the filter removed something
