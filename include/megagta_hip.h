@@ -129,6 +129,25 @@ int mgta_sdbg_outgoing(mgta_sdbg *, const int64_t *edges, int64_t n, int64_t *ou
 int mgta_sdbg_index_edges(mgta_sdbg *, const uint8_t *seqs /* n x (k+1) */, int64_t n, int64_t *edge_ids);
 
 /* ------------------------------------------------------------------------------------------------
+ * Seed finder (replaces the read scan of `megagta findstart`, fast_kmer_filter.cpp:108-176,193-215):
+ * every window of k nucleotides (k a multiple of 3, k/3 <= 24) of every read, on both strands, whose translation is one of
+ * the n_ref reference words.  A word = its residues in the code of prot_kmer.h:31-43 (ARNDCQEGHILKMFPSTWYV = 0..19, '*' = 20),
+ * 5 bits each, first residue highest: ref_words[2i] = the first min(12, k/3) residues, ref_words[2i+1] = the rest
+ * (kmer.h:66-84); of equal words the first one wins (insert_unique, fast_kmer_filter.cpp:88).
+ * reads_reversed: the reads were uploaded reversed, as mgta_sdbg_build wants them (cx1_read2sdbg_s1.cpp:97) — one upload serves
+ * both.  A hit names the read, the strand (0 = as sequenced, 1 = reverse complement), the window start inside that strand's
+ * string (ProcessSequenceMulti's nucl_pos) and the reference word.  At most `cap` hits are stored; *n_hits is the number found
+ * (call again with a larger buffer when it exceeds cap).  Order of the hits is unspecified (the reference shuffles its output).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mgta_seed_hit {
+    uint64_t read;
+    uint32_t pos_strand;             /* window start << 1 | strand */
+    int32_t ref;                     /* index into ref_words */
+} mgta_seed_hit;
+int mgta_findstart(mgta_ctx *, const mgta_reads *reads, int reads_reversed, int k, const uint64_t *ref_words, int64_t n_ref,
+                   mgta_seed_hit *hits, int64_t cap, int64_t *n_hits, double *ms_kernel /* optional */);
+
+/* ------------------------------------------------------------------------------------------------
  * Profile HMM tables (parsed on the host exactly like Parser::readHMM, hmmer3b_parser.h:19-177;
  * heuristic like MostProbablePath, most_probable_path.h:48-118)
  * ------------------------------------------------------------------------------------------------ */

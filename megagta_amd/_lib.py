@@ -68,6 +68,7 @@ SYMBOLS = {
     "mgta_sdbg_export_records_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mgta_sdbg_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
                                  C.c_int, EDGE_SINK, C.c_void_p, C.POINTER(BuildStats)]),
+    "mgta_findstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                 C.POINTER(C.c_void_p)]),
