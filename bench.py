@@ -149,6 +149,7 @@ def main():
 
     # ---- A* leg: graph + HMMs replicated, seeds dealt round-robin, one all-gather of contigs
     search = None
+    findstart_leg = None
     if args.seeds > 0:
         import tempfile
         from megagta_amd import hmm as hmmlib
@@ -162,6 +163,13 @@ def main():
         synth.write_gene_models(mg.genes, td)
         fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))
         rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "rev_enone.hmm")))
+        # seed finder (row f-2) on the reads already resident for the build: kernel time of one gene's scan
+        from megagta_amd import findstart as fsm
+        fwords, _ = fsm.reference_words(os.path.join(td, "rplB", "ref_aligned.faa"), args.k // 3)
+        fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
+        fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
+        findstart_leg = {"ms_kernel": fms, "windows_per_s": args.reads * (L - args.k + 1) * 2 / (fms * 1e-3), "hits": int(fhits.size),
+                         "reference_words": len(fwords), "note": "mgta_findstart, both strands, k=%d, one gene" % args.k}
         shutil.rmtree(td, ignore_errors=True)
         seeds = synth.synthetic_seeds(mg.genes[0], args.k, args.seeds, seed=4)
         mine = mdist.seed_share(len(seeds), rank, world)
@@ -238,6 +246,7 @@ def main():
         }
         if search is not None:
             out["search"] = search
+            out["findstart"] = findstart_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mg.reads, k, args.cpu_sample)
         print(json.dumps(out), flush=True)

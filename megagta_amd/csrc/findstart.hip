@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kFsBlock) void findstart_kernel(FsArgs a) {
         const int npos = len - k + 1;
         for (int c0 = 0; c0 < npos; c0 += 64) {
             const int p = c0 + lane;
-            if (p >= npos) continue;
-            const uint64_t q = s0 + (uint64_t)p, wi = q >> 4;
+            const bool active = p < npos;                                // (no early exit: the hits are appended wave by wave)
+            const uint64_t q = s0 + (uint64_t)(active ? p : 0), wi = q >> 4;
             const int sh = (int)(q & 15) * 2;
             uint32_t raw[kFsWords + 1], e[kFsWords], v[kFsWords];
 #pragma unroll
@@ -139,23 +139,31 @@ __global__ __launch_bounds__(kFsBlock) void findstart_kernel(FsArgs a) {
                 // first three residues: the top 15 bits of the first word's used part
                 const int n0 = kaa < 12 ? kaa : 12;
                 const uint32_t pre = (uint32_t)(w0 >> (5 * (n0 - 3))) & 0x7FFFu;
-                if (!((s_filter[pre >> 5] >> (pre & 31)) & 1u)) continue;
-                uint32_t h = (uint32_t)fs_mix(w0, w1) & a.tab_mask;
-                for (;;) {
-                    const unsigned long long k0 = a.tab[2 * (uint64_t)h];
-                    if (k0 == ~0ull) break;
-                    if (k0 == w0 && a.tab[2 * (uint64_t)h + 1] == w1) {
-                        const unsigned long long slot = atomicAdd(a.n_hits, 1ull);
+                int32_t ref = -1;
+                if (active && ((s_filter[pre >> 5] >> (pre & 31)) & 1u)) {
+                    uint32_t h = (uint32_t)fs_mix(w0, w1) & a.tab_mask;
+                    for (;;) {
+                        const unsigned long long k0 = a.tab[2 * (uint64_t)h];
+                        if (k0 == ~0ull) break;
+                        if (k0 == w0 && a.tab[2 * (uint64_t)h + 1] == w1) { ref = a.tab_ref[h]; break; }
+                        h = (h + 1) & a.tab_mask;
+                    }
+                }
+                const uint64_t found = __ballot(ref >= 0);                // one cursor update per wave
+                if (found) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.n_hits, (unsigned long long)__popcll(found));
+                    base = __shfl(base, 0, 64);
+                    if (ref >= 0) {
+                        const unsigned long long slot = base + (unsigned long long)__popcll(found & lanemask_lt());
                         if (slot < a.cap) {
                             mgta_seed_hit hit;
                             hit.read = r;
                             hit.pos_strand = ((strand == 0 ? posA : posB) << 1) | (uint32_t)strand;
-                            hit.ref = a.tab_ref[h];
+                            hit.ref = ref;
                             a.hits[slot] = hit;
                         }
-                        break;
                     }
-                    h = (h + 1) & a.tab_mask;
                 }
             }
         }

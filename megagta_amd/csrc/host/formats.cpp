@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <limits>
 #include <sstream>
 
@@ -71,11 +72,35 @@ void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out) {
     out.n_short = (uint64_t)num_reads;
 }
 
+void load_read_bin(const std::string &bin_path, bool reverse, PackedReads &out) {
+    FILE *f = fopen(bin_path.c_str(), "rb");
+    if (!f) die("cannot open %s", bin_path.c_str());
+    std::vector<uint32_t> w;
+    std::vector<uint8_t> codes;
+    uint32_t len;
+    uint64_t n = 0;
+    while (fread(&len, 4, 1, f) == 1) {                                                      // until EOF, sequence_manager.cpp:375-410
+        size_t nw = (len + 15) / 16;
+        w.resize(nw);
+        if (nw && fread(w.data(), 4, nw, f) != nw) die("%s: truncated at read %llu", bin_path.c_str(), (unsigned long long)n);
+        codes.resize(len);
+        for (uint32_t i = 0; i < len; ++i) codes[i] = (w[i >> 4] >> (30 - 2 * (i & 15))) & 3;
+        out.append(codes.data(), len, reverse);
+        ++n;
+    }
+    fclose(f);
+    out.n_short = n;
+}
+
 void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out) {
-    if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") die("gzip'ed assist sequences are not supported: %s", path.c_str());
     std::ifstream info(path + ".info");
     long long ns = 0, nb = 0;
     if (!(info >> ns >> nb)) die("cannot read %s.info (num_seq num_bases)", path.c_str());   // s1.cpp:105-108
+    load_fastx(path, reverse, out);
+}
+
+void load_fastx(const std::string &path, bool reverse, PackedReads &out) {
+    if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") die("gzip'ed sequence files are not supported: %s", path.c_str());
     std::ifstream f(path);
     if (!f.is_open()) die("cannot open %s", path.c_str());
     auto code = [](char c) -> uint8_t {                                                      // sequence_package.h:67-69
@@ -310,6 +335,60 @@ bool read_seeds(const std::string &path, std::vector<std::string> &kmers, std::v
         start_state.push_back(std::stoi(col[7]) - 1);                                 // search.cpp:157
     }
     return true;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// findstart: the reference word set (find_start, fast_kmer_filter.cpp:81-91; ProtKmerGenerator in model-only mode,
+// prot_kmer_generator.h:60-135).  A window is broken by lower case (insert columns), '-' and 'X' ('-' and 'X' still occupy a
+// model column); '.', '*' and letters outside the alphabet are skipped; of equal words the first one stays (insert_unique).
+RefWords load_reference_words(const std::string &faa_path, int kaa) {
+    std::ifstream f(faa_path);
+    if (!f.is_open()) die("File %s doesn't exist", faa_path.c_str());
+    static const char *kAlphabet = "ARNDCQEGHILKMFPSTWYV";              // prot_kmer.h:31-40
+    int code[128];
+    for (int &c : code) c = -1;
+    for (int i = 0; i < 20; ++i) code[(int)kAlphabet[i]] = i;
+    RefWords out;
+    std::map<std::pair<uint64_t, uint64_t>, int> seen;
+    std::string line, seq;
+    bool have = false;
+    auto flush = [&]() {
+        int position = 1, run = 0;
+        std::vector<int> window;
+        for (char base : seq) {
+            if ((base >= 'a' && base <= 'z') || base == '-' || base == 'X') {
+                if (base == '-' || base == 'X') ++position;
+                run = 0;
+                continue;
+            }
+            if ((unsigned char)base < 128 && code[(int)base] >= 0) {
+                window.push_back(code[(int)base]);
+                ++position;
+                if (++run >= kaa) {
+                    uint64_t w0 = 0, w1 = 0;
+                    for (int j = 0; j < kaa; ++j) {
+                        uint64_t c = (uint64_t)window[window.size() - kaa + j];
+                        if (j < 12) w0 = (w0 << 5) | c; else w1 = (w1 << 5) | c;
+                    }
+                    if (seen.emplace(std::make_pair(w0, w1), 0).second) {
+                        out.words.push_back(w0); out.words.push_back(w1);
+                        out.model_pos.push_back(position - kaa);
+                        std::string prot;
+                        for (int j = 0; j < kaa; ++j) prot.push_back((char)(kAlphabet[window[window.size() - kaa + j]] | 0x20));   // decodePacked: lower case
+                        out.prot.push_back(prot);
+                    }
+                }
+            }
+        }
+        seq.clear();
+    };
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') { if (have) flush(); have = true; continue; }
+        if (have) for (char c : line) if (c != ' ' && c != '\t') seq.push_back(c);
+    }
+    if (have) flush();
+    return out;
 }
 
 }  // namespace mgta_host

@@ -33,6 +33,16 @@ struct PackedReads {
 };
 void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out);          // ReadBinaryLibs
 void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out);        // s1.cpp:104-134
+void load_read_bin(const std::string &bin_path, bool reverse, PackedReads &out);         // a bare reads.lib.bin, read to EOF (findstart)
+void load_fastx(const std::string &path, bool reverse, PackedReads &out);                // FASTA / FASTQ, N -> G (sequence_package.h:67-69)
+
+// ---- findstart ----------------------------------------------------------------------------------------
+struct RefWords {
+    std::vector<uint64_t> words;     // [n][2]: residues 5 bits each, first residue highest; first min(12, k/3) | the rest
+    std::vector<int> model_pos;      // model column of the first residue (1-based)
+    std::vector<std::string> prot;   // lower case, as Kmer::decodePacked prints it
+};
+RefWords load_reference_words(const std::string &faa_path, int kaa);                     // fast_kmer_filter.cpp:81-91
 
 // ---- SdBG files -------------------------------------------------------------------------------------
 struct EdgeStream {

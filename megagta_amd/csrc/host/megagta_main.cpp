@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -223,16 +224,77 @@ static int main_search(int argc, char **argv) {
     return 0;
 }
 
+// megagta findstart <ref_seq> <read.lib.bin> <k_size> [num_threads=0] [contigs.fa]     (fast_kmer_filter.cpp:49-190)
+static int main_findstart(int argc, char **argv) {
+    if (argc == 1) {
+        fprintf(stderr, "Usage: %s <ref_seq> <read.lib> <k_size> [num_threads=0]\n", argv[0]);
+        return 1;
+    }
+    if (argc < 4) die("findstart: <ref_seq> <read.lib> <k_size> are required");
+    for (int i = 1; i <= 2; ++i) {
+        FILE *t = fopen(argv[i], "rb");
+        if (!t) { fprintf(stderr, "File %s doesn't exist\n", argv[i]); return 1; }       // :58-64
+        fclose(t);
+    }
+    const int k = atoi(argv[3]);
+    if (k < 9 || k % 3 != 0 || k / 3 > 24) die("findstart: k_size = %d: a multiple of 3 in [9, 72] is required (k/3 residues, at most 24)", k);
+    RssLine rss;
+    const RefWords ref = load_reference_words(argv[1], k / 3);
+    logf("reference kmer set size: %lld\n", (long long)ref.model_pos.size());
+    PackedReads pr;
+    load_read_bin(argv[2], /*reverse=*/true, pr);                       // stored as buildgraph wants them: the scan handles both orders
+    const uint64_t n_lib = pr.start.empty() ? 0 : pr.start.size() - 1;
+    if (argc > 5) load_fastx(argv[5], true, pr);
+    pr.finish();
+    const uint64_t n_reads = pr.start.size() - 1;
+    logf("Processing %llu reads, %llu contigs\n", (unsigned long long)n_lib, (unsigned long long)(n_reads - n_lib));
+    mgta_ctx *ctx = mgta_ctx_create(0);
+    if (!ctx) die("%s", mgta_last_error());
+    mgta_reads *rd = nullptr;
+    if (mgta_reads_upload(ctx, pr.words.data(), pr.words.size(), pr.start.data(), n_reads, &rd) != MGTA_OK) die("%s", mgta_last_error());
+    std::vector<mgta_seed_hit> hits(1 << 16);
+    int64_t n_hits = 0;
+    double ms = 0;
+    for (;;) {
+        if (mgta_findstart(ctx, rd, 1, k, ref.words.data(), (int64_t)ref.model_pos.size(), hits.data(), (int64_t)hits.size(), &n_hits, &ms) != MGTA_OK)
+            die("%s", mgta_last_error());
+        if (n_hits <= (int64_t)hits.size()) break;
+        hits.resize((size_t)n_hits + 1024);
+    }
+    hits.resize((size_t)n_hits);
+    logf("seed scan: %.3f ms on the device, %lld hits\n", ms, (long long)n_hits);
+    // unique by nucleotide k-mer (:181-182); the reference then shuffles, any order is as good: sorted
+    auto base_at = [&](uint64_t r, uint32_t fwd_pos) {                  // reversed storage -> base of the read as sequenced
+        const uint64_t len = pr.start[r + 1] - pr.start[r], q = pr.start[r] + (len - 1 - fwd_pos);
+        return (int)((pr.words[q >> 4] >> (30 - 2 * (q & 15))) & 3);
+    };
+    std::map<std::string, int32_t> seeds;
+    std::string nucl((size_t)k, 'A');
+    for (const mgta_seed_hit &h : hits) {
+        const uint32_t pos = h.pos_strand >> 1, len = (uint32_t)(pr.start[h.read + 1] - pr.start[h.read]);
+        for (int j = 0; j < k; ++j)
+            nucl[(size_t)j] = (h.pos_strand & 1) ? "TGCA"[base_at(h.read, len - 1 - (pos + (uint32_t)j))] : "ACGT"[base_at(h.read, pos + (uint32_t)j)];
+        seeds.emplace(nucl, h.ref);
+    }
+    for (const auto &kv : seeds)
+        printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", kv.first.c_str(), 1, ref.prot[(size_t)kv.second].c_str(),
+               ref.model_pos[(size_t)kv.second]);
+    mgta_reads_free(rd);
+    mgta_ctx_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs on the MI355X hot path:\n        buildgraph    build succinct de Bruijn graph\n"
-                        "        search        HMM-guided search of gene contigs\n        dumpversion   dump version\n", argv[0]);
+                        "        search        HMM-guided search of gene contigs\n        findstart     find starting kmers of the search\n        dumpversion   dump version\n", argv[0]);
         return 1;
     }
     std::string sub = argv[1];
     if (sub == "buildgraph") return main_buildgraph(argc - 1, argv + 1);
     if (sub == "search") return main_search(argc - 1, argv + 1);
+    if (sub == "findstart") return main_findstart(argc - 1, argv + 1);
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
-    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildgraph, search): run it with the reference's megagta binary\n", sub.c_str());
+    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildgraph, search, findstart): run it with the reference's megagta binary\n", sub.c_str());
     return 1;
 }

@@ -8,7 +8,7 @@ Drop-in surface kept (reference src/megagta.py): options `-r/-1/-2/--12 -g -k -c
 (:815-816), one child process per step with stderr relayed into the log, first non-zero exit aborts.
 
 The two sub-commands on the accelerated path, `buildgraph` and `search`, run from THIS package's
-`bin/megagta` (C++ host + libmegagta_hip.so).  Every other step (`buildlib`, `denovo`, `findstart`,
+`bin/megagta` (C++ host + libmegagta_hip.so), and so does `findstart`.  Every other step (`buildlib`, `denovo`,
 `filterbylen`, `translate`) is outside the path and is run from the binary given by `--ref-bin`
 (or $MEGAGTA_REF_BIN): the stock MegaGTA executable.
 """
@@ -283,7 +283,7 @@ def find_seed(k, gene):
         if i > 0:
             par.append(contig_file(opt.k_list[i - 1]))
         with open(graph_prefix(k) + "_" + gene + "_starting_kmers.txt", "w") as out:
-            run_step([need_ref("findstart"), "findstart"] + par, "Finding starting kmers for %s k = %d" % (gene, k), stdout=out)
+            run_step([opt.bin, "findstart"] + par, "Finding starting kmers for %s k = %d" % (gene, k), stdout=out)
     write_cp()
 
 

@@ -43,13 +43,15 @@ def test_single_k_pipeline_matches_reference_artifacts(toy_inputs, oracle, golde
     # graph files written by OUR buildgraph decode (with the oracle's reader = the reference format) to the reference's stream
     s = oracle.Stream.read(str(out / "k44" / "44")).edges()
     assert s.md5() == H.load_streams(os.path.join(toy, "sdbg_streams.json"))["44"]["md5"]
-    # seeds come from the reference's findstart on OUR reads.lib.bin -> identical to the golden seed file
-    assert (out / "k44" / "44_rplB_starting_kmers.txt").read_text() == open(os.path.join(toy, "44_rplB_starting_kmers.txt")).read()
+    # seeds come from OUR findstart (device scan) on the reads.lib.bin the reference's buildlib wrote: the golden seed lines, in
+    # sorted order (the reference shuffles its own, fast_kmer_filter.cpp:183)
+    seeds = (out / "k44" / "44_rplB_starting_kmers.txt").read_text().splitlines()
+    assert seeds == sorted(open(os.path.join(toy, "44_rplB_starting_kmers.txt")).read().splitlines())
     # contigs: one record per seed, names as hmm_graph_search.h:79, sequences == per-seed cold-cache results of the reference
-    gold = H.parse_probe_astar(H.gz_lines(os.path.join(toy, "astar_cold.txt.gz")))
+    gold = {g["kmer"].lower(): g["contig"] for g in H.parse_probe_astar(H.gz_lines(os.path.join(toy, "astar_cold.txt.gz")))}
     lines = (out / "k44" / "44_raw_contigs_rplB.fasta").read_text().splitlines()
-    assert lines[0::2] == [f">rplB_contig_{2 * i}_contig_{2 * i + 1}" for i in range(len(gold))]
-    assert lines[1::2] == [g["contig"] for g in gold]
+    assert lines[0::2] == [f">rplB_contig_{2 * i}_contig_{2 * i + 1}" for i in range(len(seeds))]
+    assert lines[1::2] == [gold[l.split("\t")[3].lower()] for l in seeds]
     # driver artefacts
     assert (out / "opts.txt").exists() and (out / "contigs" / "rplB" / "nucl_merged.fasta").exists()
     done = [l.split() for l in (out / "tmp" / "cp.txt").read_text().splitlines()]
@@ -113,3 +115,23 @@ def test_buildgraph_min_count_2_with_mercy_matches_reference_binary(toy_inputs, 
     a, b = oracle.Stream.read(str(w / "ours")).edges(), oracle.Stream.read(str(w / "ref")).edges()
     assert a.md5() == b.md5() and a.records.size > 0
     assert (w / "ours.counting").read_text() == (w / "ref.counting").read_text()
+
+
+@pytest.mark.parametrize("k,with_contigs", [(45, False), (30, True), (72, True)])
+def test_findstart_binary_matches_reference_output(golden_dir, k, with_contigs):
+    """`megagta findstart <ref> <reads.lib.bin> <k> [threads] [contigs.fa]` (fast_kmer_filter.cpp:49-190): same lines as the reference
+    (sorted: the reference shuffles), same usage / missing-file behaviour"""
+    import gzip
+    assert os.path.exists(BIN), "megagta_amd/bin/megagta missing: run __graft_entry__.build()"
+    d = os.path.join(golden_dir, "findstart")
+    cmd = [BIN, "findstart", os.path.join(d, "ref_quirks.faa"), os.path.join(d, "reads.lib.bin"), str(k), "2"]
+    if with_contigs:
+        cmd.append(os.path.join(d, "contigs.fa"))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = gzip.open(os.path.join(d, f"seeds_k{k}{'_contigs' if with_contigs else ''}.txt.gz"), "rt").read().splitlines()
+    assert r.stdout.splitlines() == sorted(want)
+    r = subprocess.run([BIN, "findstart", "/nonexistent.faa", os.path.join(d, "reads.lib.bin"), "45"], capture_output=True, text=True)
+    assert r.returncode == 1 and "doesn't exist" in r.stderr
+    r = subprocess.run([BIN, "findstart", os.path.join(d, "ref_quirks.faa"), os.path.join(d, "reads.lib.bin"), "44"], capture_output=True, text=True)
+    assert r.returncode != 0 and "multiple of 3" in r.stderr
