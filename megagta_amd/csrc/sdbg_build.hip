@@ -108,15 +108,21 @@ struct ScanArgs {
     const unsigned long long *is_solid;    // stage-1 verdicts (bit num_k1_per_read*read + position), nullptr = every position solid
     int num_k1_per_read;
     uint64_t n_short;                      // reads >= n_short (assist sequences) are always solid (s2.cpp:276)
+    uint32_t multi_width, multi_n;         // count mode: multi_n > 0 counts multi_n consecutive bucket ranges of multi_width buckets from
+                                           // b_lo in one scan: block_count[range * gridDim.x + workgroup]
 };
+constexpr int kMaxCountRanges = 64;
 
 template <int W, bool WRITE>
 __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     __shared__ uint32_t s_cursor;
     __shared__ uint32_t s_wave_cnt[kScanBlock / 64];
+    __shared__ uint32_t s_range_cnt[kMaxCountRanges];
     const int k = a.k;
     const int lane = lane_id(), wv = wave_id();
+    const bool multi = !WRITE && a.multi_n > 0;
     if (threadIdx.x == 0) s_cursor = 0;
+    if (!WRITE && threadIdx.x < kMaxCountRanges) s_range_cnt[threadIdx.x] = 0;
     __syncthreads();
     uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
     uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
@@ -169,19 +175,25 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
 #pragma unroll
                 for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
                 int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
-                auto push = [&](const Key<W> &key) {
-                    uint32_t b = key.w[0] >> 16;                       // bucket = first 8 characters (s2.cpp:832)
-                    if (b >= a.b_lo && b < a.b_hi) items[cnt++] = key;
+                // the bucket (first 8 characters of the key, s2.cpp:832) is known before the key is built: most keys of a
+                // narrow bucket range (memory-bound passes, multi-GPU shares) are dropped after three instructions
+                auto push = [&](const uint32_t (&src)[W], int from, int n, int prev) {
+                    const uint64_t two = ((uint64_t)src[0] << 32) | (uint64_t)(W > 1 ? src[W > 1 ? 1 : 0] : 0u);
+                    const uint32_t b = (uint32_t)((two << (2 * from)) >> 48);
+                    if (b < a.b_lo || b >= a.b_hi) return;
+                    if (WRITE) items[cnt] = make_key<W>(src, from, n, k, prev);
+                    else if (multi) atomicAdd(&s_range_cnt[(b - a.b_lo) / a.multi_width], 1u);
+                    ++cnt;
                 };
                 if (run_first) {                                       // left $  (s2.cpp:531-540)
-                    push(make_key<W>(e, 0, k, k, kDollar));
-                    if (!pal) push(make_key<W>(rc, 2, k - 1, k, r1c));
+                    push(e, 0, k, kDollar);
+                    if (!pal) push(rc, 2, k - 1, r1c);
                 }
-                push(make_key<W>(e, 1, k, k, e0));                     // solid   (s2.cpp:543-550)
-                if (!pal) push(make_key<W>(rc, 1, k, k, r0c));
+                push(e, 1, k, e0);                                     // solid   (s2.cpp:543-550)
+                if (!pal) push(rc, 1, k, r0c);
                 if (run_last) {                                        // right $ (s2.cpp:553-562)
-                    push(make_key<W>(e, 2, k - 1, k, e1));
-                    if (!pal) push(make_key<W>(rc, 0, k, k, kDollar));
+                    push(e, 2, k - 1, e1);
+                    if (!pal) push(rc, 0, k, kDollar);
                 }
             }
             if (!WRITE) {
@@ -201,11 +213,12 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
         my_count = wave_sum(my_count);
         if (lane == 0) s_wave_cnt[wv] = my_count;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && !multi) {
             uint32_t t = 0;
             for (int w = 0; w < kScanBlock / 64; ++w) t += s_wave_cnt[w];
             a.block_count[blockIdx.x] = t;
         }
+        if (multi && threadIdx.x < a.multi_n) a.block_count[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = s_range_cnt[threadIdx.x];
         if (lane == 0 && kmers && a.n_kmers) atomicAdd(a.n_kmers, kmers);
     }
 }
@@ -512,8 +525,6 @@ template <int W> struct LocalCfg {
     static constexpr int kTile = W <= 4 ? 4096 : 2048;           // keys sorted in LDS by one workgroup (LDS budget: kTile * 4W bytes)
     static constexpr int kIpt = kTile / kSortThreads;
     static constexpr int kChunk = kTile / kSortWaves;
-    static constexpr uint32_t kStride = kTile - kTile / 8;        // a workgroup owns the segments that START in its stride; the last one
-                                                                  // may hang over by kTile/8 keys before it is deferred
 };
 
 template <int W>
@@ -548,9 +559,11 @@ struct LocalPlan {
     const Digit *low_plan;   // every significant digit below the 8P-bit prefix, least significant first
     int n_low;
     int P;
-    Digit upper;             // the (<= 8) key bits right below the prefix, all inside word 0
+    Digit upper;             // the (<= 8) key bits right below the prefix (inside the first two key words)
     uint32_t mask_last2;     // significant bits of key word W-2 / W-1 (stage 1 carries a payload there that must not be compared);
     uint32_t mask_last;      // the digits of low_plan never look at a masked-out bit
+    uint32_t stride;         // keys of the array per workgroup of local_sort_kernel (multiple of 64, < kTile): a workgroup owns the segments
+                             // that START in its stride; the rest of the tile is room for the last one to hang over
     uint64_t *lsd_list;      // [2 * lsd_cap]: (first, end) of the tiles left to local_lsd_kernel
     uint32_t *lsd_count;
     uint32_t lsd_cap;
@@ -697,9 +710,16 @@ __device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[Local
 // run [rs, re) off a few masks; it then finds its rank among the run's keys by comparing words FIRST..W-1 (equal keys keep
 // their order) and goes to its final place in global memory.  Returns false (nothing written) when the runs are longer than
 // kMaxAvgRun on average or one of them is longer than kMaxRun.
-template <int W, int FIRST, bool MASKED>
-__device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_shift, uint32_t m2,
+// the leading PW words of a key as one integer (PW = 2: the run prefix reaches into the second word)
+template <int W, int PW>
+__device__ __forceinline__ uint64_t key_top(const Key<W> &k) {
+    return PW == 1 ? (uint64_t)k.w[0] : (((uint64_t)k.w[0] << 32) | (uint64_t)k.w[W > 1 ? 1 : 0]);
+}
+
+template <int W, int FIRST, bool MASKED, int PW>
+__device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W> *keys, uint64_t first, uint32_t nt, int run_bits, uint32_t m2,
                                                      uint32_t m1, bool skip_compare) {
+    const int run_shift = 32 * PW - run_bits;                          // runs = equal leading run_bits bits
     constexpr int kIpt = LocalCfg<W>::kIpt, kWindows = LocalCfg<W>::kTile / 64;
     const int lane = lane_id(), wv = wave_id();
     const uint64_t le_mask = lanemask_lt() | (1ull << lane);
@@ -707,7 +727,7 @@ __device__ __forceinline__ bool finish_by_comparison(CompareShared<W> &sh, Key<W
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         const uint32_t win = (uint32_t)it * kSortWaves + (uint32_t)wv, j = win * 64 + (uint32_t)lane;
-        const bool head = j < nt && (j == 0 || ((sh.keys[j - 1].w[0] ^ sh.keys[j].w[0]) >> run_shift) != 0);
+        const bool head = j < nt && (j == 0 || ((key_top<W, PW>(sh.keys[j - 1]) ^ key_top<W, PW>(sh.keys[j])) >> run_shift) != 0);
         const uint64_t hm = __ballot(head);
         if (lane == 0) sh.masks[win] = hm;
         heads += (uint32_t)__popcll(hm);
@@ -765,8 +785,9 @@ template <int W, bool WANT_KEYS>   // !WANT_KEYS: only the tile bounds are wante
 __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *keys, uint64_t n, LocalPlan lp, uint64_t *big, uint32_t *big_count,
                                                                      uint32_t big_cap) {
     constexpr int kTile = LocalCfg<W>::kTile, kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk, kWindows = kTile / 64;
-    constexpr uint32_t kLocalStride = LocalCfg<W>::kStride, NONE = ~0u;
-    static_assert(kLocalStride % 64 == 0 && kWindows <= 64, "tile bounds are read off one 64-bit head mask per lane");
+    constexpr uint32_t NONE = ~0u;
+    static_assert(kWindows <= 64, "tile bounds are read off one 64-bit head mask per lane");
+    const uint32_t kLocalStride = lp.stride;
     __shared__ CompareShared<W> sh;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), P = lp.P;
     const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
@@ -850,14 +871,14 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
     const uint32_t n_words = ((nseg << ub) + 1u) >> 1;
     for (uint32_t i = tid; i < n_words; i += kSortThreads) sh.hist[i] = 0;
     __syncthreads();
-    const int run_shift = 32 - (8 * P + ub);
+    const int run_bits = 8 * P + ub;                                   // <= 40: the digit may reach into the second key word
     uint32_t br[kIpt];                                                // bin | rank inside the bin << 16
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         const uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
         br[it] = ~0u;
         if (j - first_off < nt) {
-            const uint32_t dg = ub ? (key[it].w[0] << (8 * P)) >> (32 - ub) : 0u;
+            const uint32_t dg = ub ? (uint32_t)((key_top<W, 2>(key[it]) << (8 * P)) >> (64 - ub)) : 0u;
             const uint32_t bin = (seg[it] << ub) | dg, sh16 = (bin & 1u) * 16u;
             const uint32_t old = atomicAdd(&sh.hist[bin >> 1], 1u << sh16);
             br[it] = bin | (((old >> sh16) & 0xFFFFu) << 16);
@@ -896,12 +917,15 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
     const bool skip = (lp.debug & 1) != 0;
     const bool masked = (lp.mask_last2 & lp.mask_last) != ~0u;
     bool done;
-    if (run_shift == 0 && W > 1)
-        done = masked ? finish_by_comparison<W, (W > 1 ? 1 : 0), true>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
-                      : finish_by_comparison<W, (W > 1 ? 1 : 0), false>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
+    if (run_bits > 32 && W > 1)
+        done = masked ? finish_by_comparison<W, (W > 1 ? 1 : 0), true, 2>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip)
+                      : finish_by_comparison<W, (W > 1 ? 1 : 0), false, 2>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip);
+    else if (run_bits == 32 && W > 1)
+        done = masked ? finish_by_comparison<W, (W > 1 ? 1 : 0), true, 1>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip)
+                      : finish_by_comparison<W, (W > 1 ? 1 : 0), false, 1>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip);
     else
-        done = masked ? finish_by_comparison<W, 0, true>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip)
-                      : finish_by_comparison<W, 0, false>(sh, keys, first, nt, run_shift, lp.mask_last2, lp.mask_last, skip);
+        done = masked ? finish_by_comparison<W, 0, true, 1>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip)
+                      : finish_by_comparison<W, 0, false, 1>(sh, keys, first, nt, run_bits, lp.mask_last2, lp.mask_last, skip);
     if (!done) leave_to_lsd();                                        // global memory still holds the tile as it was
 }
 
@@ -1252,7 +1276,7 @@ static std::vector<Digit> low_digit_plan(int k, int W, int P) {
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_MULTI_COUNT, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -1275,8 +1299,10 @@ static uint64_t pool_bytes(const mgta_ctx *ctx) {
 // holds the result, nullptr on an unsupported input (error set).
 template <int WT, class LowPlanFn>
 static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
-                            std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, uint32_t mask_last2 = ~0u,
-                            uint32_t mask_last = ~0u) {
+                            std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, double prefix_frac = 1.0,
+                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u) {
+    // prefix_frac: share of the leading-byte values the keys can take (a pass over a bucket sub-range only holds that share of
+    // the prefixes, so its segments are as long as those of the whole key set)
     const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
     uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
     uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
@@ -1303,20 +1329,28 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             if (S) S->n_sort_launches++;
         }
     };
-    // P: smallest number of leading bytes that leaves segments of ~<= 256 keys on average
+    // P: smallest number of leading bytes that leaves segments of <= 256 keys on average — up to 1024 rather than a fourth
+    // global pass: a 4096-key tile still holds several such segments, and the comparison route needs key bits left in word 0
     int P = 0;
-    while (P < max_top && (double)n_items / std::pow(256.0, P) > 256.0) ++P;
+    auto avg_segment = [&](int p) { return (double)n_items / std::max(1.0, std::pow(256.0, p) * prefix_frac); };
+    while (P < max_top && avg_segment(P) > (P >= 3 ? 700.0 : 256.0)) ++P;
     if (ctx->force_full_lsd) P = 0;
     for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(WT, i)); std::swap(src, dst); }
     const std::vector<Digit> low = low_plan_for(P);
     if (low.size() > 64) { set_error("too many sort digits"); return nullptr; }
     Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
     MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
-    const uint32_t big_cap = 1u << 16;
+    // room behind the stride for the last segment of a tile: ~2.5 average segments, an eighth of the tile at least, half at most
+    const double avg_seg = avg_segment(P);
+    uint32_t margin = (uint32_t)std::min<double>(LocalCfg<WT>::kTile / 2, std::max<double>(LocalCfg<WT>::kTile / 8, 2.5 * avg_seg));
+    margin = (margin + 63u) & ~63u;
+    const uint32_t stride = (uint32_t)LocalCfg<WT>::kTile - margin;
+    const uint64_t l_blocks = (n_items + stride - 1) / stride;
+    if (l_blocks > 0x7FFFFFFFull) { set_error("too many sort tiles"); return nullptr; }
+    const uint32_t big_cap = (uint32_t)l_blocks + 1;                  // every workgroup defers one segment at most
     uint64_t *d_big = pool_get<uint64_t>(ctx, S_BIG, (2 * (uint64_t)big_cap + 2) * 8);
-    uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * big_cap);
+    uint32_t *d_big_count = reinterpret_cast<uint32_t *>(d_big + 2 * (uint64_t)big_cap);
     MGTA_HIP_CHECK(hipMemsetAsync(d_big_count, 0, 8, stream));
-    uint64_t l_blocks = (n_items + LocalCfg<WT>::kStride - 1) / LocalCfg<WT>::kStride;
     uint64_t *d_lsd = pool_get<uint64_t>(ctx, S_LSD, 2 * l_blocks * 8);
     hipEvent_t le0, le1;
     MGTA_HIP_CHECK(hipEventCreate(&le0));
@@ -1329,10 +1363,11 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     // the comparison route is skipped for a few sorts after one that found mostly long runs (highly redundant input)
     const bool skip_a = ctx->lsd_skip_left > 0;
     if (skip_a) --ctx->lsd_skip_left;
-    const int ub = ((ctx->force_lsd_tiles & 1) || skip_a) ? 0 : std::min(8, 32 - 8 * P);
+    const int ub = ((ctx->force_lsd_tiles & 1) || skip_a) ? 0 : std::max(0, std::min(8, (WT > 1 ? 40 : 32) - 8 * P));
     lp.upper = Digit{32 * WT - 8 * P - ub, ub};
     lp.mask_last2 = mask_last2;
     lp.mask_last = mask_last;
+    lp.stride = stride;
     lp.lsd_list = d_lsd;
     lp.lsd_count = d_big_count + 1;
     lp.lsd_cap = (uint32_t)l_blocks;
@@ -1454,7 +1489,7 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                 return plan;
             };
             const int max_top = std::min(4, std::max(0, (2 * (k - 1)) / 8));
-            Key<WT> *sorted = device_sort<WT>(ctx, stream, d_a, d_b, n_items, max_top, low_plan, nullptr, nullptr, 0u, 0x3Fu);
+            Key<WT> *sorted = device_sort<WT>(ctx, stream, d_a, d_b, n_items, max_top, low_plan, nullptr, nullptr, (double)(b_hi - b_lo) / MGTA_NUM_BUCKETS, 0u, 0x3Fu);
             if (!sorted) return MGTA_EUNSUPPORTED;
             char *scratch = reinterpret_cast<char *>(sorted == d_a ? d_b : d_a);
             uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
@@ -1563,6 +1598,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     std::vector<uint32_t> h_tips;
     std::vector<int64_t> h_items;
 
+    uint32_t multi_n = 0, multi_width = 0, multi_lo = 0;             // ranges counted ahead by one scan (d_multi_count rows)
+    uint32_t *d_multi_count = nullptr;
     while (b_lo < bucket_end) {
         uint32_t width = (span + n_pass - 1) / n_pass;
         uint32_t b_hi = std::min<uint32_t>(bucket_end, b_lo + width);
@@ -1574,12 +1611,26 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
         static_assert(kReadsPerBlock == 64, "item_count_closed_kernel: one lane per read of a workgroup");
         const bool closed_form = ((k + 1) & 1) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
+        const uint32_t *counts = d_block_count;
+        sa.multi_n = 0; sa.multi_width = 0;
         if (n_blocks && closed_form)
             hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(256), 0, stream, sa.start, sa.n_reads, n_blocks, k,
                                sa.block_count, sa.n_kmers);
-        else if (n_blocks)
-            hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
-        exclusive_scan_u32(stream, d_block_count, n_blocks, d_block_base, d_scan_tmp, d_total);
+        else if (n_blocks) {
+            // several equally wide ranges ahead (memory-bound passes): one scan counts them all
+            const uint32_t ranges_left = (bucket_end - b_lo + width - 1) / width;
+            if (multi_n && (width != multi_width || b_lo < multi_lo || (b_lo - multi_lo) % width != 0 || (b_lo - multi_lo) / width >= multi_n)) multi_n = 0;
+            if (!multi_n && ranges_left > 1 && ranges_left <= (uint32_t)kMaxCountRanges) {
+                d_multi_count = pool_get<uint32_t>(ctx, S_MULTI_COUNT, (uint64_t)ranges_left * n_blocks * 4);
+                ScanArgs sm = sa;
+                sm.block_count = d_multi_count; sm.b_hi = bucket_end; sm.multi_width = width; sm.multi_n = ranges_left;
+                hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sm);
+                multi_n = ranges_left; multi_width = width; multi_lo = b_lo;
+            }
+            if (multi_n) counts = d_multi_count + (uint64_t)((b_lo - multi_lo) / width) * n_blocks;
+            else hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+        }
+        exclusive_scan_u32(stream, counts, n_blocks, d_block_base, d_scan_tmp, d_total);
         uint64_t n_items = 0;
         MGTA_HIP_CHECK(hipMemcpyAsync(&n_items, d_total, 8, hipMemcpyDeviceToHost, stream));
         S.ms_count += t_ph.stop();
@@ -1593,8 +1644,10 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12);
         uint64_t need = n_items * sizeof(Key<W>) + key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
-        if (need + need / 8 > budget - std::min<uint64_t>(budget, other) && width > 1) {
-            n_pass *= 2;                                              // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
+        const uint64_t avail = budget - std::min<uint64_t>(budget, other);
+        if (need + need / 8 > avail && width > 1) {                   // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
+            const double ratio = (double)(need + need / 8) / (double)std::max<uint64_t>(avail, 1) * 1.03;
+            n_pass = std::max(n_pass + 1, (int)std::ceil((double)n_pass * ratio));
             continue;
         }
         first_pass = false;
@@ -1614,7 +1667,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
             const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
-            Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int P) { return low_digit_plan(k, W, P); }, &scatter_ev, &S);
+            Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int P) { return low_digit_plan(k, W, P); }, &scatter_ev, &S,
+                                           (double)(b_hi - b_lo) / MGTA_NUM_BUCKETS);
             if (!src) return MGTA_EUNSUPPORTED;
             Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();

@@ -239,3 +239,27 @@ def test_min_count_vs_oracle_seeded(ctx, oracle, k, m, mercy, assist):
     _same(g, o.edges())
     assert np.array_equal(ctx.last_counting(), o.counting)
     assert 0 < g.records.size < oracle.Stream.build(packed, start, k, threads=4).edges().records.size    # the filter removed something
+
+
+def test_fourth_leading_byte_and_wide_run_prefix(ctx, oracle):
+    """a bucket range so narrow and so full that three leading key bytes leave segments of > 700 keys: the sort takes a fourth global
+    pass and the run prefix of the LDS tiles reaches into the second key word (the regime of memory-bound passes over 10^10 items)"""
+    rng = np.random.default_rng(5)
+    X = np.array([0, 1, 2, 3, 0, 1, 2, 3], dtype=np.uint8)                  # ACGTACGT: every 16th position starts a key of bucket bx
+    reads = []
+    for _ in range(22000):
+        r = rng.integers(0, 4, 160).astype(np.uint8)
+        off = int(rng.integers(0, 16))
+        for p in range(off, 160 - 8, 16):
+            r[p:p + 8] = X
+        reads.append(r[:int(rng.integers(140, 161))])
+    packed, start = readlib.pack_for_build(reads)
+    k = 44
+    o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    bx = int(np.argmax(o.bucket_items))                                      # the bucket of the planted word (as the build sees the reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k, bucket_range=(bx, bx + 1))
+    assert g.stats["n_sort_launches"] == 4 and g.stats["n_items"] > 180_000       # four leading bytes
+    lo, hi = int(o.bucket_items[:bx].sum()), int(o.bucket_items[:bx + 1].sum())
+    assert hi - lo == g.records.size > 10_000
+    assert np.array_equal(g.records, o.records[lo:hi])
+    assert g.bucket_items[bx] == hi - lo and g.bucket_items.sum() == hi - lo
