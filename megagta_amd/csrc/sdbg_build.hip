@@ -9,16 +9,20 @@
 // with a device-resident design (no differential offset lists, no per-bucket CPU threads):
 //
 //   pass over a bucket range [b_lo,b_hi) that fits the memory budget (the analogue of CX1's lv1 loop)
-//     1. item_scan<count>   one wave per read chunk, one lane per (k+1)-mer position: funnel-shift the
-//                           edge out of the 2-bit read array, reverse-complement it in registers, count
-//                           the <= 6 sort items of the position that fall into the bucket range
+//     1. items per workgroup: closed form when k+1 is odd and every bucket is wanted (2 (len - k) + 4 per read), else
+//        item_scan<count>: one wave per read, one lane per (k+1)-mer position: funnel-shift the edge out of the 2-bit read
+//        array, reverse-complement it in registers, count the <= 6 sort items of the position whose first 8 characters fall
+//        into the range (one scan counts every range that is still ahead)
 //     2. prefix sum of the per-workgroup counts
 //     3. item_scan<write>   same scan, keys written (array-of-structs, W words) with wave-aggregated offsets
-//     4. LSD radix sort of the keys, 8-bit digits, zero bits skipped: digit census per tile, row scan,
-//        stable LDS-staged scatter (wave-level match ranking, coalesced run writes)
-//     5. edge emission: run heads -> sub-group descriptors (a, b, group-head) -> per sub-group decision
-//        (W, last, tip, multiplicity, $-suppression) -> order-preserving compaction of records, large
-//        multiplicities and tip labels + per-bucket boundaries
+//     4. sort: P <= 4 global LSD passes on the P leading key bytes (digit census per tile, row scan, stable LDS-staged scatter
+//        with wave-level match ranking and coalesced run writes), then every segment of equal prefix is finished inside LDS:
+//        one counting pass on (segment, next <= 8 bits) with LDS atomics, then every key ranks itself inside its short run of
+//        equal leading bits by comparison (local_sort_kernel); tiles with long runs and segments that did not fit take LSD
+//        passes in LDS (local_lsd_kernel), segments longer than a tile global passes over their own range (segment_sort_kernel)
+//     5. edge emission: run descriptors (a, b, group head, bucket head) compacted in one read of the keys by a chained scan
+//        across workgroups -> per run decision (W, last, tip, multiplicity, $-suppression) -> order-preserving compaction of
+//        records, large multiplicities and tip labels + per-bucket boundaries
 //
 // Everything is integer / byte work bound by HBM traffic; no MFMA.  Parity: bit-exact edge stream vs
 // the oracle (tests/test_sdbg_build_gpu.py).
@@ -459,8 +463,8 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 }
 
 // stable scatter of one 32768-key tile by the current digit
-template <int W, int MINW = 8>
-__global__ __launch_bounds__(kSortThreads, MINW) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
+template <int W>
+__global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
                                                                       const uint64_t *totals) {
     __shared__ ScatterShared<W> sh;
@@ -1021,27 +1025,6 @@ __device__ __forceinline__ int key_a(const Key<W> &x, int k) {   // Extract_a, s
 template <int W>
 __device__ __forceinline__ int key_b(const Key<W> &x) { return x.w[W - 1] & 7u; }   // Extract_b, s2.cpp:96-98
 
-// E1: number of run heads (distinct keys) per tile
-template <int W>
-__global__ __launch_bounds__(kEmitThreads) void emit_mark_kernel(const Key<W> *keys, uint64_t n, uint32_t *tile_heads) {
-    __shared__ uint32_t s_cnt[kEmitThreads / 64];
-    uint64_t base = (uint64_t)blockIdx.x * kEmitTile;
-    uint32_t c = 0;
-    for (int it = 0; it < kEmitPerThread; ++it) {
-        uint64_t idx = base + (uint64_t)it * kEmitThreads + threadIdx.x;
-        bool head = false;
-        if (idx < n) head = idx == 0 || !keys_equal<W>(keys[idx], keys[idx - 1]);
-        c += (uint32_t)__popcll(__ballot(head));
-    }
-    if (lane_id() == 0) s_cnt[wave_id()] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < kEmitThreads / 64; ++w) t += s_cnt[w];
-        tile_heads[blockIdx.x] = t;
-    }
-}
-
 // E1+E2: one descriptor per run (distinct key): start index + (a | b<<3 | group_head<<6 | bucket_head<<7), compacted in key order.
 // The keys are read once: the number of runs before a tile comes from a chained scan across the workgroups (device_utils.hpp).
 struct EmitChain {
@@ -1253,15 +1236,6 @@ struct Timer {
     }
 };
 
-static std::vector<Digit> digit_plan(int k, int W) {
-    // key bits from the LSB: [0,4) flags, [4,4+pad) always zero, [4+pad, 32W) characters
-    std::vector<Digit> plan;
-    int pad = 32 * W - 2 * k - 4;
-    plan.push_back(Digit{0, 4});
-    for (int pos = 4 + pad; pos < 32 * W; pos += 8) plan.push_back(Digit{pos, std::min(8, 32 * W - pos)});
-    return plan;
-}
-
 // most significant digits first: digit i = key bits [32W - 8(i+1), 32W - 8i)
 static Digit top_digit(int W, int i) { return Digit{32 * W - 8 * (i + 1), 8}; }
 // digits of the bits below 32W - 8P, least significant first (flags, then characters; the zero pad is skipped)
@@ -1317,11 +1291,7 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             MGTA_HIP_CHECK(hipEventCreate(&e1));
             MGTA_HIP_CHECK(hipEventRecord(e0, stream));
         }
-        if (false)
-            hipLaunchKernelGGL((radix_scatter_kernel<WT, 4>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
-                               d_totals);
-        else
-        hipLaunchKernelGGL((radix_scatter_kernel<WT, 4>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+        hipLaunchKernelGGL((radix_scatter_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
                            d_totals);
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
@@ -1588,7 +1558,6 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     }
 
     t_all.start();
-    const std::vector<Digit> plan = digit_plan(k, W);
     int n_pass = 1;
     uint32_t b_lo = bucket_begin;
     const uint32_t span = bucket_end - bucket_begin;
