@@ -169,35 +169,40 @@ __device__ __forceinline__ void heap_sift_up(HeapEnt *lds, HeapEnt *glob, uint64
     if (lane == 0) hset(lds, glob, ((hole + 1) >> s) - 1, v);
 }
 
-// pop_heap + pop_back; n = current size (> 0); returns the former top
+// pop_heap + pop_back; n = current size (> 0); returns the former top.
+// __adjust_heap walks down from the root moving the larger child up (the right one unless right < left).  Five levels per memory
+// round trip: lanes 0..61 hold the subtree under the hole in level order (siblings = lanes 2i, 2i+1), every lane decides locally
+// whether its parent would pick it, a chain of five ballots tells which lanes lie on the path, and those lanes move their
+// entries up at once.
 __device__ __forceinline__ HeapEnt heap_pop(HeapEnt *lds, HeapEnt *glob, uint32_t n) {
     const int lane = lane_id();
     HeapEnt top = hget(lds, glob, 0);
     if (n > 1) {
         const HeapEnt v = hget(lds, glob, n - 1);
         const int64_t len = (int64_t)n - 1;
+        const int64_t half = (len - 1) / 2;                            // nodes below `half` have two children
         int64_t hole = 0;
-        // __adjust_heap: while (hole < (len-1)/2) move the larger child up
-        while (hole < (len - 1) / 2) {
-            const int64_t base = hole;
-            int d = 31 - __builtin_clz((unsigned)lane + 2);            // depth 1..5 below `base` for lanes 0..61
-            int64_t idx = ((base + 1) << d) - 1 + (((int64_t)lane + 2) - (1ll << d));
+        const int d = 31 - __builtin_clz((unsigned)lane + 2);          // depth 1..5 below the hole for lanes 0..61
+        const int o = lane + 2 - (1 << d);                             // offset inside the level
+        const int parent_lane = d > 1 ? (1 << (d - 1)) - 2 + (o >> 1) : 0;
+        while (hole < half) {
+            const int64_t idx = ((hole + 1) << d) - 1 + o, pidx = (idx - 1) >> 1;
             HeapEnt e;
             e.key = 0; e.fval = 0; e.node = 0;
             if (lane < 62 && idx < len) e = hget(lds, glob, (uint64_t)idx);
-            uint64_t pr = ent_prio(e);
-            int o = 0;
+            const uint64_t pr = ent_prio(e), sib = __shfl_xor(pr, 1, 64);
+            // std::__adjust_heap: second = right child; if (right < left) second = left
+            const bool right_less = (o & 1) ? (pr < sib) : (sib < pr);
+            const bool chosen = lane < 62 && pidx < half && ((o & 1) ? !right_less : right_less);
+            uint64_t path = 0;
 #pragma unroll
             for (int t = 1; t <= 5; ++t) {
-                if (!(hole < (len - 1) / 2)) break;
-                int ll = (1 << t) - 2 + 2 * o;                         // lane holding the left child; right child = ll + 1
-                uint64_t pl = __shfl(pr, ll, 64), prr = __shfl(pr, ll + 1, 64);
-                int pick = (prr < pl) ? 0 : 1;                         // second = right; if (right < left) --second
-                HeapEnt ce = shfl_ent(e, ll + pick);
-                if (lane == 0) hset(lds, glob, (uint64_t)hole, ce);
-                hole = 2 * hole + 1 + pick;
-                o = 2 * o + pick;
+                const bool on = d == t && chosen && (t == 1 || ((path >> parent_lane) & 1ull));
+                path |= __ballot(on);
             }
+            if ((path >> lane) & 1ull) hset(lds, glob, (uint64_t)pidx, e);     // every node of the path moves up one level
+            const int deepest = 63 - __builtin_clzll(path);                     // path != 0: the hole has two children
+            hole = __shfl(idx, deepest, 64);
         }
         if ((len & 1) == 0 && hole == (len - 2) / 2) {                 // a last, single (left) child
             HeapEnt ce = hget(lds, glob, (uint64_t)(2 * hole + 1));
