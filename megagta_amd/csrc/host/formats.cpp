@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <zlib.h>
+
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <limits>
@@ -99,39 +102,142 @@ void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out) 
     load_fastx(path, reverse, out);
 }
 
-void load_fastx(const std::string &path, bool reverse, PackedReads &out) {
-    if (path.size() > 3 && path.substr(path.size() - 3) == ".gz") die("gzip'ed sequence files are not supported: %s", path.c_str());
-    std::ifstream f(path);
-    if (!f.is_open()) die("cannot open %s", path.c_str());
-    auto code = [](char c) -> uint8_t {                                                      // sequence_package.h:67-69
+// ---- FASTA / FASTQ records, plain or gzip'ed (the reference reads them with kseq.h over zlib) -------------------
+struct FastxReader::Impl {
+    gzFile f = nullptr;
+    std::string path, line, pending;     // pending: a header line already consumed
+    bool have_pending = false, eof = false;
+    bool getline(std::string &out) {
+        out.clear();
+        char buf[65536];
+        for (;;) {
+            if (!gzgets(f, buf, sizeof(buf))) return !out.empty();
+            size_t n = strlen(buf);
+            if (n && buf[n - 1] == '\n') {
+                out.append(buf, n - 1);
+                if (!out.empty() && out.back() == '\r') out.pop_back();
+                return true;
+            }
+            out.append(buf, n);
+        }
+    }
+};
+
+FastxReader::FastxReader(const std::string &path) : p_(new Impl) {
+    p_->path = path;
+    p_->f = gzopen(path.c_str(), "rb");
+    if (!p_->f) die("cannot open %s", path.c_str());
+}
+FastxReader::~FastxReader() {
+    if (p_->f) gzclose(p_->f);
+    delete p_;
+}
+
+// one record: a header line ('>' or '@'), sequence lines up to the next line that starts with '>', '@' or '+'; after '+' as many
+// quality characters as the sequence has are skipped (kseq.h kseq_read).  Codes: sequence_package.h:67-69 (N -> G)
+bool FastxReader::next(std::vector<uint8_t> &codes) {
+    static const auto code = [](char c) -> uint8_t {
         switch (c) {
         case 'A': case 'a': return 0;
         case 'C': case 'c': return 1;
         case 'G': case 'g': case 'N': case 'n': return 2;
         case 'T': case 't': return 3;
-        default: return 0;
+        default: return 0;                                   // (the reference indexes an uninitialised table here)
         }
     };
-    std::string line;
-    std::vector<uint8_t> seq;
-    bool have = false, fastq = false;
-    auto flush = [&]() { if (have) out.append(seq.data(), seq.size(), reverse); seq.clear(); };
-    while (std::getline(f, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        if (line[0] == '>') { flush(); have = true; fastq = false; continue; }
-        if (line[0] == '@' && !have) { have = true; fastq = true; continue; }
-        if (fastq && line[0] == '+') {               // quality block: skip as many characters as the sequence has
-            size_t need = seq.size(), got = 0;
-            std::string q;
-            while (got < need && std::getline(f, q)) got += q.size();
-            flush();
-            have = false;
-            continue;
+    codes.clear();
+    Impl &r = *p_;
+    if (r.eof) return false;
+    if (!r.have_pending) {                                   // look for the first header
+        for (;;) {
+            if (!r.getline(r.line)) { r.eof = true; return false; }
+            if (!r.line.empty() && (r.line[0] == '>' || r.line[0] == '@')) break;
         }
-        for (char c : line) seq.push_back(code(c));
     }
-    flush();
+    r.have_pending = false;
+    for (;;) {
+        if (!r.getline(r.line)) { r.eof = true; return true; }
+        if (r.line.empty()) continue;
+        const char c = r.line[0];
+        if (c == '>' || c == '@') { r.have_pending = true; return true; }
+        if (c == '+') {
+            size_t got = 0;
+            while (got < codes.size() && r.getline(r.line)) got += r.line.size();
+            return true;
+        }
+        for (char ch : r.line) codes.push_back(code(ch));
+    }
+}
+
+void load_fastx(const std::string &path, bool reverse, PackedReads &out) {
+    FastxReader rd(path);
+    std::vector<uint8_t> codes;
+    while (rd.next(codes)) out.append(codes.data(), codes.size(), reverse);
+}
+
+// ---- buildlib (build_read_lib.cpp, read_lib_functions-inl.h:116-225, sequence_manager.cpp:109-216,375-410) ----------------
+// read_lib_file: per library one free-text line, then `pe f1 f2` | `se f` | `interleaved f`.  PREFIX.bin: per read uint32 length +
+// ceil(length / 16) words, 2 bit per base, base j of a word at bits 30-2j, zero padded, forward orientation, no N trimming;
+// PREFIX.lib_info: "total_bases total_reads" then per library its text line and "from to max_read_len pe|se".
+void build_read_lib(const std::string &lib_file, const std::string &out_prefix) {
+    std::ifstream cfg(lib_file);
+    if (!cfg.is_open()) die("File to open read_lib file: %s", lib_file.c_str());
+    FILE *bin = fopen((out_prefix + ".bin").c_str(), "wb");
+    if (!bin) die("cannot write %s.bin", out_prefix.c_str());
+    struct Lib { std::string metadata; long long from, to; int max_len; bool pe; };
+    std::vector<Lib> libs;
+    long long total_reads = 0, total_bases = 0;
+    std::vector<uint8_t> codes;
+    std::vector<uint32_t> words;
+    auto write_read = [&](const std::vector<uint8_t> &c, int &max_len) {
+        const uint32_t len = (uint32_t)c.size();
+        words.assign((len + 15) / 16, 0u);
+        for (uint32_t i = 0; i < len; ++i) words[i >> 4] |= (uint32_t)c[i] << (30 - 2 * (i & 15));
+        fwrite(&len, 4, 1, bin);
+        if (!words.empty()) fwrite(words.data(), 4, words.size(), bin);
+        ++total_reads;
+        total_bases += len;
+        max_len = std::max(max_len, (int)len);
+    };
+    std::string metadata, rest;
+    while (std::getline(cfg, metadata)) {
+        std::string type, f1, f2;
+        if (!(cfg >> type)) break;
+        Lib lib{metadata, total_reads, 0, 0, type != "se"};
+        if (type == "pe") {
+            if (!(cfg >> f1 >> f2)) die("pe library needs two files: %s", metadata.c_str());
+            FastxReader r1(f1), r2(f2);
+            std::vector<uint8_t> c2;
+            for (;;) {
+                const bool a = r1.next(codes), b = r2.next(c2);
+                if (a != b) die("PE library files hold different numbers of reads: %s", metadata.c_str());
+                if (!a) break;
+                write_read(codes, lib.max_len);
+                write_read(c2, lib.max_len);
+            }
+        } else if (type == "se" || type == "interleaved") {
+            if (!(cfg >> f1)) die("library needs a file: %s", metadata.c_str());
+            FastxReader r1(f1);
+            while (r1.next(codes)) write_read(codes, lib.max_len);
+        } else {
+            fprintf(stderr, "Cannot identify read library type %s\n", type.c_str());
+            die("Valid types: pe, se, interleaved");
+        }
+        lib.to = total_reads - 1;
+        if (lib.pe && (total_reads - lib.from) % 2 != 0) {
+            fprintf(stderr, "PE library number of reads is odd: %lld!\n", total_reads - lib.from);
+            die("File(s): %s", metadata.c_str());
+        }
+        logf("Lib %zu (%s): %s, %lld reads, %d max length\n", libs.size(), metadata.c_str(), type.c_str(), total_reads - lib.from, lib.max_len);
+        libs.push_back(lib);
+        std::getline(cfg, rest);                                     // the rest of the type line
+    }
+    fclose(bin);
+    FILE *info = fopen((out_prefix + ".lib_info").c_str(), "w");
+    if (!info) die("cannot write %s.lib_info", out_prefix.c_str());
+    fprintf(info, "%lld %lld\n", total_bases, total_reads);
+    for (const Lib &l : libs) fprintf(info, "%s\n%lld %lld %d %s\n", l.metadata.c_str(), l.from, l.to, l.max_len, l.pe ? "pe" : "se");
+    fclose(info);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -34,7 +34,19 @@ struct PackedReads {
 void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out);          // ReadBinaryLibs
 void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out);        // s1.cpp:104-134
 void load_read_bin(const std::string &bin_path, bool reverse, PackedReads &out);         // a bare reads.lib.bin, read to EOF (findstart)
-void load_fastx(const std::string &path, bool reverse, PackedReads &out);                // FASTA / FASTQ, N -> G (sequence_package.h:67-69)
+void load_fastx(const std::string &path, bool reverse, PackedReads &out);                // FASTA / FASTQ (plain or .gz), N -> G (sequence_package.h:67-69)
+class FastxReader {                                                                      // kseq.h's record rules over zlib
+  public:
+    explicit FastxReader(const std::string &path);
+    ~FastxReader();
+    bool next(std::vector<uint8_t> &codes);                                              // false at end of file
+    FastxReader(const FastxReader &) = delete;
+    FastxReader &operator=(const FastxReader &) = delete;
+  private:
+    struct Impl;
+    Impl *p_;
+};
+void build_read_lib(const std::string &lib_file, const std::string &out_prefix);          // `megagta buildlib`, build_read_lib.cpp
 
 // ---- findstart ----------------------------------------------------------------------------------------
 struct RefWords {

@@ -294,7 +294,13 @@ int main(int argc, char **argv) {
     if (sub == "buildgraph") return main_buildgraph(argc - 1, argv + 1);
     if (sub == "search") return main_search(argc - 1, argv + 1);
     if (sub == "findstart") return main_findstart(argc - 1, argv + 1);
+    if (sub == "buildlib") {                                             // build_read_lib.cpp:8-20 (host only: file formats, no kernel)
+        if (argc < 4) { fprintf(stderr, "Usage %s <read_lib_file> <out_prefix>\n", argv[1]); return 1; }
+        RssLine rss;
+        build_read_lib(argv[2], argv[3]);
+        return 0;
+    }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
-    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildgraph, search, findstart): run it with the reference's megagta binary\n", sub.c_str());
+    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildlib, buildgraph, findstart, search): run it with the reference's megagta binary\n", sub.c_str());
     return 1;
 }

@@ -8,8 +8,8 @@ Drop-in surface kept (reference src/megagta.py): options `-r/-1/-2/--12 -g -k -c
 (:815-816), one child process per step with stderr relayed into the log, first non-zero exit aborts.
 
 The two sub-commands on the accelerated path, `buildgraph` and `search`, run from THIS package's
-`bin/megagta` (C++ host + libmegagta_hip.so), and so does `findstart`.  Every other step (`buildlib`, `denovo`,
-`filterbylen`, `translate`) is outside the path and is run from the binary given by `--ref-bin`
+`bin/megagta` (C++ host + libmegagta_hip.so), and so do `findstart` and `buildlib` (host only).  The remaining steps (`denovo`,
+`filterbylen`, `translate`) are outside the path and are run from the binary given by `--ref-bin`
 (or $MEGAGTA_REF_BIN): the stock MegaGTA executable.
 """
 from __future__ import annotations
@@ -241,7 +241,7 @@ def build_lib():
                 f.write(opt.pe1[i] + "," + opt.pe2[i] + "\npe " + os.path.abspath(opt.pe1[i]) + " " + os.path.abspath(opt.pe2[i]) + "\n")
             for r in opt.se:
                 f.write(r + "\nse " + os.path.abspath(r) + "\n")
-        run_step([need_ref("buildlib"), "buildlib", opt.lib, opt.lib], "Converting reads to binaries")
+        run_step([opt.bin, "buildlib", opt.lib, opt.lib], "Converting reads to binaries")
     write_cp()
 
 

@@ -82,3 +82,38 @@ def parse_probe_astar(lines):
         res.append(dict(idx=int(t[1]), kmer=t[2], start_state=int(t[3]), R=side(t[iR + 1:iL]), L=side(t[iL + 1:ic]),
                         contig=t[ic + 1]))
     return res
+
+
+def write_buildlib_inputs(d: str) -> str:
+    """seeded read files for `megagta buildlib` (multi-line FASTA with empty reads / N / lower case, gzip'ed paired FASTQ,
+    interleaved FASTQ whose quality lines start with '@' and '>'); returns the path of the read_lib file"""
+    import gzip
+    rng = np.random.default_rng(3)
+
+    def seq(n):
+        s = "".join("ACGT"[x] for x in rng.integers(0, 4, n))
+        if n > 30 and rng.random() < 0.3:
+            s = s[:5] + "N" + s[6:20] + "n" + s[21:]
+        if rng.random() < 0.2:
+            s = s.lower()
+        return s
+
+    with open(f"{d}/a.fa", "w") as f:
+        for i in range(200):
+            s = seq(int(rng.integers(0, 300)))
+            f.write(f">r{i} comment\n")
+            for j in range(0, len(s), 60):
+                f.write(s[j:j + 60] + "\n")
+    for tag in "12":
+        with gzip.GzipFile(f"{d}/p{tag}.fq.gz", "wb", mtime=0) as f:
+            for i in range(150):
+                s = seq(int(rng.integers(20, 160)))
+                f.write(f"@p{i}/{tag}\n{s}\n+\n{'I' * len(s)}\n".encode())
+    with open(f"{d}/i.fq", "w") as f:
+        for i in range(100):
+            s = seq(100)
+            q = ("@" if i % 3 == 0 else ">" if i % 3 == 1 else "I") + "I" * 99
+            f.write(f"@i{i}\n{s}\n+i{i}\n{q}\n")
+    lib = f"{d}/reads.lib"
+    open(lib, "w").write(f"a.fa\nse {d}/a.fa\np1.fq.gz,p2.fq.gz\npe {d}/p1.fq.gz {d}/p2.fq.gz\ni.fq\ninterleaved {d}/i.fq\n")
+    return lib
