@@ -224,6 +224,91 @@ static int main_search(int argc, char **argv) {
     return 0;
 }
 
+// ---- the two one-screen text filters of the driver's last step (host only) ------------------------------------------------
+// FASTA/FASTQ records with name and comment as kseq.h splits them (name = header up to the first blank)
+struct TextRecord { std::string name, comment, seq; bool has_comment; };
+static bool next_text_record(FILE *f, std::string &pending, TextRecord &r) {
+    auto getline = [&](std::string &out) {
+        out.clear();
+        int c;
+        bool any = false;
+        while ((c = fgetc(f)) != EOF) { any = true; if (c == '\n') break; out.push_back((char)c); }
+        if (!out.empty() && out.back() == '\r') out.pop_back();
+        return any;
+    };
+    std::string line;
+    if (pending.empty()) {
+        for (;;) {
+            if (!getline(line)) return false;
+            if (!line.empty() && (line[0] == '>' || line[0] == '@')) break;
+        }
+    } else { line = pending; pending.clear(); }
+    size_t sp = line.find_first_of(" \t");
+    r.name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+    r.has_comment = sp != std::string::npos;
+    r.comment = r.has_comment ? line.substr(sp + 1) : "";
+    r.seq.clear();
+    for (;;) {
+        if (!getline(line)) return true;
+        if (line.empty()) continue;
+        if (line[0] == '>' || line[0] == '@') { pending = line; return true; }
+        if (line[0] == '+') {
+            size_t got = 0;
+            while (got < r.seq.size() && getline(line)) got += line.size();
+            return true;
+        }
+        r.seq += line;
+    }
+}
+
+// cat contigs.fa | megagta filterbylen <min_len>     (filter_by_len.cpp:33-61)
+static int main_filterbylen(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "Usage: cat contigs.fa | %s <min_len>\n", argv[0]); return 1; }
+    const unsigned min_len = (unsigned)atoi(argv[1]);
+    std::map<long long, size_t> hist;
+    std::string pending, comment = "(null)";                         // kseq never clears its comment buffer: a record without a
+    TextRecord r;                                                      // comment prints the previous one, the first ones "(null)"
+    while (next_text_record(stdin, pending, r)) {
+        if (r.has_comment) comment = r.comment;
+        if (r.seq.size() >= min_len) {
+            ++hist[(long long)r.seq.size()];
+            printf(">%s %s\n%s\n", r.name.c_str(), comment.c_str(), r.seq.c_str());
+        }
+    }
+    double sum = 0;
+    size_t n = 0;
+    for (auto &kv : hist) { sum += 1.0 * kv.first * kv.second; n += kv.second; }
+    long long n50 = 0;
+    double acc = 0;
+    for (auto it = hist.rbegin(); it != hist.rend(); ++it) { acc += (double)it->second * it->first; if (acc >= sum * 0.5) { n50 = it->first; break; } }
+    fprintf(stderr, "%d contigs, total %lld bp, min %lld bp, max %lld bp, avg %d bp, N50 %lld bp\n", (int)n, (long long)sum,
+            hist.empty() ? 0LL : hist.begin()->first, hist.empty() ? 0LL : hist.rbegin()->first, int((n ? sum / n : 0) + 0.5), n50);
+    return 0;
+}
+
+// megagta translate <nucl_seq>     (translate.cpp:14-35): frame 0, standard code, lower case, any codon with a letter outside ACGT -> x
+static int main_translate(int argc, char **argv) {
+    if (argc == 1) { fprintf(stderr, "Usage: %s <nucl_seq> \n", argv[0]); return 1; }
+    FILE *f = fopen(argv[1], "r");
+    if (!f) die("cannot open %s", argv[1]);
+    static const char *kCodon = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+    auto code = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                                          case 'T': case 't': case 'U': case 'u': return 3; default: return -1; } };
+    std::string pending;
+    TextRecord r;
+    while (next_text_record(f, pending, r)) {
+        std::string aa;
+        for (size_t i = 0; i + 3 <= r.seq.size(); i += 3) {
+            int a = code(r.seq[i]), b = code(r.seq[i + 1]), c = code(r.seq[i + 2]);
+            char ch = (a < 0 || b < 0 || c < 0) ? 'X' : kCodon[16 * a + 4 * b + c];
+            aa.push_back((char)tolower(ch));
+        }
+        printf(">%s\n%s\n", r.name.c_str(), aa.c_str());
+    }
+    fclose(f);
+    return 0;
+}
+
 // megagta findstart <ref_seq> <read.lib.bin> <k_size> [num_threads=0] [contigs.fa]     (fast_kmer_filter.cpp:49-190)
 static int main_findstart(int argc, char **argv) {
     if (argc == 1) {
@@ -294,6 +379,8 @@ int main(int argc, char **argv) {
     if (sub == "buildgraph") return main_buildgraph(argc - 1, argv + 1);
     if (sub == "search") return main_search(argc - 1, argv + 1);
     if (sub == "findstart") return main_findstart(argc - 1, argv + 1);
+    if (sub == "filterbylen") return main_filterbylen(argc - 1, argv + 1);
+    if (sub == "translate") return main_translate(argc - 1, argv + 1);
     if (sub == "buildlib") {                                             // build_read_lib.cpp:8-20 (host only: file formats, no kernel)
         if (argc < 4) { fprintf(stderr, "Usage %s <read_lib_file> <out_prefix>\n", argv[1]); return 1; }
         RssLine rss;
@@ -301,6 +388,6 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
-    fprintf(stderr, "sub-command '%s' is outside the accelerated path (buildlib, buildgraph, findstart, search): run it with the reference's megagta binary\n", sub.c_str());
+    fprintf(stderr, "sub-command '%s' is not built here (buildlib, buildgraph, findstart, search, filterbylen, translate are): run it with the reference's megagta binary\n", sub.c_str());
     return 1;
 }

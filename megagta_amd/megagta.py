@@ -8,9 +8,9 @@ Drop-in surface kept (reference src/megagta.py): options `-r/-1/-2/--12 -g -k -c
 (:815-816), one child process per step with stderr relayed into the log, first non-zero exit aborts.
 
 The two sub-commands on the accelerated path, `buildgraph` and `search`, run from THIS package's
-`bin/megagta` (C++ host + libmegagta_hip.so), and so do `findstart` and `buildlib` (host only).  The remaining steps (`denovo`,
-`filterbylen`, `translate`) are outside the path and are run from the binary given by `--ref-bin`
-(or $MEGAGTA_REF_BIN): the stock MegaGTA executable.
+`bin/megagta` (C++ host + libmegagta_hip.so), and so do `findstart` and the host-only `buildlib`, `filterbylen`, `translate`: a
+single-k run needs nothing else.  `denovo` (between the k values of a multi-k run) is outside the path and is run from the binary
+given by `--ref-bin` (or $MEGAGTA_REF_BIN): the stock MegaGTA executable.
 """
 from __future__ import annotations
 
@@ -299,12 +299,12 @@ def search_contigs(k):
         os.makedirs(d, exist_ok=True)
         if should_run():
             with open(graph_prefix(k) + "_raw_contigs_" + gene + ".fasta") as fin, open(d + "/nucl_merged.fasta", "w") as fout:
-                run_step([need_ref("filterbylen"), "filterbylen", str(opt.min_contig_len)],
+                run_step([opt.bin, "filterbylen", str(opt.min_contig_len)],
                          "Filtering contigs with minimum length = %d" % opt.min_contig_len, stdin=fin, stdout=fout)
         write_cp()
         if should_run():
             with open(d + "/prot_merged.fasta", "w") as fout:
-                run_step([need_ref("translate"), "translate", d + "/nucl_merged.fasta"], "Translating nucl contigs to aa contigs", stdout=fout)
+                run_step([opt.bin, "translate", d + "/nucl_merged.fasta"], "Translating nucl contigs to aa contigs", stdout=fout)
         write_cp()
 
 

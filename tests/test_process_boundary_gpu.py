@@ -36,8 +36,9 @@ def test_single_k_pipeline_matches_reference_artifacts(toy_inputs, oracle, golde
     _need()
     d = toy_inputs
     out = d / "out1"
+    # a single-k run needs no reference binary at all: buildlib, buildgraph, findstart, search, filterbylen, translate are ours
     r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "45", "-o", str(out),
-                        "-t", "4", "--ref-bin", REF], capture_output=True, text=True)
+                        "-t", "4", "--min-contig-len", "150"], capture_output=True, text=True, env={**os.environ, "MEGAGTA_REF_BIN": ""})
     assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
     toy = os.path.join(golden_dir, "toy")
     # graph files written by OUR buildgraph decode (with the oracle's reader = the reference format) to the reference's stream
@@ -52,6 +53,12 @@ def test_single_k_pipeline_matches_reference_artifacts(toy_inputs, oracle, golde
     lines = (out / "k44" / "44_raw_contigs_rplB.fasta").read_text().splitlines()
     assert lines[0::2] == [f">rplB_contig_{2 * i}_contig_{2 * i + 1}" for i in range(len(seeds))]
     assert lines[1::2] == [gold[l.split("\t")[3].lower()] for l in seeds]
+    # the last step's text filters against the reference's (filter_by_len.cpp, translate.cpp), header quirks included
+    raw = out / "k44" / "44_raw_contigs_rplB.fasta"
+    nucl = subprocess.run([REF, "filterbylen", "150"], stdin=open(raw), capture_output=True, text=True, check=True).stdout
+    assert (out / "contigs" / "rplB" / "nucl_merged.fasta").read_text() == nucl and nucl.count(">") > 10
+    prot = subprocess.run([REF, "translate", str(out / "contigs" / "rplB" / "nucl_merged.fasta")], capture_output=True, text=True, check=True).stdout
+    assert (out / "contigs" / "rplB" / "prot_merged.fasta").read_text() == prot
     # driver artefacts
     assert (out / "opts.txt").exists() and (out / "contigs" / "rplB" / "nucl_merged.fasta").exists()
     done = [l.split() for l in (out / "tmp" / "cp.txt").read_text().splitlines()]
