@@ -1610,8 +1610,10 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         }
         // does the pass fit?  two key buffers (the second doubles as emit scratch) + census + outputs (estimate)
         uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
+        // either key buffer may end up as the emitter's scratch (11 bytes per key: run start u64, record u16, info u8), whichever
+        // the last sort pass leaves idle: both hold >= 12 bytes per key
         uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12);
-        uint64_t need = n_items * sizeof(Key<W>) + key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
+        uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
         const uint64_t avail = budget - std::min<uint64_t>(budget, other);
         if (need + need / 8 > avail && width > 1) {                   // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
@@ -1626,7 +1628,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         h_items.assign((size_t)nb * 3, 0);
         uint64_t n_edges = 0, n_large = 0, n_tips = 0;
         if (n_items > 0) {
-            Key<W> *d_a = pool_get<Key<W>>(ctx, S_KEYS_A, n_items * sizeof(Key<W>));
+            Key<W> *d_a = pool_get<Key<W>>(ctx, S_KEYS_A, key_b);
             Key<W> *d_b = pool_get<Key<W>>(ctx, S_KEYS_B, key_b);
             // ---- 3. write keys
             t_ph.start();

@@ -263,3 +263,25 @@ def test_fourth_leading_byte_and_wide_run_prefix(ctx, oracle):
     assert hi - lo == g.records.size > 10_000
     assert np.array_equal(g.records, o.records[lo:hi])
     assert g.bucket_items[bx] == hi - lo and g.bucket_items.sum() == hi - lo
+
+
+@pytest.mark.parametrize("k,L", [(29, 100), (60, 150), (95, 250), (127, 250)])
+def test_routes_agree_at_scale_other_key_widths(ctx, k, L):
+    """10^7..10^8 sort items, W = 2, 4, 6, 8 key words, read lengths 100..250: the comparison finish and the LSD finish of the LDS
+    tiles (independent code after the tile prologue) produce the same stream, and so does a build split over three bucket ranges"""
+    from megagta_amd import synth
+    mg = synth.make_metagenome(200_000, L, (("rplB", 60),), seed=k)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    rd = ctx.upload_reads(packed, start)
+    a = ctx.build_sdbg(rd, k)
+    assert a.stats["n_lsd_tiles"] * 4 < a.stats["n_items"] / 4096          # the comparison route did the work
+    ctx.set_full_lsd(2)
+    try:
+        b = ctx.build_sdbg(rd, k)
+    finally:
+        ctx.set_full_lsd(0)
+    _same(a, b)
+    parts = [ctx.build_sdbg(rd, k, bucket_range=r) for r in ((0, 20000), (20000, 47000), (47000, 65536))]
+    assert np.array_equal(np.concatenate([p.records for p in parts]), a.records)
+    assert np.array_equal(np.concatenate([p.tips for p in parts]), a.tips)
+    assert np.array_equal(sum(p.bucket_items for p in parts), a.bucket_items)
