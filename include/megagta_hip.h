@@ -78,6 +78,7 @@ typedef struct mgta_build_stats {
     int64_t n_big_segments;          /* key segments deferred by the tiled LDS sort (sorted alone in LDS, or by global passes) */
     int64_t n_lsd_tiles;             /* LDS tiles whose runs were too long to finish by comparison (LSD passes over every digit) */
     uint64_t bytes_peak;             /* device bytes allocated at the peak */
+    double ms_stage1;                /* min_count >= 2: solid-edge counting + mercy edges, before (and not part of) ms_total */
 } mgta_build_stats;
 
 /* a1: packed reads as `buildgraph` holds them — every read REVERSED (cx1_read2sdbg_s1.cpp:97,117),

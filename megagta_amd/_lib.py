@@ -26,7 +26,7 @@ class BuildStats(C.Structure):
                 ("n_tips", C.c_int64), ("n_large", C.c_int64), ("n_sort_launches", C.c_int64), ("ms_total", C.c_double),
                 ("ms_count", C.c_double), ("ms_gen", C.c_double), ("ms_sort", C.c_double), ("ms_emit", C.c_double),
                 ("ms_d2h", C.c_double), ("ms_sort_scatter", C.c_double), ("ms_local_sort", C.c_double), ("n_big_segments", C.c_int64), ("n_lsd_tiles", C.c_int64),
-                ("bytes_peak", C.c_uint64)]
+                ("bytes_peak", C.c_uint64), ("ms_stage1", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1250,7 +1250,7 @@ static std::vector<Digit> low_digit_plan(int k, int W, int P) {
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_MULTI_COUNT, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_MULTI_COUNT, S_POS2ID, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -1402,6 +1402,15 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         set_error("mercy edges: reads longer than %d bases (%u) are not supported", kMercyMaxLen, max_len);
         return MGTA_EUNSUPPORTED;
     }
+    // base index -> read id table (one entry per 1024 bases, one past the end) and the left shift that puts the highest bit a mercy
+    // candidate (base index << 2 | code) can have at bit 63
+    if (n_reads >= 0xFFFFFFFFull) { set_error("stage 1: more than 2^32 reads"); return MGTA_EUNSUPPORTED; }
+    const uint64_t bases_bound = rd->n_words * 16 + 16;
+    const uint64_t n_pos_entries = (bases_bound >> kPosStepLog) + 2;
+    uint32_t *d_pos2id = pool_get<uint32_t>(ctx, S_POS2ID, n_pos_entries * 4);
+    hipLaunchKernelGGL(pos_to_id_kernel, dim3((unsigned)((n_pos_entries + 255) / 256)), dim3(256), 0, stream, rd->d_start, n_reads, n_pos_entries, d_pos2id);
+    int cand_shift = 0;
+    while (cand_shift < 40 && (((bases_bound << 2) | 3ull) << (cand_shift + 1)) >> (cand_shift + 1) == ((bases_bound << 2) | 3ull)) ++cand_shift;
     const int num_k1 = std::max<int>(0, (int)max_len - k);                 // num_k1_per_read, s1.cpp:152
     const uint64_t n_bits = (uint64_t)num_k1 * n_short;
     unsigned long long *d_solid = pool_get<unsigned long long>(ctx, S_SOLID, (n_bits / 64 + 2) * 8);
@@ -1478,8 +1487,9 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                                run_start, run_info);
             unsigned rb = (unsigned)((m + 255) / 256);
             hipLaunchKernelGGL(s1_group_kernel, dim3(rb), dim3(256), 0, stream, run_start, run_info, m, n_items, min_count, group_mask);
-            hipLaunchKernelGGL((s1_apply_kernel<W>), dim3(rb), dim3(256), 0, stream, sorted, run_start, run_info, group_mask, m, n_items, min_count,
-                               k, rd->d_start, n_reads, n_short, num_k1, d_solid, d_edge_count, d_mercy, d_mercy_count, mercy_cap, need_mercy);
+            hipLaunchKernelGGL((s1_apply_kernel<W>), dim3(std::min(rb, 8192u)), dim3(256), 0, stream, sorted, run_start, run_info, group_mask, m, n_items, min_count,
+                               k, rd->d_start, n_reads, n_short, num_k1, d_solid, d_edge_count, d_mercy, d_mercy_count, mercy_cap, need_mercy,
+                               d_pos2id, cand_shift);
         }
         b_lo = b_hi;
     }
@@ -1501,7 +1511,7 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             Key<2> *cs = device_sort<2>(ctx, stream, d_mercy, d_tmp, n_cand, 4, low64, nullptr, nullptr);
             if (!cs) return MGTA_EUNSUPPORTED;
             hipLaunchKernelGGL(mercy_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, stream, cs, n_cand, rd->d_start, n_reads, k, num_k1,
-                               d_solid, d_num_mercy);
+                               d_solid, d_num_mercy, d_pos2id, cand_shift);
             MGTA_HIP_CHECK(hipStreamSynchronize(stream));
         }
     }
@@ -1547,9 +1557,12 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         unsigned long long *sol = nullptr;
         int nk1 = 0;
         int rc1 = MGTA_EUNSUPPORTED;
+        Timer t_s1(stream);
+        t_s1.start();
         if constexpr (W <= 7) rc1 = run_stage1<W>(ctx, rd, n_short, k, min_count, need_mercy, budget, &sol, &nk1, &S);
         else set_error("min_count > 1 with k > 110 is not supported (sort record of %d words)", W + 2);
         if (rc1 != MGTA_OK) return rc1;
+        S.ms_stage1 = t_s1.stop();
         sa.is_solid = sol; sa.num_k1_per_read = nk1;
         // run_stage1 may have re-grown pool slots: refresh the small pointers
         d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);

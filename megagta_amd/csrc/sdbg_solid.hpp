@@ -249,6 +249,24 @@ __global__ __launch_bounds__(256) void s1_group_kernel(const uint64_t *run_start
     group_mask[s] = (uint16_t)(has_in | (has_out << 4) | (l_has_out << 8) | (r_has_in << 12));
 }
 
+// read that holds absolute base index `abs` (SequencePackage::get_id, sequence_package.h:164-188): like the reference's pos_to_id_
+// table, a coarse table (one entry per 1024 bases = the last read starting at or before that base) narrows the search to a few reads
+constexpr int kPosStepLog = 10;
+__global__ __launch_bounds__(256) void pos_to_id_kernel(const uint64_t *start_idx, uint64_t n_reads, uint64_t n_entries, uint32_t *table) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint64_t abs = i << kPosStepLog;
+    uint64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (start_idx[mid] <= abs) lo = mid; else hi = mid; }
+    table[i] = (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t read_of_base(const uint64_t *start_idx, uint64_t n_reads, const uint32_t *table, uint64_t abs) {
+    uint64_t lo = table[abs >> kPosStepLog], hi = (uint64_t)table[(abs >> kPosStepLog) + 1] + 1;   // the table has one entry past the last base
+    if (hi > n_reads) hi = n_reads;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (start_idx[mid] <= abs) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // per run: apply the verdict to every item of the run (s1.cpp:750-828)
 template <int W1>
 __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, const uint64_t *run_start, const uint16_t *run_info,
@@ -256,9 +274,13 @@ __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, 
                                                        const uint64_t *start_idx, uint64_t n_reads, uint64_t n_short, int num_k1_per_read,
                                                        unsigned long long *is_solid, unsigned long long *edge_count /* [65536] */,
                                                        Key<2> *mercy, unsigned long long *mercy_count, uint64_t mercy_cap,
-                                                       int need_mercy) {
-    uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= m) return;
+                                                       int need_mercy, const uint32_t *pos_to_id, int cand_shift) {
+    // multiplicities are few and small: counted in LDS, flushed once per workgroup (a global atomic per (k+1)-mer would
+    // hammer a handful of addresses a billion times)
+    __shared__ unsigned int s_count[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_count[i] = 0;
+    __syncthreads();
+    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (uint64_t)gridDim.x * 256) {
     const uint32_t inf = run_info[s];
     const int hd = inf & 7, tl = (inf >> 3) & 7;
     // group head + masks
@@ -272,12 +294,21 @@ __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, 
     while (b < m && !((run_info[b] >> 12) & 1) && (run_info[b] & 63u) == (inf & 63u)) ++b;
     const uint64_t cnt_ht = (b < m ? run_start[b] : n_items) - run_start[a];
     const bool real = hd != kDollar && tl != kDollar;
-    if (real && a == s) atomicAdd(&edge_count[cnt_ht > 65535 ? 65535 : cnt_ht], 1ull);       // one count per (k+1)-mer (s1.cpp:756-758)
+    if (real && a == s) {                                                                  // one count per (k+1)-mer (s1.cpp:756-758)
+        if (cnt_ht < 1024) atomicAdd(&s_count[cnt_ht], 1u);
+        else atomicAdd(&edge_count[cnt_ht > 65535 ? 65535 : cnt_ht], 1ull);
+    }
     const bool solid = real && cnt_ht >= (uint64_t)threshold;
     const uint64_t end = s + 1 < m ? run_start[s + 1] : n_items;
     auto cand = [&](uint64_t v) {
         if (!need_mercy) return;
-        unsigned long long q = atomicAdd(mercy_count, 1ull);
+        // the lanes that are here together share one cursor update
+        const uint64_t act = __ballot(1);
+        const int leader = __ffsll((long long)act) - 1;
+        unsigned long long q = 0;
+        if (lane_id() == leader) q = atomicAdd(mercy_count, (unsigned long long)__popcll(act));
+        q = __shfl(q, leader, 64) + (unsigned long long)__popcll(act & lanemask_lt());
+        v <<= cand_shift;                                              // left-aligned: the sort's leading bytes are not all zero
         if (q < mercy_cap) { mercy[q].w[0] = (uint32_t)(v >> 32); mercy[q].w[1] = (uint32_t)v; }
     };
     for (uint64_t i = run_start[s]; i < end; ++i) {
@@ -286,10 +317,7 @@ __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, 
         uint64_t fo = info >> 6;
         int strand = (int)(fo & 1);
         uint64_t abs = fo >> 1;
-        // read id: last start_idx <= abs   (SequencePackage::get_id, sequence_package.h:164-188)
-        uint64_t lo = 0, hi = n_reads;
-        while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (start_idx[mid] <= abs) lo = mid; else hi = mid; }
-        const uint64_t read_id = lo;
+        const uint64_t read_id = read_of_base(start_idx, n_reads, pos_to_id, abs);
         if (read_id >= n_short) continue;                                                      // assist sequences are always solid
         const int64_t offset = (int64_t)(abs - start_idx[read_id]) - 1;
         const int64_t l_off = strand == 0 ? offset : offset + 1, r_off = strand == 0 ? offset + 1 : offset;
@@ -312,6 +340,10 @@ __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, 
             }
         }
     }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256)
+        if (s_count[i]) atomicAdd(&edge_count[i], (unsigned long long)s_count[i]);
 }
 
 // ---- mercy edges (s2_read_mercy_prepare, cx1_read2sdbg_s2.cpp:106-250) ---------------------------------
@@ -319,16 +351,13 @@ constexpr int kMercyMaxLen = 1024;   // longest short read handled (flags live i
 
 // sorted candidates -> one wave per read: flag arrays, then the serial gap-filling scan
 __global__ __launch_bounds__(256) void mercy_kernel(const Key<2> *cands, uint64_t n_cand, const uint64_t *start_idx, uint64_t n_reads, int k,
-                                                    int num_k1_per_read, unsigned long long *is_solid, unsigned long long *num_mercy) {
+                                                    int num_k1_per_read, unsigned long long *is_solid, unsigned long long *num_mercy,
+                                                    const uint32_t *pos_to_id, int cand_shift) {
     __shared__ uint8_t s_flags[4][3][kMercyMaxLen + 64];
     const int lane = lane_id(), wv = wave_id();
     uint8_t *no_in = s_flags[wv][0], *no_out = s_flags[wv][1], *has_k = s_flags[wv][2];
-    auto val = [&](uint64_t i) { return ((uint64_t)cands[i].w[0] << 32) | cands[i].w[1]; };
-    auto read_of = [&](uint64_t abs) {
-        uint64_t lo = 0, hi = n_reads;
-        while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (start_idx[mid] <= abs) lo = mid; else hi = mid; }
-        return lo;
-    };
+    auto val = [&](uint64_t i) { return (((uint64_t)cands[i].w[0] << 32) | cands[i].w[1]) >> cand_shift; };
+    auto read_of = [&](uint64_t abs) { return read_of_base(start_idx, n_reads, pos_to_id, abs); };
     // every wave takes the candidate ranges whose first candidate index is a multiple-of-stride hit: simple static split by
     // candidate index: wave g handles the reads whose FIRST candidate lies in [g*64, g*64+64)
     const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;

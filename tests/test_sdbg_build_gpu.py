@@ -285,3 +285,24 @@ def test_routes_agree_at_scale_other_key_widths(ctx, k, L):
     assert np.array_equal(np.concatenate([p.records for p in parts]), a.records)
     assert np.array_equal(np.concatenate([p.tips for p in parts]), a.tips)
     assert np.array_equal(sum(p.bucket_items for p in parts), a.bucket_items)
+
+
+@pytest.mark.parametrize("k,m", [(29, 2), (60, 3)])
+def test_stage1_routes_agree_at_scale(ctx, k, m):
+    """-m >= 2 on 3*10^7 stage-1 sort items (payload-carrying keys, masked comparisons): comparison finish == LSD finish, stream and
+    .counting histogram alike"""
+    from megagta_amd import synth
+    mg = synth.make_metagenome(200_000, 150, (("rplB", 60),), seed=100 + k)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    rd = ctx.upload_reads(packed, start)
+    a = ctx.build_sdbg(rd, k, min_count=m, need_mercy=True)
+    ca = ctx.last_counting().copy()
+    ctx.set_full_lsd(2)
+    try:
+        b = ctx.build_sdbg(rd, k, min_count=m, need_mercy=True)
+        cb = ctx.last_counting().copy()
+    finally:
+        ctx.set_full_lsd(0)
+    _same(a, b)
+    assert np.array_equal(ca, cb) and ca.sum() > 0
+    assert 0 < a.records.size < ctx.build_sdbg(rd, k).records.size
