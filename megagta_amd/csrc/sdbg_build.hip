@@ -227,6 +227,62 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     }
 }
 
+// Key generation when the item layout is known in closed form (k+1 odd: no palindromes; every position solid; every bucket
+// wanted): read r owns 2 npos + 4 consecutive keys [left $ of e, left $ of rc, then (e, rc) of every position, right $ of e,
+// right $ of rc], so every lane stores its two keys at a fixed place: no staging, no prefix sums, fully coalesced 24-byte pairs.
+template <int W>
+__global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs a) {
+    __shared__ uint32_t s_read_base[kReadsPerBlock];
+    const int k = a.k;
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
+    const uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
+    if (wv == 0) {                                                    // first key of every read of the workgroup
+        uint32_t items = 0;
+        if (r0 + lane < r1) {
+            const int len = (int)(a.start[r0 + lane + 1] - a.start[r0 + lane]);
+            if (len >= k + 1) items = 2u * (uint32_t)(len - k) + 4u;
+        }
+        s_read_base[lane] = wave_incl_scan(items) - items;
+    }
+    __syncthreads();
+    Key<W> *out = reinterpret_cast<Key<W> *>(a.out) + a.block_base[blockIdx.x];
+    const int pad_bits = 2 * (16 * W - (k + 1));
+    for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
+        const uint64_t s0 = a.start[r];
+        const int len = (int)(a.start[r + 1] - s0);
+        if (len < k + 1) continue;
+        const int npos = len - k;
+        Key<W> *ro = out + s_read_base[r - r0];
+        for (int c0 = 0; c0 < npos; c0 += 64) {
+            const int p = c0 + lane;
+            if (p >= npos) continue;
+            const uint64_t q = s0 + (uint64_t)p, wi = q >> 4;
+            const int sh = (int)(q & 15) * 2;
+            uint32_t raw[W + 1], e[W], rc[W];
+#pragma unroll
+            for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
+#pragma unroll
+            for (int j = 0; j < W; ++j) e[j] = sh ? ((raw[j] << sh) | (raw[j + 1] >> (32 - sh))) : raw[j];
+            keep_chars<W>(e, k + 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
+            shl_bits<W>(rc, pad_bits);
+            const int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+            ro[2 + 2 * p] = make_key<W>(e, 1, k, k, e0);                 // solid   (s2.cpp:543-550)
+            ro[3 + 2 * p] = make_key<W>(rc, 1, k, k, r0c);
+            if (p == 0) {                                               // left $  (s2.cpp:531-540)
+                ro[0] = make_key<W>(e, 0, k, k, kDollar);
+                ro[1] = make_key<W>(rc, 2, k - 1, k, r1c);
+            }
+            if (p == npos - 1) {                                        // right $ (s2.cpp:553-562)
+                ro[2 + 2 * npos] = make_key<W>(e, 2, k - 1, k, e1);
+                ro[3 + 2 * npos] = make_key<W>(rc, 0, k, k, kDollar);
+            }
+        }
+    }
+}
+
 // Items per workgroup of item_scan_kernel in closed form.  With k+1 odd no (k+1)-mer equals its reverse complement, so when
 // every position is solid and every bucket is wanted a read with npos = len - k >= 1 positions yields exactly
 // 2 npos + 4 items (two per position, two more at each end of the read): no edge has to be built to count them.
@@ -1646,7 +1702,10 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             // ---- 3. write keys
             t_ph.start();
             sa.out = d_a;
-            hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+            if (closed_form)
+                hipLaunchKernelGGL((item_write_closed_kernel<W>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+            else
+                hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             S.ms_gen += t_ph.stop();
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
