@@ -1081,6 +1081,21 @@ __device__ __forceinline__ int key_a(const Key<W> &x, int k) {   // Extract_a, s
 template <int W>
 __device__ __forceinline__ int key_b(const Key<W> &x) { return x.w[W - 1] & 7u; }   // Extract_b, s2.cpp:96-98
 
+// Where the runs start: the low 32 bits per run, the full 64 bits for every kRunBaseStep-th run.  Runs are consecutive, so a
+// length is a 32-bit difference (a run never holds 2^32 keys) and a full start is rebuilt from the nearest base.
+constexpr int kRunBaseStepLog = 10;
+struct RunStarts {
+    uint32_t *lo;                // [m]
+    uint64_t *base;              // [m >> kRunBaseStepLog + 1]
+};
+__device__ __forceinline__ uint64_t run_full_start(const RunStarts &r, uint64_t s) {
+    const uint64_t b = r.base[s >> kRunBaseStepLog];
+    return b + (uint32_t)(r.lo[s] - (uint32_t)b);
+}
+__device__ __forceinline__ uint64_t run_length(const RunStarts &r, uint64_t s, uint64_t m, uint64_t n_items) {
+    return s + 1 < m ? (uint64_t)(uint32_t)(r.lo[s + 1] - r.lo[s]) : n_items - run_full_start(r, s);
+}
+
 // E1+E2: one descriptor per run (distinct key): start index + (a | b<<3 | group_head<<6 | bucket_head<<7), compacted in key order.
 // The keys are read once: the number of runs before a tile comes from a chained scan across the workgroups (device_utils.hpp).
 struct EmitChain {
@@ -1094,7 +1109,7 @@ struct EmitChain {
 // if a tile ever waits in vain the bounded walk raises chain.error and the host repeats the launch with TICKET = true.
 template <int W, bool TICKET>
 __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W> *keys, uint64_t n, int k, EmitChain chain, uint32_t n_tiles,
-                                                                     uint64_t *sub_start, uint8_t *sub_info) {
+                                                                     RunStarts sub_start, uint8_t *sub_info) {
     __shared__ uint32_t s_cnt[kEmitPerThread * (kEmitThreads / 64)];
     __shared__ uint32_t s_scr[kEmitThreads / 64 + 1];
     __shared__ uint32_t s_tile;
@@ -1147,7 +1162,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W>
         if ((headbits >> it) & 1u) {
             uint64_t idx = base + (uint64_t)it * kEmitThreads + threadIdx.x;
             uint64_t s = tb + s_cnt[it * (kEmitThreads / 64) + wv] + rank_in_wave[it];
-            sub_start[s] = idx;
+            sub_start.lo[s] = (uint32_t)idx;
+            if ((s & ((1u << kRunBaseStepLog) - 1)) == 0) sub_start.base[s >> kRunBaseStepLog] = idx;
             sub_info[s] = info[it];
         }
     }
@@ -1163,7 +1179,7 @@ __device__ __forceinline__ bool run_suppressed(int a, int b, int has_a, int has_
     return (a == kDollar && ((has_b >> b) & 1)) || (b == kDollar && ((has_a >> a) & 1));
 }
 
-__global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(const uint64_t *sub_start, const uint8_t *sub_info, uint64_t m,
+__global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(RunStarts sub_start, const uint8_t *sub_info, uint64_t m,
                                                                       uint64_t n_items, uint16_t *rec, uint32_t *cnt_e,
                                                                       uint32_t *cnt_l, uint32_t *cnt_t) {
     __shared__ uint32_t s_e[kDecideThreads / 64], s_l[kDecideThreads / 64], s_t[kDecideThreads / 64];
@@ -1201,8 +1217,7 @@ __global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(const uint6
                 }
                 last = later ? 0 : 1;
             }
-            uint64_t end = (s + 1 < m) ? sub_start[s + 1] : n_items;
-            uint64_t run = end - sub_start[s];
+            uint64_t run = run_length(sub_start, s, m, n_items);
             uint32_t count = run > 65535 ? 65535u : (uint32_t)run;  // kMaxMulti_t
             int tip = a == kDollar;
             r = (uint16_t)(w | (last << 4) | (tip << 5) | ((count > 255 ? 255u : count) << 8));
@@ -1224,7 +1239,7 @@ __global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(const uint6
 
 // E5: order-preserving compaction into the output stream + per-bucket boundaries
 template <int W>
-__global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W> *keys, const uint64_t *sub_start, const uint8_t *sub_info, const uint16_t *rec,
+__global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W> *keys, RunStarts sub_start, const uint8_t *sub_info, const uint16_t *rec,
                                                                      uint64_t m, uint64_t n_items, const uint64_t *base_e,
                                                                      const uint64_t *base_l, const uint64_t *base_t, int words_per_tip,
                                                                      uint32_t b_lo, uint16_t *out_rec, uint16_t *out_large,
@@ -1240,8 +1255,7 @@ __global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W>
         if (s < m) {
             r[q] = rec[s];
             if (r[q] != 0xFFFF) {
-                uint64_t end = (s + 1 < m) ? sub_start[s + 1] : n_items;
-                uint64_t run = end - sub_start[s];
+                uint64_t run = run_length(sub_start, s, m, n_items);
                 cnts[q] = run > 65535 ? 65535u : (uint32_t)run;
                 packed += 1ull + ((uint64_t)(cnts[q] > 254) << 20) + ((uint64_t)((r[q] >> 5) & 1) << 40);
             }
@@ -1253,8 +1267,10 @@ __global__ __launch_bounds__(kDecideThreads) void emit_write_kernel(const Key<W>
     for (int q = 0; q < kDecidePerThread; ++q) {
         uint64_t s = s0 + q;
         if (s >= m) break;
-        uint64_t first_item = sub_start[s];
-        if (sub_info[s] & 128) {                                   // number of records/large/tips before this bucket
+        const bool is_tip = r[q] != 0xFFFF && ((r[q] >> 5) & 1);
+        const bool bucket_head = (sub_info[s] & 128) != 0;
+        const uint64_t first_item = (is_tip || bucket_head) ? run_full_start(sub_start, s) : 0;   // only these two look at the key
+        if (bucket_head) {                                         // number of records/large/tips before this bucket
             uint32_t bucket = keys[first_item].w[0] >> 16;
             int64_t *bf = bucket_first + (uint64_t)(bucket - b_lo) * 3;
             bf[0] = (int64_t)ie; bf[1] = (int64_t)il; bf[2] = (int64_t)it;
@@ -1681,7 +1697,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
         // either key buffer may end up as the emitter's scratch (11 bytes per key: run start u64, record u16, info u8), whichever
         // the last sort pass leaves idle: both hold >= 12 bytes per key
-        uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12);
+        uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12) + 4096;
         uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
         const uint64_t avail = budget - std::min<uint64_t>(budget, other);
@@ -1722,7 +1738,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             uint64_t e_tiles = (n_items + kEmitTile - 1) / kEmitTile;
             d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(std::max(n_blocks, e_tiles), n_items / kDecideTile + 1)) * 8);
             // run descriptors, compacted in key order in one read of the keys (chained scan over the tiles).  Scratch layout for up to
-            // n_items runs (<= 11 bytes per key of a >= 12-byte-per-key buffer): sub_start u64 | rec u16 | info u8
+            // n_items runs (<= 7.01 bytes per key of a >= 12-byte-per-key buffer): start u32 | rec u16 | info u8 | full start u64 per 1024 runs
             if (e_tiles > 0xFFFFFFFFull) { set_error("too many emit tiles"); return MGTA_EUNSUPPORTED; }
             unsigned long long *d_chain = pool_get<unsigned long long>(ctx, S_TILE_BASE, (e_tiles + 4) * 8);
             EmitChain chain;
@@ -1730,9 +1746,11 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             chain.total = d_chain + e_tiles;
             chain.ticket = reinterpret_cast<uint32_t *>(d_chain + e_tiles + 1);
             chain.error = reinterpret_cast<uint32_t *>(d_chain + e_tiles + 2);
-            uint64_t *sub_start = reinterpret_cast<uint64_t *>(scratch);
-            uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + n_items * 8);
-            uint8_t *info = reinterpret_cast<uint8_t *>(scratch + n_items * 10);
+            RunStarts sub_start;
+            sub_start.lo = reinterpret_cast<uint32_t *>(scratch);
+            uint16_t *rec = reinterpret_cast<uint16_t *>(scratch + n_items * 4);
+            uint8_t *info = reinterpret_cast<uint8_t *>(scratch + n_items * 6);
+            sub_start.base = reinterpret_cast<uint64_t *>(scratch + ((n_items * 7 + 7) & ~7ull));
             unsigned long long chain_out[3] = {0, 0, 0};                   // total, ticket, error
             for (int attempt = 0; attempt < 2; ++attempt) {
                 MGTA_HIP_CHECK(hipMemsetAsync(d_chain, 0, (e_tiles + 4) * 8, stream));
