@@ -306,3 +306,44 @@ def test_stage1_routes_agree_at_scale(ctx, k, m):
     _same(a, b)
     assert np.array_equal(ca, cb) and ca.sum() > 0
     assert 0 < a.records.size < ctx.build_sdbg(rd, k).records.size
+
+
+@pytest.mark.parametrize("seed", list(range(64)))
+def test_fuzz_small_inputs_vs_oracle(ctx, oracle, seed):
+    """seeded random inputs: any k in [9, 127], ragged read lengths (also shorter than k+1), duplicated and reverse-complemented reads,
+    low-complexity stretches (palindromes, hot k-mers), a random bucket sub-range, and -m 2/3 with mercy on every third seed"""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([9, 10, 15, 16, 20, 27, 31, 32, 44, 47, 48, 63, 64, 80, 95, 111, 127]))
+    genome = rng.integers(0, 4, int(rng.integers(300, 3000))).astype(np.uint8)
+    if seed % 4 == 0:
+        genome[100:160] = 0                                                   # poly-A
+        genome[200:260] = np.tile(np.array([0, 3], dtype=np.uint8), 30)        # (AT)n: palindromic (k+1)-mers when k+1 is even
+    reads = []
+    for _ in range(int(rng.integers(20, 400))):
+        L = int(rng.integers(1, min(genome.size, 330)))
+        p = int(rng.integers(0, genome.size - L + 1))
+        r = genome[p:p + L].copy()
+        if rng.random() < 0.1 and L > 3:
+            r[int(rng.integers(0, L))] = int(rng.integers(0, 4))
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+        if rng.random() < 0.2:
+            reads.append(r.copy())
+    packed, start = readlib.pack_for_build(reads)
+    rd = ctx.upload_reads(packed, start)
+    g = ctx.build_sdbg(rd, k)
+    o = oracle.Stream.build(packed, start, k, threads=2).edges()
+    _same(g, o)
+    b0 = int(rng.integers(0, 65535))
+    b1 = int(rng.integers(b0 + 1, 65537))
+    part = ctx.build_sdbg(rd, k, bucket_range=(b0, b1))
+    lo, hi = int(o.bucket_items[:b0].sum()), int(o.bucket_items[:b1].sum())
+    assert np.array_equal(part.records, o.records[lo:hi]) and np.array_equal(part.bucket_items[b0:b1], o.bucket_items[b0:b1])
+    if seed % 3 == 0 and k <= 110:
+        m = int(rng.choice([2, 3]))
+        mercy = max(r.size for r in reads) <= 1024
+        gs = ctx.build_sdbg(rd, k, min_count=m, need_mercy=mercy)
+        os_ = oracle.Stream.build_solid(packed, start, k, m, mercy, threads=2)
+        _same(gs, os_.edges())
+        assert np.array_equal(ctx.last_counting(), os_.counting)
