@@ -95,3 +95,47 @@ def test_gpu_forward_and_reversed_storage_agree(ctx, golden_dir):
         findstart.find_hits(ctx, ctx.upload_reads(packed_r, start), True, 44, pw)
     with pytest.raises(api.MegaGtaError):
         findstart.find_hits(ctx, ctx.upload_reads(packed_r, start), True, 75, pw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_gpu_fuzz_vs_oracle(ctx, tmp_path, seed):
+    """random alignments over the generator's whole input alphabet, every k/3 in [3, 24], ragged reads on both strands"""
+    import numpy as np
+    from megagta_amd import findstart
+    from oracle import findstart_oracle as F
+    rng = np.random.default_rng(500 + seed)
+    kaa = int(rng.integers(3, 25))
+    alphabet = list("ARNDCQEGHILKMFPSTWYV" * 6 + "arndcq" + "--..XX**BZUxj")
+    faa = tmp_path / "ref.faa"
+    prots = []
+    with open(faa, "w") as f:
+        for i in range(int(rng.integers(1, 5))):
+            s = "".join(alphabet[int(x)] for x in rng.integers(0, len(alphabet), int(rng.integers(kaa, 200))))
+            prots.append(s)
+            f.write(f">s{i} d\n")
+            for j in range(0, len(s), 37):
+                f.write(s[j:j + 37] + "\n")
+    codons = {a: [i for i in range(64) if F.CODON_AA[i] == a] for a in F.AA_UPPER + "*"}
+    clean = ["".join(c for c in p if c in F.AA_UPPER) for p in prots]
+    reads = []
+    for _ in range(300):
+        L = int(rng.integers(1, 260))
+        r = rng.integers(0, 4, L).astype(np.uint8)
+        src = clean[int(rng.integers(0, len(clean)))]
+        if len(src) >= 2 and rng.random() < 0.8:
+            n_aa = int(rng.integers(1, min(len(src), 60) + 1))
+            st = int(rng.integers(0, len(src) - n_aa + 1))
+            core = []
+            for a in src[st:st + n_aa]:
+                c = int(rng.choice(codons[a]))
+                core += [c >> 4, (c >> 2) & 3, c & 3]
+            core = np.array(core[:L], dtype=np.uint8)
+            off = int(rng.integers(0, L - core.size + 1))
+            r[off:off + core.size] = core
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    k = 3 * kaa
+    lines, st = findstart.find_start(ctx, str(faa), reads, k)
+    assert lines == F.find_start(str(faa), ["".join("ACGT"[x] for x in r) for r in reads], k)
