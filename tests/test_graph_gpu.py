@@ -114,3 +114,41 @@ def test_graph_from_device_resident_stream(ctx, golden_dir, case, k):
     ctx.build_sdbg(rd, k, collect=False, bucket_range=(0, 30000))
     with pytest.raises(api.MegaGtaError):
         api.Graph(ctx, None, k)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_navigation_vs_oracle(ctx, oracle, seed):
+    """random small graphs (any k, tips, $ edges, hot k-mers): OutgoingEdges of every edge and IndexBinarySearchEdge of present and absent
+    (k+1)-mers agree with the oracle; so does the graph read off the device-resident stream"""
+    from megagta_amd import api
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.choice([9, 15, 21, 31, 32, 44, 63, 64, 95]))
+    genome = rng.integers(0, 4, int(rng.integers(400, 2500))).astype(np.uint8)
+    reads = []
+    for _ in range(int(rng.integers(30, 250))):
+        L = int(rng.integers(k + 1, min(genome.size, 300)))
+        p = int(rng.integers(0, genome.size - L + 1))
+        r = genome[p:p + L].copy()
+        if rng.random() < 0.15:
+            r[int(rng.integers(0, L))] = int(rng.integers(0, 4))
+        reads.append((3 - r[::-1]).astype(np.uint8) if rng.random() < 0.5 else r)
+    packed, start = readlib.pack_for_build(reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    og = oracle.Graph(oracle.Stream.build(packed, start, k, threads=2))
+    for g in (api.Graph(ctx, stream), api.Graph(ctx, None, k)):
+        assert g.size == og.size
+        deg, out = g.outgoing(np.arange(g.size))
+        for e in range(g.size):
+            n, ref = og.outgoing(e)
+            assert deg[e] == n and out[e, :max(n, 0)].tolist() == ref, (seed, e)
+        kmers = []
+        for _ in range(60):
+            r = reads[int(rng.integers(0, len(reads)))]
+            p = int(rng.integers(0, r.size - k))
+            s = r[p:p + k + 1].copy()
+            if rng.random() < 0.3:
+                s[int(rng.integers(0, k + 1))] = int(rng.integers(0, 4))
+            kmers.append("".join("ACGT"[x] for x in s))
+        ids = g.index_edges(kmers)
+        want = [og.index_edge(km) for km in kmers]
+        assert ids.tolist() == want
