@@ -142,3 +142,34 @@ def test_windowed_warm_vs_oracle(ctx, oracle, window):
                     assert got["ok"] == ref.ok and got["n_closed"] == ref.n_closed and got["n_expanded"] == ref.n_expanded
                     if ref.ok:
                         assert got["real_score"] == ref.real_score and got["fval"] == ref.fval
+
+
+@pytest.mark.parametrize("M,k1,prune,pen,seed", [(60, 30, 20, 0.5, 1), (90, 36, 0, 0.5, 2), (150, 45, 20, 0.0, 3), (75, 45, 5, 2.0, 4),
+                                                   (200, 36, 20, 0.5, 5), (48, 30, 3, 0.25, 6)])
+def test_fuzz_genes_k_and_search_options_vs_oracle(ctx, oracle, tmp_path, M, k1, prune, pen, seed):
+    """other gene lengths, k = 30 / 36 / 45, pruning on / off / tight, low-coverage penalties; the seeds are the ones OUR findstart reports
+    on the same reads (the real pipeline), plus seeds that are absent from the graph: GPU == oracle per seed, scores bit-equal"""
+    from megagta_amd import api, findstart
+    mg = synth.make_metagenome(4000, 150, (("g", M),), seed=40 + seed, reads_per_genome=500, genome_len=6000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    k = k1 - 1
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    synth.write_gene_models(mg.genes, str(tmp_path))
+    fpath, rpath, faa = (os.path.join(str(tmp_path), "g", n) for n in ("for_enone.hmm", "rev_enone.hmm", "ref_aligned.faa"))
+    lines, _ = findstart.find_start(ctx, faa, list(mg.reads), k1)
+    seeds = [(l.split("\t")[3], int(l.split("\t")[7])) for l in lines][:150]
+    seeds += synth.synthetic_seeds(mg.genes[0], k1, 30, seed=seed)
+    assert len(seeds) > 40
+    g = api.Graph(ctx, stream)
+    fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+    res, st = api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], prune, pen)
+    og = oracle.Graph(oracle.Stream.build(packed, start, k, threads=4))
+    S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), prune, pen)
+    for (kmer, pos), r in zip(seeds, res):
+        contig, R, L = S.search(kmer, pos - 1, cold=True)
+        assert r.contig(kmer) == contig
+        for got, ref in ((r.right_side, R), (r.left_side, L)):
+            assert (got["ok"], got["n_closed"], got["n_expanded"], got["partial"], got["n_opened"]) == \
+                   (ref.ok, ref.n_closed, ref.n_expanded, ref.partial, ref.n_opened)
+            if ref.ok:
+                assert got["real_score"] == ref.real_score and got["score"] == ref.score and got["fval"] == ref.fval
