@@ -142,3 +142,34 @@ def test_findstart_binary_matches_reference_output(golden_dir, k, with_contigs):
     assert r.returncode == 1 and "doesn't exist" in r.stderr
     r = subprocess.run([BIN, "findstart", os.path.join(d, "ref_quirks.faa"), os.path.join(d, "reads.lib.bin"), "44"], capture_output=True, text=True)
     assert r.returncode != 0 and "multiple of 3" in r.stderr
+
+
+def test_multi_k_driver_run_stagewise_vs_reference(toy_inputs, oracle):
+    """`megagta.py -k 30,36,45`: every step ours except `denovo` (reference binary).  Each stage is checked against the reference binary fed
+    with the same inputs: the three graphs (two of them built with the previous k's contigs as assist sequences), the seeds found in reads
+    plus contigs, and the last step's filters."""
+    _need()
+    d = toy_inputs
+    out = d / "out_mk"
+    r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "30,36,45", "-o", str(out),
+                        "-t", "4", "--min-contig-len", "150", "--ref-bin", REF], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
+    run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
+    lib = str(out / "tmp" / "reads.lib")
+    common = ["-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4", "--num_output_threads", "1",
+              "--read_lib_file", lib]
+    prev = None
+    for k in (29, 35, 44):
+        cmd = [REF, "buildgraph", "-k", str(k), "--output_prefix", str(d / f"ref_mk_{k}")] + common
+        if prev is not None:
+            cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
+        run(cmd)
+        ours, ref = oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges(), oracle.Stream.read(str(d / f"ref_mk_{k}")).edges()
+        assert ours.md5() == ref.md5() and ours.records.size > 100000, k
+        prev = k
+    faa = (d / "gene_list.txt").read_text().split()[3]
+    ref_seeds = run([REF, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")]).stdout.decode().splitlines()
+    ours_seeds = (out / "k44" / "44_rplB_starting_kmers.txt").read_text().splitlines()
+    assert ours_seeds == sorted(ref_seeds) and len(ours_seeds) >= 93
+    nucl = run([REF, "filterbylen", "150"], stdin=open(out / "k44" / "44_raw_contigs_rplB.fasta")).stdout.decode()
+    assert (out / "contigs" / "rplB" / "nucl_merged.fasta").read_text() == nucl and nucl.count(">") > 10
