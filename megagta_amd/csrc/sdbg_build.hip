@@ -124,12 +124,14 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     __shared__ uint32_t s_range_cnt[kMaxCountRanges];
     const int k = a.k;
     const int lane = lane_id(), wv = wave_id();
+    __shared__ uint64_t s_start[kReadsPerBlock + 1];                  // one coalesced load instead of two dependent ones per read
     const bool multi = !WRITE && a.multi_n > 0;
-    if (threadIdx.x == 0) s_cursor = 0;
-    if (!WRITE && threadIdx.x < kMaxCountRanges) s_range_cnt[threadIdx.x] = 0;
-    __syncthreads();
     uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
     uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
+    if (threadIdx.x == 0) s_cursor = 0;
+    if (!WRITE && threadIdx.x < kMaxCountRanges) s_range_cnt[threadIdx.x] = 0;
+    if (threadIdx.x <= r1 - r0) s_start[threadIdx.x] = a.start[r0 + threadIdx.x];
+    __syncthreads();
     Key<W> *out = reinterpret_cast<Key<W> *>(a.out);
     uint64_t base = WRITE ? a.block_base[blockIdx.x] : 0;
     uint32_t my_count = 0;
@@ -137,8 +139,8 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     const int pad_bits = 2 * (16 * W - (k + 1));   // 2..32
 
     for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
-        uint64_t s0 = a.start[r];
-        int len = (int)(a.start[r + 1] - s0);
+        uint64_t s0 = s_start[r - r0];
+        int len = (int)(s_start[r - r0 + 1] - s0);
         if (len < k + 1) continue;                                     // s2.cpp:262-264
         int npos = len - k;
         if (lane == 0) kmers += (unsigned long long)npos;
@@ -233,14 +235,18 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
 template <int W>
 __global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs a) {
     __shared__ uint32_t s_read_base[kReadsPerBlock];
+    __shared__ uint64_t s_start[kReadsPerBlock + 1];                  // one coalesced load instead of two dependent ones per read
     const int k = a.k;
     const int lane = lane_id(), wv = wave_id();
     const uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
     const uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
     if (wv == 0) {                                                    // first key of every read of the workgroup
+        const uint64_t st = r0 + lane <= r1 ? a.start[r0 + lane] : 0, st_next = r0 + lane < r1 ? a.start[r0 + lane + 1] : st;
+        s_start[lane] = st;
+        if (r0 + lane + 1 == r1) s_start[lane + 1] = st_next;
         uint32_t items = 0;
         if (r0 + lane < r1) {
-            const int len = (int)(a.start[r0 + lane + 1] - a.start[r0 + lane]);
+            const int len = (int)(st_next - st);
             if (len >= k + 1) items = 2u * (uint32_t)(len - k) + 4u;
         }
         s_read_base[lane] = wave_incl_scan(items) - items;
@@ -249,8 +255,8 @@ __global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs 
     Key<W> *out = reinterpret_cast<Key<W> *>(a.out) + a.block_base[blockIdx.x];
     const int pad_bits = 2 * (16 * W - (k + 1));
     for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
-        const uint64_t s0 = a.start[r];
-        const int len = (int)(a.start[r + 1] - s0);
+        const uint64_t s0 = s_start[r - r0];
+        const int len = (int)(s_start[r - r0 + 1] - s0);
         if (len < k + 1) continue;
         const int npos = len - k;
         Key<W> *ro = out + s_read_base[r - r0];
