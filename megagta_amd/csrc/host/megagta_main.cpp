@@ -110,7 +110,10 @@ static int main_buildgraph(int argc, char **argv) {
 
     mgta_ctx *ctx = mgta_ctx_create(0);
     if (!ctx) die("%s", mgta_last_error());
-    if (gpu_mem > 0) mgta_ctx_set_mem_limit(ctx, (uint64_t)gpu_mem);
+    // --gpu_mem: device budget in bytes.  Unset, a one-shot process takes 64 GB at most: device memory is mapped at ~27 ms/GB
+    // (measured: 194 GB cost 5.3 s before the first kernel ran), which outweighs the few extra bucket-range passes of a tighter budget
+    // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  A resident caller (bench, multi-k API) keeps the pool.
+    mgta_ctx_set_mem_limit(ctx, gpu_mem > 0 ? (uint64_t)gpu_mem : (64ull << 30));
     EdgeStream s;
     s.k = k; s.words_per_tip = (2 * k + 31) / 32;
     mgta_build_stats st;
