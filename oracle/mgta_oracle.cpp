@@ -1029,6 +1029,296 @@ void fill_result(orc_astar_result *r, const AstarOut &o, const Node *goal) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// =================================================================================================
+// 6. denovo: tips, bubbles, unitigs (the reference run with ONE thread: its loops are order dependent)
+// =================================================================================================
+namespace denovo {
+
+struct Bits {
+    std::vector<uint64_t> v;
+    void reset(int64_t n) { v.assign((size_t)((n + 63) / 64) + 1, 0); }
+    bool get(int64_t i) const { return (v[i >> 6] >> (i & 63)) & 1; }
+    void set(int64_t i) { v[i >> 6] |= 1ULL << (i & 63); }
+    void unset(int64_t i) { v[i >> 6] &= ~(1ULL << (i & 63)); }
+    bool try_lock(int64_t i) { if (get(i)) return false; set(i); return true; }   // atomic_bit_vector.h try_lock, one thread
+};
+
+inline void set_invalid(Graph &g, int64_t e) { g.invalid[e >> 6] |= 1ULL << (e & 63); }
+inline void set_valid(Graph &g, int64_t e) { g.invalid[e >> 6] &= ~(1ULL << (e & 63)); }
+inline int multiplicity(const Graph &g, int64_t e) { return 2 - (int)g.is_multi1(e); }   // succinct_dbg.h:133-135 (need_multiplicity = false)
+
+int64_t last_index(const Graph &g, int64_t x) {   // GetLastIndex = rs_last_.Succ, succinct_dbg.h:105
+    while (x < g.size && !g.is_last(x)) ++x;
+    return x;
+}
+
+// the edges that point to the node / edge x (shared scan of IncomingEdges, UniquePrevEdge, UniquePrevNode, NodeIndegreeZero,
+// DeleteAllEdges: succinct_dbg.cpp:99-127,196-225,268-315,348-371); `all` also reports invalid ones
+int incoming_scan(const Graph &g, int64_t x, int64_t *in, bool all) {
+    int64_t first = g_backward(g, x);
+    int c = g.W(first), ones = g.last_or_tip(first), n = 0;
+    if (all || g.valid(first)) in[n++] = first;
+    for (int64_t y = first + 1; ones < 5 && y < g.size; ++y) {
+        ones += g.last_or_tip(y);
+        int cur = g.W(y);
+        if (cur == c) break;
+        if (cur == c + 4 && (all || g.valid(y))) in[n++] = y;
+    }
+    return n;
+}
+int node_edges(const Graph &g, int64_t node, int64_t *out, bool all) {   // the node's own edges, from its last one downwards
+    int64_t e = last_index(g, node);
+    int n = 0;
+    do {
+        if (all || g.valid(e)) out[n++] = e;
+        --e;
+    } while (e >= 0 && !g.last_or_tip(e));
+    return n;
+}
+bool node_outdegree_zero(const Graph &g, int64_t node) { int64_t t[8]; return node_edges(g, node, t, false) == 0; }     // :227-240
+bool node_indegree_zero(const Graph &g, int64_t node) { int64_t t[8]; return incoming_scan(g, node, t, false) == 0; }   // :242-266
+int64_t unique_prev_node(const Graph &g, int64_t node) {                                                                // :268-292
+    int64_t t[8];
+    return incoming_scan(g, node, t, false) == 1 ? last_index(g, t[0]) : -1;
+}
+int64_t unique_next_node(const Graph &g, int64_t node) {                                                                // :294-315
+    int64_t t[8];
+    return node_edges(g, node, t, false) == 1 ? last_index(g, g_forward(g, t[0])) : -1;
+}
+void delete_all_edges(Graph &g, int64_t node) {                                                                         // :317-346
+    int64_t t[8];
+    int n = node_edges(g, node, t, true);
+    for (int i = 0; i < n; ++i) set_invalid(g, t[i]);
+    n = incoming_scan(g, node, t, true);
+    for (int i = 0; i < n; ++i) set_invalid(g, t[i]);
+}
+int64_t unique_next_edge(const Graph &g, int64_t e) {                                                                   // :173-194
+    int64_t o[8];
+    if (!g.valid(e)) return -1;
+    int n = 0;
+    int64_t nx = g_forward(g, e);
+    do {
+        if (g.valid(nx)) o[n++] = nx;
+        --nx;
+    } while (nx >= 0 && !g.last_or_tip(nx));
+    return n == 1 ? o[0] : -1;
+}
+int64_t unique_prev_edge(const Graph &g, int64_t e) {                                                                   // :196-225
+    int64_t t[8];
+    if (!g.valid(e)) return -1;
+    return incoming_scan(g, e, t, false) == 1 ? t[0] : -1;
+}
+int64_t prev_simple(const Graph &g, int64_t e) { int64_t p = unique_prev_edge(g, e); return p != -1 && unique_next_edge(g, p) != -1 ? p : -1; }
+int64_t next_simple(const Graph &g, int64_t e) { int64_t n = unique_next_edge(g, e); return n != -1 && unique_prev_edge(g, n) != -1 ? n : -1; }
+int edge_outdegree(const Graph &g, int64_t e) { int64_t o[8]; return g_outgoing(g, e, o); }
+int edge_indegree(const Graph &g, int64_t e) { int64_t o[8]; return g_incoming(g, e, o); }
+
+int64_t edge_reverse_complement(const Graph &g, int64_t e) {   // succinct_dbg.cpp:551-593
+    if (!g.valid(e)) return -1;
+    std::vector<uint8_t> seq((size_t)g.k + 1);
+    g_label(g, e, seq.data());
+    seq[g.k] = (uint8_t)g.out_label(e);
+    std::reverse(seq.begin(), seq.end());
+    for (auto &c : seq) c = uint8_t(5 - c);
+    return g_index_edge(g, seq.data());
+}
+
+// Trim, assembly_algorithms.cpp:76-159
+int64_t trim(Graph &g, Bits &removed, int len) {
+    int64_t n_tips = 0;
+    for (int64_t x = 0; x < g.size; ++x) {
+        if (!(g.is_last(x) && !removed.get(x) && node_outdegree_zero(g, x))) continue;
+        std::vector<int64_t> path{x};
+        int64_t cur = x;
+        bool is_tip = false;
+        for (int i = 1; i < len; ++i) {
+            int64_t prev = unique_prev_node(g, cur);
+            if (prev == -1) { is_tip = node_indegree_zero(g, cur); break; }
+            if (unique_next_node(g, prev) == -1) { is_tip = true; break; }
+            path.push_back(prev);
+            cur = prev;
+        }
+        if (is_tip) { for (int64_t p : path) removed.set(p); ++n_tips; }
+    }
+    for (int64_t x = 0; x < g.size; ++x) {
+        if (!(g.is_last(x) && !removed.get(x) && node_indegree_zero(g, x))) continue;
+        std::vector<int64_t> path{x};
+        int64_t cur = x;
+        bool is_tip = false;
+        for (int i = 1; i < len; ++i) {
+            int64_t next = unique_next_node(g, cur);
+            if (next == -1) { is_tip = node_outdegree_zero(g, cur); break; }
+            if (unique_prev_node(g, next) == -1) { is_tip = true; break; }   // the reference keeps looping here; the outcome is the same
+            path.push_back(next);
+            cur = next;
+        }
+        if (is_tip) { for (int64_t p : path) removed.set(p); ++n_tips; }
+    }
+    for (int64_t x = 0; x < g.size; ++x)
+        if (removed.get(x)) delete_all_edges(g, x);
+    return n_tips;
+}
+
+int64_t remove_tips(Graph &g, int max_tip_len) {   // :161-183
+    Bits removed;
+    removed.reset(g.size);
+    int64_t n = 0;
+    for (int len = 2; len < max_tip_len; len *= 2) n += trim(g, removed, len);
+    n += trim(g, removed, max_tip_len);
+    return n;
+}
+
+struct BranchGroup {   // branch_group.cpp:22-141
+    Graph &g;
+    int64_t begin, end = -1;
+    int max_branches, max_length;
+    std::vector<std::vector<int64_t>> branches;
+    std::vector<int> mult;
+    bool search() {
+        if (!g.valid(begin)) return false;
+        int outd = edge_outdegree(g, begin);
+        if (outd <= 1 || outd > max_branches) return false;
+        branches.push_back({begin});
+        mult.push_back(0);
+        bool converged = false;
+        for (int j = 1; j < max_length; ++j) {
+            int nb = (int)branches.size();
+            for (int i = 0; i < nb; ++i) {
+                int64_t out[8];
+                int od = g_outgoing(g, branches[i].back(), out);
+                if (od < 1) return false;       // a dead branch can never converge (the reference runs on and fails later)
+                branches[i].push_back(out[0]);
+                mult[i] += multiplicity(g, out[0]);
+                if ((int)branches.size() + od - 1 > max_branches) return false;
+                std::vector<int64_t> copy = branches[i];
+                int base = mult[i] - multiplicity(g, out[0]);
+                for (int x = 1; x < od; ++x) {
+                    copy.back() = out[x];
+                    branches.push_back(copy);
+                    mult.push_back(base + multiplicity(g, out[x]));
+                }
+            }
+            for (auto &b : branches) {
+                int64_t in[8];
+                int id = g_incoming(g, b.back(), in);
+                if (id == 1) continue;
+                for (int x = 0; x < id; ++x) {
+                    bool found = false;
+                    for (auto &o : branches)
+                        if (o[j - 1] == in[x]) { found = true; break; }
+                    if (!found) return false;
+                }
+            }
+            end = branches[0].back();
+            if (edge_outdegree(g, end) == 1) {
+                converged = true;
+                for (auto &b : branches)
+                    if (b.back() != end) { converged = false; break; }
+                if (converged) break;
+            }
+        }
+        return converged && begin != end;
+    }
+    bool pop(Bits &marked) {
+        int best = 0, best_m = mult[0];
+        for (size_t i = 1; i < branches.size(); ++i)
+            if (mult[i] >= best_m) { best = (int)i; best_m = mult[i]; }
+        std::vector<int64_t> locked;
+        for (auto &b : branches)
+            for (size_t j = 1; j + 1 < b.size(); ++j) {
+                if (!marked.try_lock(b[j])) {
+                    for (int64_t e : locked) { marked.unset(e); set_valid(g, e); }
+                    return false;
+                }
+                locked.push_back(b[j]);
+                set_invalid(g, b[j]);
+            }
+        auto &w = branches[best];
+        for (size_t j = 1; j + 1 < w.size(); ++j) { set_valid(g, w[j]); marked.unset(w[j]); }
+        return true;
+    }
+};
+
+int64_t pop_bubbles(Graph &g) {   // assembly_algorithms.cpp:245-301
+    const int max_len = g.k * 2 + 4;
+    std::vector<int64_t> cand, again;
+    Bits marked;
+    marked.reset(g.size);
+    for (int64_t e = 0; e < g.size; ++e) {
+        if (!g.valid(e)) continue;
+        BranchGroup b{g, e, -1, 16, max_len};
+        if (b.search()) cand.push_back(e);
+    }
+    int64_t popped = 0;
+    for (int64_t e : cand) {
+        BranchGroup b{g, e, -1, 16, max_len};
+        if (b.search()) { if (b.pop(marked)) ++popped; else again.push_back(e); }
+    }
+    for (int64_t e : again) {
+        BranchGroup b{g, e, -1, 16, max_len};
+        if (b.search() && b.pop(marked)) ++popped;
+    }
+    return popped;
+}
+
+struct Contig { int flag; double multi; std::string seq; };
+
+std::string path_label(const Graph &g, int64_t start, int64_t end, int length) {   // VertexToDNAString, unitig_graph.cpp:80-112
+    std::string s;
+    int64_t cur = end;
+    for (int i = 1; i < length; ++i) {
+        s.push_back("ACGT"[g.out_label(cur) - 1]);
+        cur = prev_simple(g, cur);
+    }
+    s.push_back("ACGT"[g.out_label(cur) - 1]);
+    std::vector<uint8_t> lab((size_t)g.k);
+    g_label(g, start, lab.data());
+    for (int i = g.k - 1; i >= 0; --i) s.push_back("ACGT"[lab[i] - 1]);
+    std::reverse(s.begin(), s.end());
+    return s;
+}
+
+std::vector<Contig> unitigs(const Graph &g, int min_contig) {   // UnitigGraph::InitFromSdBG with a file, unitig_graph.cpp:208-303
+    std::vector<Contig> out;
+    Bits marked;
+    marked.reset(g.size);
+    for (int64_t e = 0; e < g.size; ++e) {
+        if (!(g.valid(e) && next_simple(g, e) == -1 && marked.try_lock(e))) continue;
+        bool add = true;
+        int64_t cur = e, prev;
+        int64_t depth = multiplicity(g, e);
+        int64_t length = 1;
+        while ((prev = prev_simple(g, cur)) != -1) {
+            cur = prev;
+            if (!marked.try_lock(cur)) { add = false; break; }
+            depth += multiplicity(g, cur);
+            ++length;
+        }
+        if (!add) continue;
+        int64_t rc_start = edge_reverse_complement(g, e), rc_end = -1;
+        if (!marked.try_lock(rc_start)) {
+            rc_end = edge_reverse_complement(g, cur);
+            if (std::max(e, cur) < std::max(rc_start, rc_end)) add = false;
+        } else {
+            int64_t rc = rc_start;
+            while ((rc = next_simple(g, rc)) != -1)
+                if (!marked.try_lock(rc)) break;
+        }
+        if (!add) continue;
+        std::string label = path_label(g, cur, e, (int)length);
+        if ((int)label.size() < min_contig) continue;
+        int flag = (edge_indegree(g, cur) == 0 && edge_outdegree(g, e) == 0) ? 1 : 0;     // contig_flag::kIsolated
+        double multi = std::min(65535.0, (double)depth / (double)length);
+        std::string rc(label.rbegin(), label.rend());
+        for (auto &c : rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        out.push_back(Contig{flag, multi, label < rc ? label : rc});
+    }
+    return out;
+}
+
+}  // namespace denovo
+
+
 struct orc_stream : Stream {};
 struct orc_graph : Graph {};
 struct orc_hmm : Hmm {};
@@ -1203,5 +1493,36 @@ int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, or
     memcpy(contig, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
 }
+
+// main_assemble (assembler.cpp:98-167) on a loaded graph; the graph's validity bits are consumed.  Returns the FASTA text
+// (">k{K}_{id} flag={f} multi={%.4lf} len={L}\n{seq}\n", unitig_graph.cpp:134-150), malloc'd.
+char *orc_denovo(orc_graph *g, int max_tip_len, int no_bubble, int min_contig, int64_t *n_contigs, int64_t *total_len, int64_t *n_tips,
+                 int64_t *n_bubbles) {
+    if (max_tip_len == -1) max_tip_len = g->k * 2;
+    int64_t tips = 0, bub = 0;
+    if (max_tip_len > 0) tips = denovo::remove_tips(*g, max_tip_len);
+    if (!no_bubble) bub = denovo::pop_bubbles(*g);
+    auto cs = denovo::unitigs(*g, min_contig);
+    std::string text;
+    int64_t total = 0, id = 0;
+    char head[128];
+    for (auto &c : cs) {
+        ++id;
+        snprintf(head, sizeof head, ">k%d_%lld flag=%d multi=%.4lf len=%d\n", g->k, (long long)id, c.flag, c.multi, (int)c.seq.size());
+        text += head;
+        text += c.seq;
+        text += '\n';
+        total += (int64_t)c.seq.size();
+    }
+    if (n_contigs) *n_contigs = (int64_t)cs.size();
+    if (total_len) *total_len = total;
+    if (n_tips) *n_tips = tips;
+    if (n_bubbles) *n_bubbles = bub;
+    char *r = (char *)malloc(text.size() + 1);
+    memcpy(r, text.c_str(), text.size() + 1);
+    return r;
+}
+void orc_free(void *p) { free(p); }
+const uint64_t *orc_graph_invalid_now(const orc_graph *g) { return g->invalid.data(); }
 
 }  // extern "C"

@@ -69,6 +69,14 @@ int orc_incoming(const orc_graph *, int64_t e, int64_t in[4]);    /* [succinct_d
 int orc_label(const orc_graph *, int64_t e, uint8_t *seq);        /* [succinct_dbg.cpp:503] */
 int64_t orc_index_edge(const orc_graph *, const uint8_t *seq);    /* k+1 symbols 1..4 [succinct_dbg.cpp:427,530] */
 
+/* ---- denovo (tips, bubbles, unitigs) as the reference's ONE-thread run ---------------------------
+ * [assembler.cpp:98-167, assembly_algorithms.cpp:76-183,245-301, branch_group.cpp:22-141, unitig_graph.cpp:80-150,208-303]
+ * Consumes the graph's validity bits.  Returns the malloc'd FASTA text (free with orc_free). */
+char *orc_denovo(orc_graph *, int max_tip_len, int no_bubble, int min_contig, int64_t *n_contigs, int64_t *total_len,
+                 int64_t *n_tips, int64_t *n_bubbles);
+void orc_free(void *);
+const uint64_t *orc_graph_invalid_now(const orc_graph *);
+
 /* ---- profile HMM ------------------------------------------------------------------------------ */
 typedef struct orc_hmm orc_hmm;
 orc_hmm *orc_hmm_parse(const char *path);                         /* [hmmer3b_parser.h:19-201], normalized=true */

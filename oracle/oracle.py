@@ -57,6 +57,7 @@ def lib():
         "orc_forward": (i64, [vp, i64]), "orc_backward": (i64, [vp, i64]),
         "orc_outgoing": (i32, [vp, i64, vp]), "orc_incoming": (i32, [vp, i64, vp]),
         "orc_label": (i32, [vp, i64, vp]), "orc_index_edge": (i64, [vp, vp]),
+        "orc_denovo": (vp, [vp, i32, i32, i32, vp, vp, vp, vp]), "orc_free": (None, [vp]), "orc_graph_invalid_now": (vp, [vp]),
         "orc_hmm_parse": (vp, [C.c_char_p]), "orc_hmm_free": (None, [vp]),
         "orc_hmm_M": (i32, [vp]), "orc_hmm_A": (i32, [vp]),
         "orc_hmm_msc": (vp, [vp]), "orc_hmm_isc": (vp, [vp]), "orc_hmm_tsc": (vp, [vp]), "orc_hmm_maxm": (vp, [vp]),
@@ -193,6 +194,18 @@ class Graph:
         m = {"A": 1, "C": 2, "G": 3, "T": 4, "N": 3}
         buf = (C.c_uint8 * (self.k + 2))(*[m[c] for c in kmer.upper()[: self.k + 1]])
         return lib().orc_index_edge(self.h, buf)
+
+    def denovo(self, max_tip_len: int = 150, no_bubble: bool = False, min_contig: int = 0):
+        """`megagta denovo` as the reference's one-thread run; CONSUMES the validity bits of this graph.
+        Returns (fasta_text, dict(n_contigs, total_len, n_tips, n_bubbles))."""
+        n = (C.c_int64 * 4)()
+        ptr = lib().orc_denovo(self.h, max_tip_len, int(no_bubble), min_contig, C.byref(n, 0), C.byref(n, 8), C.byref(n, 16), C.byref(n, 24))
+        text = C.string_at(ptr).decode()
+        lib().orc_free(ptr)
+        return text, dict(n_contigs=n[0], total_len=n[1], n_tips=n[2], n_bubbles=n[3])
+
+    def invalid_now(self) -> np.ndarray:
+        return _arr(lib().orc_graph_invalid_now(self.h), (self.size + 63) // 64, np.uint64).copy()
 
     def __del__(self):
         if getattr(self, "h", None):
