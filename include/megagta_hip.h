@@ -149,6 +149,27 @@ int mgta_findstart(mgta_ctx *, const mgta_reads *reads, int reads_reversed, int 
                    mgta_seed_hit *hits, int64_t cap, int64_t *n_hits, double *ms_kernel /* optional */);
 
 /* ------------------------------------------------------------------------------------------------
+ * `megagta denovo` on a loaded graph (multi-k runs: the contigs of k feed `buildgraph --assist_seq` of the next k and `findstart`):
+ * RemoveTips (assembly_algorithms.cpp:76-183), PopBubbles (:245-301, branch_group.cpp:22-141), then the maximal simple paths
+ * written as contigs (main_assemble, assembler.cpp:98-167; UnitigGraph::InitFromSdBG with a file, unitig_graph.cpp:80-150,208-303).
+ * The reference's loops race between threads; the result here is that of its ONE-thread run, byte for byte, computed in parallel
+ * on the device (see denovo.hip).  CONSUMES the validity bits of the graph (as the reference does): do not search it afterwards.
+ * max_tip_len: -1 = 2k, 0 = keep tips; min_contig: shortest contig written (the driver passes the next k + 1).
+ * *fasta receives the malloc'd text of PREFIX.contigs.fa (">k{K}_{id} flag={f} multi={%.4lf} len={L}\n{seq}\n" per contig, ids in
+ * ascending end-edge order = the one-thread order); free it with mgta_host_free.  PREFIX.contigs.fa.info is "n_contigs total_len\n".
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mgta_denovo_stats {
+    int64_t n_tips, n_bubbles;               /* what the reference logs: tips removed, bubbles popped */
+    int64_t n_bubble_candidates, n_bubble_rounds;
+    int64_t n_paths, n_unitig_sweeps;
+    int64_t n_contigs, total_len;
+    float ms_tips, ms_bubbles, ms_unitigs;
+} mgta_denovo_stats;
+int mgta_denovo(mgta_sdbg *, int max_tip_len, int no_bubble, int min_contig, char **fasta, uint64_t *fasta_len,
+                mgta_denovo_stats *stats /* optional */);
+void mgta_host_free(void *);
+
+/* ------------------------------------------------------------------------------------------------
  * Profile HMM tables (parsed on the host exactly like Parser::readHMM, hmmer3b_parser.h:19-177;
  * heuristic like MostProbablePath, most_probable_path.h:48-118)
  * ------------------------------------------------------------------------------------------------ */

@@ -20,6 +20,15 @@ class MegaGtaError(RuntimeError):
     pass
 
 
+class DenovoStats(C.Structure):
+    _fields_ = [("n_tips", C.c_int64), ("n_bubbles", C.c_int64), ("n_bubble_candidates", C.c_int64), ("n_bubble_rounds", C.c_int64),
+                ("n_paths", C.c_int64), ("n_unitig_sweeps", C.c_int64), ("n_contigs", C.c_int64), ("total_len", C.c_int64),
+                ("ms_tips", C.c_float), ("ms_bubbles", C.c_float), ("ms_unitigs", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class BuildStats(C.Structure):
     _fields_ = [("k", C.c_int32), ("words_per_key", C.c_int32), ("words_per_tip", C.c_int32), ("n_passes", C.c_int32),
                 ("n_reads", C.c_int64), ("n_kmers", C.c_int64), ("n_items", C.c_int64), ("n_edges", C.c_int64),
@@ -70,6 +79,8 @@ SYMBOLS = {
                                  C.c_int, EDGE_SINK, C.c_void_p, C.POINTER(BuildStats)]),
     "mgta_findstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgta_host_free": (None, [C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "mgta_sdbg_free": (None, [C.c_void_p]),

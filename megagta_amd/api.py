@@ -163,6 +163,18 @@ class Graph:
         check(self.ctx._L.mgta_sdbg_index_edges(self.h, seqs.ctypes.data, len(kmers), ids.ctypes.data), "mgta_sdbg_index_edges")
         return ids
 
+    def denovo(self, max_tip_len: int = 150, no_bubble: bool = False, min_contig: int = 0) -> tuple[str, dict]:
+        """`megagta denovo` (main_assemble, assembler.cpp:98-167): tips, bubbles, unitigs -> (text of PREFIX.contigs.fa, stats).
+        The result is the reference's one-thread output.  CONSUMES the validity bits of this graph."""
+        from ._lib import DenovoStats
+        text, n, st = C.c_void_p(), C.c_uint64(), DenovoStats()
+        check(self.ctx._L.mgta_denovo(self.h, max_tip_len, int(no_bubble), min_contig, C.byref(text), C.byref(n), C.byref(st)), "mgta_denovo")
+        try:
+            fasta = C.string_at(text, n.value).decode()
+        finally:
+            self.ctx._L.mgta_host_free(text)
+        return fasta, st.as_dict()
+
     def free(self):
         if getattr(self, "h", None):
             self.ctx._L.mgta_sdbg_free(self.h)

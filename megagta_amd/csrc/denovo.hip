@@ -1,0 +1,773 @@
+// denovo.hip — `megagta denovo` (tips, bubbles, unitigs) on the device-resident succinct de Bruijn graph.
+//
+// Replaces main_assemble (assembler.cpp:98-167): RemoveTips / Trim (assembly_algorithms.cpp:76-183), PopBubbles (:245-301) with
+// BranchGroup::Search / Pop (branch_group.cpp:22-141), and UnitigGraph::InitFromSdBG writing contigs (unitig_graph.cpp:80-150,208-303).
+//
+// The reference's OpenMP loops race (its 8-thread output differs from its 1-thread output on the same graph); the result reproduced
+// here is the ONE-thread run, byte for byte, and it is computed in parallel:
+//  * Trim marks on a snapshot and deletes afterwards, so every start node is an independent thread.
+//  * PopBubbles is order dependent (a pop changes what the next search sees).  Candidates are taken in windows of ascending edge id;
+//    every candidate of the window runs its search on the current graph and stamps every still-valid edge it looked at with
+//    (round, rank) by atomicMax; a candidate keeps its claim if it still holds all its stamps.  Everything below the FIRST candidate
+//    that lost a stamp has a footprint no lower candidate touches, so those searches see exactly what the sequential loop would
+//    show them: they commit (pop) together, the window restarts at the first loser.  No clearing: a newer round outranks old stamps.
+//  * Unitigs: the reference walks every maximal simple path back from its end edge in ascending order, locking edges in a bit
+//    vector, then locks the path of the reverse complement forwards from RC(end).  With one thread the locks held inside a path are
+//    always a suffix of it that reaches its end edge, so the whole protocol collapses to: path P (end e) is skipped iff an earlier
+//    processed (q < e), not skipped path Q has RC(q) inside P.  That recursion over ascending ids is resolved by a few data-parallel
+//    sweeps; the rarely taken "RC(end) already locked" branch (:243-252) is evaluated from the same claims.
+//    (PopBubbles keeps the LAST branch on equal multiplicities, which is a different allele on the two strands: the graph is not
+//    strand-symmetric afterwards, so none of this may assume that RC(path) is a path.)
+#include <algorithm>
+#include <memory>
+
+#include "graph.hpp"
+#include "scan.hpp"
+
+namespace mgta {
+namespace {
+
+constexpr int kMaxBranches = 16;      // kMaxBranchesPerGroup, assembly_algorithms.cpp:248
+constexpr int kBubbleWindowMax = 16384;
+constexpr int kMaxK = 255;
+
+struct Dn {
+    GraphDev g;
+    GLine *rw;     // the same lines, writable: validity bits
+};
+
+// ---- bit vectors (AtomicBitVector, one bit per edge) ---------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_get(const unsigned long long *b, int64_t i) { return (b[i >> 6] >> (i & 63)) & 1; }
+__device__ __forceinline__ void bit_set(unsigned long long *b, int64_t i) { atomicOr(&b[i >> 6], 1ull << (i & 63)); }
+__device__ __forceinline__ void bit_unset(unsigned long long *b, int64_t i) { atomicAnd(&b[i >> 6], ~(1ull << (i & 63))); }
+__device__ __forceinline__ bool bit_try_lock(unsigned long long *b, int64_t i) { return !((atomicOr(&b[i >> 6], 1ull << (i & 63)) >> (i & 63)) & 1); }
+
+__device__ __forceinline__ void set_invalid(const Dn &d, int64_t e) { atomicOr((unsigned long long *)&d.rw[e >> 6].invalid, 1ull << (e & 63)); }
+__device__ __forceinline__ void set_valid(const Dn &d, int64_t e) { atomicAnd((unsigned long long *)&d.rw[e >> 6].invalid, ~(1ull << (e & 63))); }
+__device__ __forceinline__ int multiplicity(const GraphDev &g, int64_t e) { return 2 - (int)g_multi1(g, e); }   // succinct_dbg.h:133-135, need_multiplicity = false
+
+// ---- navigation the A* path does not need (succinct_dbg.cpp:99-371) -----------------------------------------------------------
+__device__ inline int64_t d_last_index(const GraphDev &g, int64_t x) {   // GetLastIndex = rs_last_.Succ, succinct_dbg.h:105
+    uint64_t li = (uint64_t)x >> 6;
+    uint64_t m = g.lines[li].last >> (x & 63);
+    if (m) return x + __ffsll((long long)m) - 1;
+    while (++li < g.n_lines) {
+        uint64_t w = g.lines[li].last;
+        if (w) return (int64_t)(li << 6) + __ffsll((long long)w) - 1;
+    }
+    return g.size;
+}
+
+// edges that point to the node of x (IncomingEdges / UniquePrev* / NodeIndegreeZero / DeleteAllEdges share this scan)
+template <bool ALL>
+__device__ inline int d_incoming_scan(const GraphDev &g, int64_t x, int64_t *in) {
+    int64_t first = g_backward(g, x);
+    const int c = g_W(g, first);
+    int ones = g_last_or_tip(g, first), n = 0;
+    if (ALL || g_valid(g, first)) in[n++] = first;
+    for (int64_t y = first + 1; ones < 5 && y < g.size; ++y) {
+        ones += g_last_or_tip(g, y);
+        const int cur = g_W(g, y);
+        if (cur == c) break;
+        if (cur == c + 4 && (ALL || g_valid(g, y)) && n < 8) in[n++] = y;
+    }
+    return n;
+}
+template <bool ALL>
+__device__ inline int d_node_edges(const GraphDev &g, int64_t node, int64_t *out) {   // the node's own edges, from its last one downwards
+    int64_t e = d_last_index(g, node);
+    int n = 0;
+    do {
+        if ((ALL || g_valid(g, e)) && n < 8) out[n++] = e;
+        --e;
+    } while (e >= 0 && !g_last_or_tip(g, e));
+    return n;
+}
+__device__ inline int d_outgoing(const GraphDev &g, int64_t e, int64_t *out) {   // OutgoingEdges, valid edge ids in descending order
+    if (!g_valid(g, e)) return -1;
+    int n = 0;
+    int64_t x = g_forward(g, e);
+    do {
+        if (g_valid(g, x) && n < 8) out[n++] = x;
+        --x;
+    } while (x >= 0 && !g_last_or_tip(g, x));
+    return n;
+}
+__device__ inline int d_incoming(const GraphDev &g, int64_t e, int64_t *in) {
+    if (!g_valid(g, e)) return -1;
+    return d_incoming_scan<false>(g, e, in);
+}
+__device__ inline bool node_outdegree_zero(const GraphDev &g, int64_t node) { int64_t t[8]; return d_node_edges<false>(g, node, t) == 0; }
+__device__ inline bool node_indegree_zero(const GraphDev &g, int64_t node) { int64_t t[8]; return d_incoming_scan<false>(g, node, t) == 0; }
+__device__ inline int64_t unique_prev_node(const GraphDev &g, int64_t node) {
+    int64_t t[8];
+    return d_incoming_scan<false>(g, node, t) == 1 ? d_last_index(g, t[0]) : -1;
+}
+__device__ inline int64_t unique_next_node(const GraphDev &g, int64_t node) {
+    int64_t t[8];
+    return d_node_edges<false>(g, node, t) == 1 ? d_last_index(g, g_forward(g, t[0])) : -1;
+}
+__device__ inline int64_t unique_next_edge(const GraphDev &g, int64_t e) {
+    int64_t t[8];
+    return d_outgoing(g, e, t) == 1 ? t[0] : -1;
+}
+__device__ inline int64_t unique_prev_edge(const GraphDev &g, int64_t e) {
+    int64_t t[8];
+    return d_incoming(g, e, t) == 1 ? t[0] : -1;
+}
+__device__ inline int64_t prev_simple(const GraphDev &g, int64_t e) {   // PrevSimplePathEdge
+    int64_t p = unique_prev_edge(g, e);
+    return p != -1 && unique_next_edge(g, p) != -1 ? p : -1;
+}
+__device__ inline int64_t next_simple(const GraphDev &g, int64_t e) {   // NextSimplePathEdge
+    int64_t n = unique_next_edge(g, e);
+    return n != -1 && unique_prev_edge(g, n) != -1 ? n : -1;
+}
+
+__device__ inline void d_label(const GraphDev &g, int64_t e, uint8_t *seq) {   // Label, succinct_dbg.cpp:503-528 (symbols 1..4)
+    int64_t x = e;
+    for (int i = g.k - 1; i >= 0; --i) {
+        if (g_tip(g, x)) {
+            int64_t tr = g_rank_tip(g, x) - 1;
+            for (int j = 0; j <= i; ++j) seq[i - j] = (uint8_t)(g_tip_char(g, tr, j) + 1);
+            break;
+        }
+        x = g_backward(g, x);
+        int c = g_W(g, x);
+        seq[i] = (uint8_t)(c > 4 ? c - 4 : c);
+    }
+}
+__device__ inline int64_t edge_reverse_complement(const GraphDev &g, int64_t e) {   // succinct_dbg.cpp:551-593
+    if (!g_valid(g, e)) return -1;
+    uint8_t seq[kMaxK + 2];
+    d_label(g, e, seq);
+    int w = g_W(g, e);
+    seq[g.k] = (uint8_t)(w > 4 ? w - 4 : w);
+    for (int i = 0, j = g.k; i <= j; ++i, --j) {
+        uint8_t a = (uint8_t)(5 - seq[i]), b = (uint8_t)(5 - seq[j]);
+        seq[i] = b; seq[j] = a;
+    }
+    return g_index_edge(g, seq);
+}
+
+// ---- ordered compaction: one 64-bit mask per line of edges -> ascending list of edge ids ------------------------------------------
+struct PredTipStartOut {   // Trim, first loop: assembly_algorithms.cpp:82
+    const unsigned long long *removed;
+    __device__ bool operator()(const GraphDev &g, int64_t x) const { return g_last(g, x) && !bit_get(removed, x) && node_outdegree_zero(g, x); }
+};
+struct PredTipStartIn {    // second loop, :116
+    const unsigned long long *removed;
+    __device__ bool operator()(const GraphDev &g, int64_t x) const { return g_last(g, x) && !bit_get(removed, x) && node_indegree_zero(g, x); }
+};
+struct PredBranching {     // BranchGroup::Search can only succeed from an edge whose out-degree is 2..16 (branch_group.cpp:23-27)
+    __device__ bool operator()(const GraphDev &g, int64_t x) const {
+        int64_t t[8];
+        return d_outgoing(g, x, t) >= 2;
+    }
+};
+struct PredPathEnd {       // unitig_graph.cpp:223
+    __device__ bool operator()(const GraphDev &g, int64_t x) const { return g_valid(g, x) && next_simple(g, x) == -1; }
+};
+
+template <class Pred>
+__global__ __launch_bounds__(256) void edge_mask_kernel(GraphDev g, Pred pred, unsigned long long *mask, uint32_t *count) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one wave = one line of 64 edges
+    const bool p = x < g.size && pred(g, x);
+    const unsigned long long m = __ballot(p);
+    if ((threadIdx.x & 63) == 0 && (uint64_t)(x >> 6) < g.n_lines) {
+        mask[x >> 6] = m;
+        count[x >> 6] = (uint32_t)__popcll(m);
+    }
+}
+__global__ __launch_bounds__(256) void mask_expand_kernel(const unsigned long long *mask, const uint64_t *base, uint64_t n_lines, int64_t *list) {
+    const uint64_t li = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= n_lines) return;
+    unsigned long long m = mask[li];
+    uint64_t o = base[li];
+    while (m) {
+        int b = __ffsll((long long)m) - 1;
+        list[o++] = (int64_t)(li << 6) + b;
+        m &= m - 1;
+    }
+}
+__global__ __launch_bounds__(256) void list_compact_kernel(const int64_t *in, const uint32_t *flag, const uint64_t *base, uint64_t n, int64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && flag[i]) out[base[i]] = in[i];
+}
+
+// ---- tips -----------------------------------------------------------------------------------------------------------------------
+template <bool OUT>
+__global__ __launch_bounds__(64) void trim_walk_kernel(GraphDev g, const int64_t *starts, uint64_t n, int len, unsigned long long *removed,
+                                                       unsigned long long *n_tips) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t x = starts[i];
+    int64_t cur = x;
+    bool is_tip = false;
+    int steps = 0;
+    for (int s = 1; s < len; ++s) {
+        const int64_t nb = OUT ? unique_prev_node(g, cur) : unique_next_node(g, cur);
+        if (nb == -1) { is_tip = OUT ? node_indegree_zero(g, cur) : node_outdegree_zero(g, cur); break; }
+        if ((OUT ? unique_next_node(g, nb) : unique_prev_node(g, nb)) == -1) { is_tip = true; break; }
+        cur = nb;
+        ++steps;
+    }
+    if (!is_tip) return;
+    cur = x;
+    bit_set(removed, cur);
+    for (int s = 0; s < steps; ++s) {      // the same walk again (nothing changes the graph while tips are being marked)
+        cur = OUT ? unique_prev_node(g, cur) : unique_next_node(g, cur);
+        bit_set(removed, cur);
+    }
+    atomicAdd(n_tips, 1ull);
+}
+__global__ __launch_bounds__(256) void trim_delete_kernel(Dn d, const unsigned long long *removed) {   // DeleteAllEdges of every marked node
+    const uint64_t li = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= d.g.n_lines) return;
+    unsigned long long m = removed[li];
+    while (m) {
+        const int64_t node = (int64_t)(li << 6) + __ffsll((long long)m) - 1;
+        m &= m - 1;
+        int64_t t[8];
+        int n = d_node_edges<true>(d.g, node, t);
+        for (int i = 0; i < n; ++i) set_invalid(d, t[i]);
+        n = d_incoming_scan<true>(d.g, node, t);
+        for (int i = 0; i < n; ++i) set_invalid(d, t[i]);
+    }
+}
+
+// ---- bubbles --------------------------------------------------------------------------------------------------------------------
+struct SinkNone { __device__ void operator()(int64_t) {} };
+struct SinkStamp {
+    unsigned long long *owner, key;
+    __device__ void operator()(int64_t e) { atomicMax(&owner[e], key); }
+};
+struct SinkCheck {
+    const unsigned long long *owner;
+    unsigned long long key;
+    bool ok;
+    __device__ void operator()(int64_t e) { if (owner[e] != key) ok = false; }
+};
+
+// BranchGroup::Search (branch_group.cpp:22-103).  br[b * max_len + j] = j-th edge of branch b; every still-valid edge whose validity
+// the search reads goes through `sink` (an invalid edge stays invalid, reading it is not a dependency).
+template <class Sink>
+__device__ bool bubble_search(const GraphDev &g, int64_t begin, int max_len, int64_t *br, int *mult, int &nb, int &len, Sink &sink) {
+    if (!g_valid(g, begin)) return false;
+    sink(begin);
+    int64_t out[8];
+    const int outd = d_outgoing(g, begin, out);
+    for (int x = 0; x < outd; ++x) sink(out[x]);
+    if (outd <= 1 || outd > kMaxBranches) return false;
+    nb = 1; len = 1;
+    br[0] = begin;
+    mult[0] = 0;
+    bool converged = false;
+    int64_t end = -1;
+    for (int j = 1; j < max_len; ++j) {
+        const int nb0 = nb;
+        for (int i = 0; i < nb0; ++i) {
+            const int od = d_outgoing(g, br[(size_t)i * max_len + j - 1], out);
+            for (int x = 0; x < od; ++x) sink(out[x]);
+            if (od < 1) return false;                       // a dead end never converges (the reference runs on and fails later)
+            br[(size_t)i * max_len + j] = out[0];
+            const int m0 = mult[i];
+            mult[i] = m0 + multiplicity(g, out[0]);
+            if (nb + od - 1 > kMaxBranches) return false;
+            for (int x = 1; x < od; ++x) {
+                for (int q = 0; q < j; ++q) br[(size_t)nb * max_len + q] = br[(size_t)i * max_len + q];
+                br[(size_t)nb * max_len + j] = out[x];
+                mult[nb] = m0 + multiplicity(g, out[x]);
+                ++nb;
+            }
+        }
+        len = j + 1;
+        for (int b = 0; b < nb; ++b) {                      // every edge into a branch head must come from the group
+            int64_t in[8];
+            const int id = d_incoming(g, br[(size_t)b * max_len + j], in);
+            for (int x = 0; x < id; ++x) sink(in[x]);
+            if (id == 1) continue;
+            for (int x = 0; x < id; ++x) {
+                bool found = false;
+                for (int o = 0; o < nb && !found; ++o) found = br[(size_t)o * max_len + j - 1] == in[x];
+                if (!found) return false;
+            }
+        }
+        end = br[j];
+        const int eo = d_outgoing(g, end, out);
+        for (int x = 0; x < eo; ++x) sink(out[x]);
+        if (eo == 1) {
+            converged = true;
+            for (int b = 1; b < nb && converged; ++b) converged = br[(size_t)b * max_len + j] == end;
+            if (converged) break;
+        }
+    }
+    return converged && begin != end;
+}
+
+// BranchGroup::Pop (branch_group.cpp:105-141) with one thread: fails (and undoes itself) when an inner edge shows up twice
+__device__ bool bubble_pop(const Dn &d, unsigned long long *marked, const int64_t *br, const int *mult, int nb, int len, int max_len) {
+    int best = 0, best_m = mult[0];
+    for (int i = 1; i < nb; ++i)
+        if (mult[i] >= best_m) { best = i; best_m = mult[i]; }
+    for (int i = 0; i < nb; ++i)
+        for (int j = 1; j + 1 < len; ++j) {
+            const int64_t e = br[(size_t)i * max_len + j];
+            if (!bit_try_lock(marked, e)) {
+                for (int i2 = 0; i2 <= i; ++i2)
+                    for (int j2 = 1; j2 + 1 < len && (i2 < i || j2 < j); ++j2) {
+                        const int64_t u = br[(size_t)i2 * max_len + j2];
+                        bit_unset(marked, u);
+                        set_valid(d, u);
+                    }
+                return false;
+            }
+            set_invalid(d, e);
+        }
+    for (int j = 1; j + 1 < len; ++j) {
+        const int64_t e = br[(size_t)best * max_len + j];
+        set_valid(d, e);
+        bit_unset(marked, e);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64_t *cand, uint64_t n, int max_len, int64_t *scratch, uint32_t *found) {
+    const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x, stride = (uint64_t)gridDim.x * 64;
+    int64_t *br = scratch + t * (size_t)kMaxBranches * max_len;
+    for (uint64_t i = t; i < n; i += stride) {
+        int mult[kMaxBranches], nb = 0, len = 0;
+        SinkNone s;
+        found[i] = bubble_search(g, cand[i], max_len, br, mult, nb, len, s) ? 1u : 0u;
+    }
+}
+__global__ __launch_bounds__(64) void bubble_stamp_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
+                                                          unsigned long long *owner, unsigned long long round) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int mult[kMaxBranches], nb = 0, len = 0;
+    SinkStamp s{owner, (round << 32) | (0xFFFFFFFFull - i)};
+    bubble_search(g, cand[i], max_len, scratch + (size_t)i * kMaxBranches * max_len, mult, nb, len, s);
+}
+__global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
+                                                          const unsigned long long *owner, unsigned long long round, uint32_t *first_loser) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int mult[kMaxBranches], nb = 0, len = 0;
+    SinkCheck s{owner, (round << 32) | (0xFFFFFFFFull - i), true};
+    bubble_search(g, cand[i], max_len, scratch + (size_t)i * kMaxBranches * max_len, mult, nb, len, s);
+    if (!s.ok) atomicMin(first_loser, i);
+}
+// status: 0 = the search fails now, 1 = popped, 2 = Pop undid itself (goes to the second list, assembly_algorithms.cpp:273-277)
+__global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
+                                                           unsigned long long *marked, uint32_t *status) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int mult[kMaxBranches], nb = 0, len = 0;
+    int64_t *br = scratch + (size_t)i * kMaxBranches * max_len;
+    SinkNone s;
+    uint32_t st = 0;
+    if (bubble_search(d.g, cand[i], max_len, br, mult, nb, len, s)) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
+    status[i] = st;
+}
+__global__ __launch_bounds__(256) void flag_equals_kernel(const uint32_t *status, uint64_t n, uint32_t want, uint32_t *flag, unsigned long long *count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t f = status[i] == want;
+    flag[i] = f;
+    if (f && count) atomicAdd(count, 1ull);
+}
+
+// ---- unitigs --------------------------------------------------------------------------------------------------------------------
+struct PathRec {
+    int64_t end, start, rc_start, depth;
+    uint32_t length;      // edges
+    int32_t target;       // path whose suffix the walk from RC(end) locks (-1: RC(end) is not on a path that ends)
+    uint32_t dist;        // edges from RC(end) to that path's end
+    int32_t next;         // next claim on the same target
+};
+
+__device__ inline int32_t find_path(const int64_t *ends, uint32_t n, int64_t e) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ends[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && ends[lo] == e ? (int32_t)lo : -1;
+}
+
+__global__ __launch_bounds__(64) void unitig_walk_kernel(GraphDev g, const int64_t *ends, uint32_t n, PathRec *rec, int32_t *head) {
+    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    if (pid >= n) return;
+    const int64_t e = ends[pid];
+    int64_t cur = e, p;
+    int64_t depth = multiplicity(g, e);
+    uint32_t length = 1;
+    while ((p = prev_simple(g, cur)) != -1) {       // unitig_graph.cpp:229-239 (never a cycle: e has no simple successor)
+        cur = p;
+        depth += multiplicity(g, cur);
+        ++length;
+    }
+    PathRec r;
+    r.end = e; r.start = cur; r.depth = depth; r.length = length;
+    r.rc_start = edge_reverse_complement(g, e);
+    r.target = -1; r.dist = 0; r.next = -1;
+    if (r.rc_start >= 0 && g_valid(g, r.rc_start)) {     // :262-273: lock forwards from RC(end) to the end of the path it lies on
+        int64_t x = r.rc_start, nx;
+        uint32_t dist = 0;
+        bool cycle = false;
+        while ((nx = next_simple(g, x)) != -1) {
+            x = nx;
+            ++dist;
+            if (x == r.rc_start) { cycle = true; break; }
+        }
+        if (!cycle) { r.target = find_path(ends, n, x); r.dist = dist; }
+    }
+    if (r.target >= 0) r.next = atomicExch(&head[r.target], (int32_t)pid);
+    rec[pid] = r;
+}
+
+// state: 0 = not known yet, 1 = processed (its edges get locked by its own walk), 2 = skipped at `marked.try_lock(edge_idx)`
+__global__ __launch_bounds__(256) void unitig_resolve_kernel(const PathRec *rec, const int32_t *head, uint32_t n, uint32_t *state, uint32_t *undecided) {
+    const uint32_t pid = blockIdx.x * 256 + threadIdx.x;
+    if (pid >= n || __hip_atomic_load(&state[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int64_t e = rec[pid].end;
+    bool pending = false, skipped = false;
+    for (int32_t q = head[pid]; q >= 0; q = rec[q].next) {
+        if ((uint32_t)q == pid || rec[q].end >= e) continue;
+        const uint32_t s = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s == 1) { skipped = true; break; }
+        if (s == 0) pending = true;
+    }
+    if (skipped) __hip_atomic_store(&state[pid], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (!pending) __hip_atomic_store(&state[pid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else atomicAdd(undecided, 1u);
+}
+
+__global__ __launch_bounds__(64) void unitig_decide_kernel(GraphDev g, const PathRec *rec, const int32_t *head, const uint32_t *state, uint32_t n,
+                                                           int min_contig, uint32_t *emit, uint32_t *emit_len) {
+    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    if (pid >= n) return;
+    emit[pid] = 0; emit_len[pid] = 0;
+    if (state[pid] != 1) return;
+    const PathRec r = rec[pid];
+    bool add = true;
+    if (r.target >= 0) {       // was RC(end) locked when this path was processed? (unitig_graph.cpp:245)
+        const int32_t t = r.target;
+        bool locked = (uint32_t)t == pid || (state[t] == 1 && rec[t].end < r.end);
+        for (int32_t q = head[t]; q >= 0 && !locked; q = rec[q].next)
+            locked = (uint32_t)q != pid && state[q] == 1 && rec[q].end < r.end && rec[q].dist > r.dist;
+        if (locked) {
+            const int64_t rc_end = edge_reverse_complement(g, r.start);
+            const int64_t a = r.end > r.start ? r.end : r.start, b = r.rc_start > rc_end ? r.rc_start : rc_end;
+            if (a < b) add = false;                                                  // :248-252
+        }
+    }
+    const uint32_t len = r.length + (uint32_t)g.k;
+    if (add && (int)len >= min_contig) { emit[pid] = 1; emit_len[pid] = len; }
+}
+
+struct ContigMeta { int64_t depth; uint32_t length, len; int32_t flag; uint32_t pad; uint64_t offset; };
+
+__global__ __launch_bounds__(64) void unitig_emit_kernel(GraphDev g, const PathRec *rec, const uint32_t *emit, const uint64_t *idx, const uint64_t *off,
+                                                         uint32_t n, ContigMeta *meta, char *text) {
+    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    if (pid >= n || !emit[pid]) return;
+    const PathRec r = rec[pid];
+    const int k = g.k;
+    const uint32_t len = r.length + (uint32_t)k;
+    char *s = text + off[pid];
+    int64_t cur = r.end;
+    for (uint32_t i = r.length; i-- > 0;) {          // VertexToDNAString, unitig_graph.cpp:80-112
+        int w = g_W(g, cur);
+        s[k + i] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
+        if (i) cur = prev_simple(g, cur);
+    }
+    uint8_t lab[kMaxK + 1];
+    d_label(g, r.start, lab);
+    for (int i = 0; i < k; ++i) s[i] = "ACGT"[lab[i] - 1];
+    // the smaller of the label and its reverse complement (WriteContig, :134-150)
+    auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
+    int cmp = 0;
+    for (uint32_t i = 0; i < len && cmp == 0; ++i) {
+        const char a = s[i], b = comp(s[len - 1 - i]);
+        cmp = a < b ? -1 : a > b ? 1 : 0;
+    }
+    if (cmp > 0)
+        for (uint32_t i = 0, j = len - 1; i <= j && j != 0xFFFFFFFFu; ++i, --j) {
+            const char a = comp(s[i]), b = comp(s[j]);
+            s[i] = b; s[j] = a;
+        }
+    int64_t t[8];
+    ContigMeta m;
+    m.depth = r.depth; m.length = r.length; m.len = len; m.pad = 0; m.offset = off[pid];
+    m.flag = (d_incoming(g, r.start, t) == 0 && d_outgoing(g, r.end, t) == 0) ? 1 : 0;   // contig_flag::kIsolated
+    meta[idx[pid]] = m;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+struct Work {
+    mgta_ctx *ctx;
+    hipStream_t st;
+    Dn d;
+    DevBuf mask, count, base, tmp, total;
+    uint64_t *live() { return &ctx->live_bytes; }
+    uint64_t *peak() { return &ctx->peak_bytes; }
+};
+
+static uint64_t read_u64(Work &w, const void *p) {
+    uint64_t v = 0;
+    MGTA_HIP_CHECK(hipMemcpyAsync(&v, p, 8, hipMemcpyDeviceToHost, w.st));
+    MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+    return v;
+}
+
+template <class Pred>
+static uint64_t edges_where(Work &w, Pred pred, DevBuf &list) {   // ascending ids of the edges that satisfy pred
+    const GraphDev &g = w.d.g;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mask_kernel<Pred>), dim3((unsigned)((g.size + 255) / 256)), dim3(256), 0, w.st, g, pred,
+                       w.mask.as<unsigned long long>(), w.count.as<uint32_t>());
+    exclusive_scan_u32(w.st, w.count.as<uint32_t>(), g.n_lines, w.base.as<uint64_t>(), w.tmp.as<uint64_t>(), w.total.as<uint64_t>());
+    const uint64_t n = read_u64(w, w.total.p);
+    list.alloc(n * 8 + 64, w.live(), w.peak());
+    if (n)
+        hipLaunchKernelGGL(mask_expand_kernel, dim3((unsigned)((g.n_lines + 255) / 256)), dim3(256), 0, w.st, w.mask.as<unsigned long long>(),
+                           w.base.as<uint64_t>(), g.n_lines, list.as<int64_t>());
+    return n;
+}
+
+static uint64_t compact_list(Work &w, const DevBuf &in, const DevBuf &flag, uint64_t n, DevBuf &out) {
+    if (n == 0) { out.alloc(64, w.live(), w.peak()); return 0; }
+    DevBuf base, tmp;
+    base.alloc(n * 8, w.live(), w.peak());
+    tmp.alloc(scan_tmp_elems(n) * 8, w.live(), w.peak());
+    exclusive_scan_u32(w.st, flag.as<uint32_t>(), n, base.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
+    const uint64_t m = read_u64(w, w.total.p);
+    out.alloc(m * 8 + 64, w.live(), w.peak());
+    if (m)
+        hipLaunchKernelGGL(list_compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w.st, in.as<int64_t>(), flag.as<uint32_t>(),
+                           base.as<uint64_t>(), n, out.as<int64_t>());
+    MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+    return m;
+}
+
+static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms.cpp:161-183
+    const GraphDev &g = w.d.g;
+    DevBuf removed, counter;
+    removed.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
+    counter.alloc(64, w.live(), w.peak());
+    MGTA_HIP_CHECK(hipMemsetAsync(removed.p, 0, (g.n_lines + 1) * 8, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 64, w.st));
+    auto trim = [&](int len) {
+        DevBuf starts;
+        uint64_t n = edges_where(w, PredTipStartOut{removed.as<unsigned long long>()}, starts);
+        if (n)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trim_walk_kernel<true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, w.st, g, starts.as<int64_t>(), n, len,
+                               removed.as<unsigned long long>(), counter.as<unsigned long long>());
+        n = edges_where(w, PredTipStartIn{removed.as<unsigned long long>()}, starts);
+        if (n)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(trim_walk_kernel<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, w.st, g, starts.as<int64_t>(), n, len,
+                               removed.as<unsigned long long>(), counter.as<unsigned long long>());
+        hipLaunchKernelGGL(trim_delete_kernel, dim3((unsigned)((g.n_lines + 255) / 256)), dim3(256), 0, w.st, w.d, removed.as<unsigned long long>());
+        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+    };
+    for (int len = 2; len < max_tip_len; len *= 2) trim(len);
+    trim(max_tip_len);
+    return read_u64(w, counter.p);
+}
+
+// the ordered loop `for each candidate: Search, then Pop` (assembly_algorithms.cpp:266-279 and :283-292) in windows
+static void pop_in_order(Work &w, const DevBuf &cand, uint64_t n, int max_len, DevBuf &scratch, DevBuf &owner, DevBuf &marked, DevBuf &status,
+                         uint64_t &round, int64_t &n_rounds) {
+    const GraphDev &g = w.d.g;
+    DevBuf first;
+    first.alloc(64, w.live(), w.peak());
+    uint64_t p = 0;
+    uint32_t window = 2048;
+    while (p < n) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(window, n - p);
+        ++round; ++n_rounds;
+        const int64_t *c = cand.as<int64_t>() + p;
+        MGTA_HIP_CHECK(hipMemsetAsync(first.p, 0xFF, 4, w.st));
+        hipLaunchKernelGGL(bubble_stamp_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, scratch.as<int64_t>(),
+                           owner.as<unsigned long long>(), (unsigned long long)round);
+        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, scratch.as<int64_t>(),
+                           owner.as<unsigned long long>(), (unsigned long long)round, first.as<uint32_t>());
+        uint32_t f = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&f, first.p, 4, hipMemcpyDeviceToHost, w.st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+        if (f > m) f = m;
+        if (f == 0) f = 1;        // the lowest candidate holds every stamp it made; never taken
+        hipLaunchKernelGGL(bubble_commit_kernel, dim3((f + 63) / 64), dim3(64), 0, w.st, w.d, c, f, max_len, scratch.as<int64_t>(),
+                           marked.as<unsigned long long>(), status.as<uint32_t>() + p);
+        p += f;
+        window = f == m ? std::min<uint32_t>(kBubbleWindowMax, window * 2) : std::max<uint32_t>(256, std::min<uint32_t>(kBubbleWindowMax, 2 * f));
+    }
+    MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+}
+
+static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {   // assembly_algorithms.cpp:245-301
+    const GraphDev &g = w.d.g;
+    const int max_len = g.k * 2 + 4;
+    DevBuf branching, found, cand, scratch, owner, marked, status, flag, again, counter;
+    uint64_t nb = edges_where(w, PredBranching{}, branching);
+    const uint64_t per = (uint64_t)kMaxBranches * max_len;
+    scratch.alloc((size_t)kBubbleWindowMax * per * 8, w.live(), w.peak());
+    found.alloc(nb * 4 + 64, w.live(), w.peak());
+    if (nb)
+        hipLaunchKernelGGL(bubble_find_kernel, dim3(kBubbleWindowMax / 64), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len,
+                           scratch.as<int64_t>(), found.as<uint32_t>());
+    const uint64_t nc = compact_list(w, branching, found, nb, cand);
+    n_candidates = (int64_t)nc;
+    if (nc == 0) return 0;
+    owner.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
+    marked.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
+    status.alloc(nc * 4 + 64, w.live(), w.peak());
+    flag.alloc(nc * 4 + 64, w.live(), w.peak());
+    counter.alloc(64, w.live(), w.peak());
+    MGTA_HIP_CHECK(hipMemsetAsync(owner.p, 0, (size_t)g.size * 8 + 64, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(marked.p, 0, (g.n_lines + 1) * 8, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 64, w.st));
+    uint64_t round = 0;
+    pop_in_order(w, cand, nc, max_len, scratch, owner, marked, status, round, n_rounds);
+    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), nc, 1u, flag.as<uint32_t>(),
+                       counter.as<unsigned long long>());
+    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), nc, 2u, flag.as<uint32_t>(),
+                       (unsigned long long *)nullptr);
+    const uint64_t na = compact_list(w, cand, flag, nc, again);
+    if (na) {
+        pop_in_order(w, again, na, max_len, scratch, owner, marked, status, round, n_rounds);
+        hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), na, 1u, flag.as<uint32_t>(),
+                           counter.as<unsigned long long>());
+    }
+    return read_u64(w, counter.p);
+}
+
+struct Contigs {
+    std::vector<ContigMeta> meta;
+    std::vector<char> text;
+    int64_t n_paths = 0, n_sweeps = 0;
+};
+
+static void unitigs(Work &w, int min_contig, Contigs &out) {
+    const GraphDev &g = w.d.g;
+    DevBuf ends, rec, head, state, undecided, emit, emit_len, idx, off, tmp, meta, text;
+    const uint64_t n64 = edges_where(w, PredPathEnd{}, ends);
+    if (n64 >= 0x7FFFFFFFull) { set_error("mgta_denovo: %llu paths exceed 31-bit path ids", (unsigned long long)n64); throw HipError{MGTA_EUNSUPPORTED}; }
+    const uint32_t n = (uint32_t)n64;
+    out.n_paths = n;
+    if (n == 0) return;
+    rec.alloc((size_t)n * sizeof(PathRec), w.live(), w.peak());
+    head.alloc((size_t)n * 4, w.live(), w.peak());
+    state.alloc((size_t)n * 4, w.live(), w.peak());
+    undecided.alloc(64, w.live(), w.peak());
+    MGTA_HIP_CHECK(hipMemsetAsync(head.p, 0xFF, (size_t)n * 4, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(state.p, 0, (size_t)n * 4, w.st));
+    hipLaunchKernelGGL(unitig_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), head.as<int32_t>());
+    for (;;) {
+        MGTA_HIP_CHECK(hipMemsetAsync(undecided.p, 0, 4, w.st));
+        hipLaunchKernelGGL(unitig_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, w.st, rec.as<PathRec>(), head.as<int32_t>(), n, state.as<uint32_t>(),
+                           undecided.as<uint32_t>());
+        ++out.n_sweeps;
+        uint32_t left = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&left, undecided.p, 4, hipMemcpyDeviceToHost, w.st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+        if (left == 0) break;
+    }
+    emit.alloc((size_t)n * 4, w.live(), w.peak());
+    emit_len.alloc((size_t)n * 4, w.live(), w.peak());
+    idx.alloc((size_t)n * 8, w.live(), w.peak());
+    off.alloc((size_t)n * 8, w.live(), w.peak());
+    tmp.alloc(scan_tmp_elems(n) * 8, w.live(), w.peak());
+    hipLaunchKernelGGL(unitig_decide_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), head.as<int32_t>(), state.as<uint32_t>(), n, min_contig,
+                       emit.as<uint32_t>(), emit_len.as<uint32_t>());
+    exclusive_scan_u32(w.st, emit.as<uint32_t>(), n, idx.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
+    const uint64_t n_contigs = read_u64(w, w.total.p);
+    exclusive_scan_u32(w.st, emit_len.as<uint32_t>(), n, off.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
+    const uint64_t n_chars = read_u64(w, w.total.p);
+    if (n_contigs == 0) return;
+    meta.alloc(n_contigs * sizeof(ContigMeta), w.live(), w.peak());
+    text.alloc(n_chars + 64, w.live(), w.peak());
+    hipLaunchKernelGGL(unitig_emit_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), emit.as<uint32_t>(), idx.as<uint64_t>(), off.as<uint64_t>(), n,
+                       meta.as<ContigMeta>(), text.as<char>());
+    out.meta.resize(n_contigs);
+    out.text.resize(n_chars);
+    MGTA_HIP_CHECK(hipMemcpyAsync(out.meta.data(), meta.p, n_contigs * sizeof(ContigMeta), hipMemcpyDeviceToHost, w.st));
+    MGTA_HIP_CHECK(hipMemcpyAsync(out.text.data(), text.p, n_chars, hipMemcpyDeviceToHost, w.st));
+    MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+}
+
+}  // namespace
+}  // namespace mgta
+
+using namespace mgta;
+
+extern "C" {
+
+int mgta_denovo(mgta_sdbg *graph, int max_tip_len, int no_bubble, int min_contig, char **fasta, uint64_t *fasta_len, mgta_denovo_stats *stats) {
+    if (!graph || !fasta || !fasta_len) { set_error("mgta_denovo: bad argument"); return MGTA_EINVAL; }
+    if (graph->dev.k > kMaxK) { set_error("mgta_denovo: k = %d > %d", graph->dev.k, kMaxK); return MGTA_EUNSUPPORTED; }
+    *fasta = nullptr; *fasta_len = 0;
+    mgta_denovo_stats s;
+    memset(&s, 0, sizeof s);
+    try {
+        mgta_ctx *ctx = graph->ctx;
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        Work w;
+        w.ctx = ctx; w.st = ctx->stream;
+        w.d.g = graph->dev;
+        w.d.rw = graph->lines.as<GLine>();
+        const GraphDev &g = w.d.g;
+        std::string text;
+        if (g.size > 0) {
+            w.mask.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
+            w.count.alloc((g.n_lines + 1) * 4, w.live(), w.peak());
+            w.base.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
+            w.tmp.alloc(scan_tmp_elems(g.n_lines) * 8, w.live(), w.peak());
+            w.total.alloc(64, w.live(), w.peak());
+            hipEvent_t ev[4];
+            for (auto &e : ev) MGTA_HIP_CHECK(hipEventCreate(&e));
+            MGTA_HIP_CHECK(hipEventRecord(ev[0], w.st));
+            if (max_tip_len == -1) max_tip_len = g.k * 2;                           // assembler.cpp:125-127
+            if (max_tip_len > 0) s.n_tips = (int64_t)remove_tips(w, max_tip_len);
+            MGTA_HIP_CHECK(hipEventRecord(ev[1], w.st));
+            if (!no_bubble) s.n_bubbles = (int64_t)pop_bubbles(w, s.n_bubble_rounds, s.n_bubble_candidates);
+            MGTA_HIP_CHECK(hipEventRecord(ev[2], w.st));
+            Contigs c;
+            unitigs(w, min_contig, c);
+            MGTA_HIP_CHECK(hipEventRecord(ev[3], w.st));
+            MGTA_HIP_CHECK(hipEventSynchronize(ev[3]));
+            MGTA_HIP_CHECK(hipEventElapsedTime(&s.ms_tips, ev[0], ev[1]));
+            MGTA_HIP_CHECK(hipEventElapsedTime(&s.ms_bubbles, ev[1], ev[2]));
+            MGTA_HIP_CHECK(hipEventElapsedTime(&s.ms_unitigs, ev[2], ev[3]));
+            for (auto &e : ev) (void)hipEventDestroy(e);
+            s.n_paths = c.n_paths;
+            s.n_unitig_sweeps = c.n_sweeps;
+            s.n_contigs = (int64_t)c.meta.size();
+            text.reserve(c.text.size() + c.meta.size() * 64);
+            char head[160];
+            long long id = 0;
+            for (const ContigMeta &m : c.meta) {                                      // WriteContig, unitig_graph.cpp:134-150
+                ++id;
+                const double multi = std::min(65535.0, (double)m.depth / (double)m.length);
+                int hl = snprintf(head, sizeof head, ">k%d_%lld flag=%d multi=%.4lf len=%d\n", g.k, id, m.flag, multi, (int)m.len);
+                text.append(head, (size_t)hl);
+                text.append(c.text.data() + m.offset, m.len);
+                text.push_back('\n');
+                s.total_len += m.len;
+            }
+        }
+        char *buf = (char *)malloc(text.size() + 1);
+        if (!buf) { set_error("mgta_denovo: out of host memory"); return MGTA_ENOMEM; }
+        memcpy(buf, text.data(), text.size());
+        buf[text.size()] = 0;
+        *fasta = buf;
+        *fasta_len = text.size();
+        if (stats) *stats = s;
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+void mgta_host_free(void *p) { free(p); }
+
+}  // extern "C"

@@ -94,6 +94,39 @@ def make_metagenome(n_reads: int, read_len: int = 150, gene_specs=(("rplB", 277)
     return Metagenome(reads=reads, genes=genes, gene_pos=gene_pos, genome_len=genome_len)
 
 
+def make_strain_mix(seed: int, n_genomes: int = 3, genome_len: int = 3000, read_len: int = 100, cov: int = 20, snp_every: int = 150,
+                    err: float = 0.004) -> list[np.ndarray]:
+    """reads of n_genomes random genomes, each sequenced together with a second strain (SNPs, a few 1-base indels) at the same depth:
+    bubbles whose branches tie in multiplicity, plus the tips and bubbles of substitution errors (the `denovo` test input)"""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for _ in range(n_genomes):
+        g = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+        s = g.copy()
+        grid = np.arange(snp_every // 2, genome_len - 50, snp_every)
+        pos = grid + rng.integers(-20, 20, size=grid.size)
+        s[pos] = (s[pos] + rng.integers(1, 4, size=pos.size, dtype=np.uint8)) & 3
+        s = list(s)
+        for p in sorted(rng.integers(200, genome_len - 200, size=3), reverse=True):
+            if rng.random() < 0.5:
+                del s[p]
+            else:
+                s.insert(p, int(rng.integers(0, 4)))
+        seqs += [g, np.array(s, dtype=np.uint8)]
+    reads = []
+    for g in seqs:
+        n = cov * len(g) // read_len
+        for p in rng.integers(0, len(g) - read_len + 1, size=n):
+            r = g[p:p + read_len].copy()
+            e = rng.random(read_len) < err
+            r[e] = (r[e] + rng.integers(1, 4, size=int(e.sum()), dtype=np.uint8)) & 3
+            if rng.random() < 0.5:
+                r = 3 - r[::-1]
+            reads.append(r.astype(np.uint8))
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
 # ----------------------------------------------------------------------------------------------
 # 2-bit packing (A0 C1 G2 T3, base j of a word at bits 30-2j: sequence_package.h:126-129)
 # ----------------------------------------------------------------------------------------------

@@ -8,34 +8,7 @@ from oracle import oracle
 REF = os.path.join("oracle", "_ref", "megagta")
 
 
-def strain_reads(seed, n_genomes=3, genome_len=3000, read_len=100, cov=20, snp_every=150, err=0.004):
-    """every genome comes with a second strain (SNPs, a few short indels) at the same depth: bubbles with tied branches, plus error tips / bubbles"""
-    rng = np.random.default_rng(seed)
-    seqs = []
-    for _ in range(n_genomes):
-        g = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
-        s = g.copy()
-        pos = np.arange(snp_every // 2, genome_len - 50, snp_every) + rng.integers(-20, 20, size=len(range(snp_every // 2, genome_len - 50, snp_every)))
-        s[pos] = (s[pos] + rng.integers(1, 4, size=pos.size, dtype=np.uint8)) & 3
-        s = list(s)
-        for p in sorted(rng.integers(200, genome_len - 200, size=3), reverse=True):
-            if rng.random() < 0.5:
-                del s[p]
-            else:
-                s.insert(p, int(rng.integers(0, 4)))
-        seqs += [g, np.array(s, dtype=np.uint8)]
-    reads = []
-    for g in seqs:
-        n = cov * len(g) // read_len
-        for p in rng.integers(0, len(g) - read_len + 1, size=n):
-            r = g[p:p + read_len].copy()
-            e = rng.random(read_len) < err
-            r[e] = (r[e] + rng.integers(1, 4, size=int(e.sum()), dtype=np.uint8)) & 3
-            if rng.random() < 0.5:
-                r = 3 - r[::-1]
-            reads.append(r)
-    order = rng.permutation(len(reads))
-    return [reads[i] for i in order]
+from megagta_amd.synth import make_strain_mix as strain_reads
 
 
 def write_fasta(reads, path):
