@@ -127,6 +127,9 @@ int64_t mgta_sdbg_size(const mgta_sdbg *);
  * outdeg[i] = -1 for an invalid edge.  out4 = n x 4 int64 (unused slots -1). Host pointers. */
 int mgta_sdbg_outgoing(mgta_sdbg *, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg);
 /* batched IndexBinarySearchEdge over (k+1)-symbol strings (symbols 1..4) [succinct_dbg.cpp:427-549]. */
+/* the validity bits as they are now (SuccinctDBG::invalid_, succinct_dbg.h:117-131): bit e of words[e / 64]; ceil(size / 64) words.
+ * Set for tips and $ edges after a load, and for everything `mgta_denovo` removed. */
+int mgta_sdbg_invalid_bits(mgta_sdbg *, uint64_t *words);
 int mgta_sdbg_index_edges(mgta_sdbg *, const uint8_t *seqs /* n x (k+1) */, int64_t n, int64_t *edge_ids);
 
 /* ------------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ SYMBOLS = {
                                  C.c_int, EDGE_SINK, C.c_void_p, C.POINTER(BuildStats)]),
     "mgta_findstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgta_host_free": (None, [C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

@@ -163,6 +163,12 @@ class Graph:
         check(self.ctx._L.mgta_sdbg_index_edges(self.h, seqs.ctypes.data, len(kmers), ids.ctypes.data), "mgta_sdbg_index_edges")
         return ids
 
+    def invalid_bits(self) -> np.ndarray:
+        """the validity bits as they are now (bit e of word e // 64 set = edge e is not part of the graph)"""
+        out = np.zeros((self.size + 63) // 64, dtype=np.uint64)
+        check(self.ctx._L.mgta_sdbg_invalid_bits(self.h, out.ctypes.data), "mgta_sdbg_invalid_bits")
+        return out
+
     def denovo(self, max_tip_len: int = 150, no_bubble: bool = False, min_contig: int = 0) -> tuple[str, dict]:
         """`megagta denovo` (main_assemble, assembler.cpp:98-167): tips, bubbles, unitigs -> (text of PREFIX.contigs.fa, stats).
         The result is the reference's one-thread output.  CONSUMES the validity bits of this graph."""

@@ -681,6 +681,17 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
     tmp.alloc(scan_tmp_elems(n) * 8, w.live(), w.peak());
     hipLaunchKernelGGL(unitig_decide_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), head.as<int32_t>(), state.as<uint32_t>(), n, min_contig,
                        emit.as<uint32_t>(), emit_len.as<uint32_t>());
+    if (getenv("MGTA_DENOVO_DEBUG")) {      // the path table, for comparing with the oracle's model of this step
+        std::vector<PathRec> h(n);
+        std::vector<uint32_t> hs(n), he(n);
+        MGTA_HIP_CHECK(hipMemcpy(h.data(), rec.p, (size_t)n * sizeof(PathRec), hipMemcpyDeviceToHost));
+        MGTA_HIP_CHECK(hipMemcpy(hs.data(), state.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        MGTA_HIP_CHECK(hipMemcpy(he.data(), emit.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "device: %u paths\n", n);
+        for (uint32_t i = 0; i < n; ++i)
+            fprintf(stderr, "device p=%u end=%lld start=%lld len=%u rc=%lld target=%d dist=%u state=%u emit=%u\n", i, (long long)h[i].end, (long long)h[i].start,
+                    h[i].length, (long long)h[i].rc_start, h[i].target, h[i].dist, hs[i], he[i]);
+    }
     exclusive_scan_u32(w.st, emit.as<uint32_t>(), n, idx.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
     const uint64_t n_contigs = read_u64(w, w.total.p);
     exclusive_scan_u32(w.st, emit_len.as<uint32_t>(), n, off.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());

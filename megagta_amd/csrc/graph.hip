@@ -75,13 +75,15 @@ __global__ __launch_bounds__(256) void graph_rank_kernel(GLine *lines, uint64_t 
     }
 }
 
-// G4: forward hints (needs rank_f): line of Select(rank_f[a] + #a before this line)
+// G4: forward hints (needs rank_f): line of Select(rank_f[a] + #a before this line - 1).  One rank early on purpose: an edge with
+// W = a + 4 at the start of the line, before any plain a, forwards to the target of the last plain a of an EARLIER line (Forward counts
+// plain symbols only, succinct_dbg.h:155-164), and the look-up only ever walks forwards from the hint.
 __global__ __launch_bounds__(256) void graph_hint_kernel(GraphDev g, GLine *lines) {
     uint64_t li = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (li >= g.n_lines) return;
 #pragma unroll
     for (int a = 1; a <= 4; ++a) {
-        int64_t r0 = g.rank_f[a] + (int64_t)lines[li].rank_w[a - 1];
+        int64_t r0 = g.rank_f[a] + (int64_t)lines[li].rank_w[a - 1] - 1;
         uint64_t h = g.n_lines - 1;
         if (r0 < g.total_last) {
             if (r0 < 0) r0 = 0;
@@ -117,6 +119,11 @@ __global__ __launch_bounds__(64) void graph_index_kernel(GraphDev g, const uint8
 }  // namespace mgta
 
 using namespace mgta;
+
+__global__ __launch_bounds__(256) void graph_invalid_kernel(const GLine *lines, uint64_t n_lines, uint64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_lines) out[i] = lines[i].invalid;
+}
 
 extern "C" {
 
@@ -247,6 +254,22 @@ int mgta_sdbg_outgoing(mgta_sdbg *g, const int64_t *edges, int64_t n, int64_t *o
                            d_o.as<int64_t>(), d_d.as<int8_t>());
         MGTA_HIP_CHECK(hipMemcpyAsync(out4, d_o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
         MGTA_HIP_CHECK(hipMemcpyAsync(outdeg, d_d.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_sdbg_invalid_bits(mgta_sdbg *g, uint64_t *words) {
+    if (!g || !words) { set_error("mgta_sdbg_invalid_bits: bad argument"); return MGTA_EINVAL; }
+    if (g->dev.size == 0) return MGTA_OK;
+    try {
+        mgta_ctx *ctx = g->ctx;
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        const uint64_t n = g->dev.n_lines;
+        DevBuf d;
+        d.alloc(n * 8);
+        hipLaunchKernelGGL(graph_invalid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g->dev.lines, n, d.as<uint64_t>());
+        MGTA_HIP_CHECK(hipMemcpyAsync(words, d.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }

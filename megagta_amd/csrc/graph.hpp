@@ -22,8 +22,9 @@ struct alignas(128) GLine {
     uint64_t rank_last;   // ones of `last` before this line
     uint64_t rank_tip;    // tips before this line
     uint64_t rank_w[4];   // occurrences of W == a (a = 1..4, plain symbols only) before this line
-    uint32_t fwd_hint[4]; // line where Forward of the first W == a edge at/after this line lands (a = 1..4): Forward(e) needs
-                          // no select-sample lookup, it starts from this hint and advances at most a line or two
+    uint32_t fwd_hint[4]; // line where Forward of the last W == a edge BEFORE this line lands (a = 1..4): Forward(e) of any edge of
+                          // this line (also an a + 4 edge that precedes the line's first plain a) needs no select-sample
+                          // lookup, it starts from this hint and advances at most a line or two
 };
 static_assert(sizeof(GLine) == 128, "one line per 64 edges");
 

@@ -374,16 +374,76 @@ static int main_findstart(int argc, char **argv) {
     return 0;
 }
 
+// ---- denovo: main_assemble (assembler.cpp:60-167) --------------------------------------------------------------------------------
+static int main_denovo(int argc, char **argv) {
+    RssLine rss;
+    std::string sdbg_name, out_prefix = "out";
+    int max_tip_len = -1, no_bubble = 0, min_contig = 0;
+    static struct option opts[] = {{"sdbg_name", required_argument, 0, 's'}, {"output_prefix", required_argument, 0, 'o'},
+                                   {"num_cpu_threads", required_argument, 0, 't'}, {"max_tip_len", required_argument, 0, 1},
+                                   {"no_bubble", no_argument, 0, 2}, {"min_standalone", required_argument, 0, 3},
+                                   {"min_contig", required_argument, 0, 4}, {0, 0, 0, 0}};
+    optind = 1;
+    int ch;
+    bool bad = false;
+    while ((ch = getopt_long(argc, argv, "s:o:t:", opts, nullptr)) != -1) {
+        switch (ch) {
+        case 's': sdbg_name = optarg; break;
+        case 'o': out_prefix = optarg; break;
+        case 't': break;                      // threads: the device decides; the result is the reference's one-thread result
+        case 1: max_tip_len = atoi(optarg); break;
+        case 2: no_bubble = 1; break;
+        case 3: break;                        // min_standalone is parsed and never used by the reference either (assembly_algorithms.cpp:92,128)
+        case 4: min_contig = atoi(optarg); break;
+        default: bad = true;
+        }
+    }
+    if (bad || sdbg_name.empty()) {
+        fprintf(stderr, "%s\nUsage: %s -s sdbg_name -o output_prefix\n", bad ? "unknown option" : "no succinct de Bruijn graph name!", argv[0]);
+        return 1;
+    }
+    double t0 = now_s();
+    EdgeStream s;
+    read_sdbg(sdbg_name.c_str(), s);
+    mgta_ctx *ctx = mgta_ctx_create(0);
+    if (!ctx) die("%s", mgta_last_error());
+    mgta_sdbg *g = nullptr;
+    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
+                       s.words_per_tip, &g) != MGTA_OK)
+        die("mgta_sdbg_load: %s", mgta_last_error());
+    logf("Number of Edges: %lld; K value: %d (load %.3f s)", (long long)s.recs.size(), s.k, now_s() - t0);
+    char *fasta = nullptr;
+    uint64_t len = 0;
+    mgta_denovo_stats st;
+    if (mgta_denovo(g, max_tip_len, no_bubble, min_contig, &fasta, &len, &st) != MGTA_OK) die("mgta_denovo: %s", mgta_last_error());
+    logf("Tips removed: %lld (%.1f ms); bubbles removed: %lld of %lld candidates in %lld rounds (%.1f ms); %lld simple paths, %lld contigs, "
+         "total length %lld (%.1f ms)", (long long)st.n_tips, st.ms_tips, (long long)st.n_bubbles, (long long)st.n_bubble_candidates,
+         (long long)st.n_bubble_rounds, st.ms_bubbles, (long long)st.n_paths, (long long)st.n_contigs, (long long)st.total_len, st.ms_unitigs);
+    FILE *f = fopen((out_prefix + ".contigs.fa").c_str(), "w");
+    if (!f) die("cannot write %s.contigs.fa", out_prefix.c_str());
+    if (len && fwrite(fasta, 1, len, f) != len) die("short write to %s.contigs.fa", out_prefix.c_str());
+    fclose(f);
+    f = fopen((out_prefix + ".contigs.fa.info").c_str(), "w");
+    if (!f) die("cannot write %s.contigs.fa.info", out_prefix.c_str());
+    fprintf(f, "%lld %lld\n", (long long)st.n_contigs, (long long)st.total_len);        // assembler.cpp:162
+    fclose(f);
+    mgta_host_free(fasta);
+    mgta_sdbg_free(g);
+    mgta_ctx_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs on the MI355X hot path:\n        buildgraph    build succinct de Bruijn graph\n"
-                        "        search        HMM-guided search of gene contigs\n        findstart     find starting kmers of the search\n        dumpversion   dump version\n", argv[0]);
+                        "        denovo        tips, bubbles, contigs of an intermediate k\n        search        HMM-guided search of gene contigs\n        findstart     find starting kmers of the search\n        dumpversion   dump version\n", argv[0]);
         return 1;
     }
     std::string sub = argv[1];
     if (sub == "buildgraph") return main_buildgraph(argc - 1, argv + 1);
     if (sub == "search") return main_search(argc - 1, argv + 1);
     if (sub == "findstart") return main_findstart(argc - 1, argv + 1);
+    if (sub == "denovo") return main_denovo(argc - 1, argv + 1);
     if (sub == "filterbylen") return main_filterbylen(argc - 1, argv + 1);
     if (sub == "translate") return main_translate(argc - 1, argv + 1);
     if (sub == "buildlib") {                                             // build_read_lib.cpp:8-20 (host only: file formats, no kernel)
@@ -393,6 +453,6 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
-    fprintf(stderr, "sub-command '%s' is not built here (buildlib, buildgraph, findstart, search, filterbylen, translate are): run it with the reference's megagta binary\n", sub.c_str());
+    fprintf(stderr, "sub-command '%s' is not built here (buildlib, buildgraph, denovo, findstart, search, filterbylen, translate are): run it with the reference's megagta binary\n", sub.c_str());
     return 1;
 }

@@ -7,10 +7,9 @@ Drop-in surface kept (reference src/megagta.py): options `-r/-1/-2/--12 -g -k -c
 `k<K>/<K>.*`, `contigs/<gene>/{nucl,prot}_merged.fasta`, k list decremented by one for the graph
 (:815-816), one child process per step with stderr relayed into the log, first non-zero exit aborts.
 
-The two sub-commands on the accelerated path, `buildgraph` and `search`, run from THIS package's
-`bin/megagta` (C++ host + libmegagta_hip.so), and so do `findstart` and the host-only `buildlib`, `filterbylen`, `translate`: a
-single-k run needs nothing else.  `denovo` (between the k values of a multi-k run) is outside the path and is run from the binary
-given by `--ref-bin` (or $MEGAGTA_REF_BIN): the stock MegaGTA executable.
+Every sub-command runs from THIS package's `bin/megagta` (C++ host + libmegagta_hip.so): `buildgraph`, `denovo`, `findstart`, `search`
+on the device, `buildlib`, `filterbylen`, `translate` on the host.  `--ref-bin` / $MEGAGTA_REF_BIN (the stock MegaGTA executable) is
+kept for steps a future reference version may add; nothing needs it today.
 """
 from __future__ import annotations
 
@@ -270,7 +269,7 @@ def build_graph(k, assist):
 def assemble(k):
     if should_run():
         nxt = opt.k_list[opt.k_list.index(k) + 1]
-        run_step([need_ref("denovo"), "denovo", "-s", graph_prefix(k), "-o", graph_prefix(k), "-t", str(opt.num_cpu_threads),
+        run_step([opt.bin, "denovo", "-s", graph_prefix(k), "-o", graph_prefix(k), "-t", str(opt.num_cpu_threads),
                   "--min_standalone", "400", "--max_tip_len", str(opt.max_tip_len), "--min_contig", str(nxt + 1)],
                  "De novo assembling contigs from SdBG for k = %d" % k, stdout=subprocess.PIPE)
     write_cp()

@@ -95,13 +95,23 @@ def make_metagenome(n_reads: int, read_len: int = 150, gene_specs=(("rplB", 277)
 
 
 def make_strain_mix(seed: int, n_genomes: int = 3, genome_len: int = 3000, read_len: int = 100, cov: int = 20, snp_every: int = 150,
-                    err: float = 0.004) -> list[np.ndarray]:
+                    err: float = 0.004, tricky: bool = False) -> list[np.ndarray]:
     """reads of n_genomes random genomes, each sequenced together with a second strain (SNPs, a few 1-base indels) at the same depth:
     bubbles whose branches tie in multiplicity, plus the tips and bubbles of substitution errors (the `denovo` test input)"""
     rng = np.random.default_rng(seed)
     seqs = []
     for _ in range(n_genomes):
         g = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+        if tricky:      # hairpins (a stretch followed by its reverse complement), tandem repeats, a stretch shared between genomes
+            for _ in range(3):
+                p, n = int(rng.integers(100, genome_len - 400)), int(rng.integers(20, 120))
+                g[p + n:p + 2 * n] = 3 - g[p:p + n][::-1]
+            for _ in range(2):
+                p, u, c = int(rng.integers(100, genome_len - 400)), int(rng.integers(5, 40)), int(rng.integers(2, 6))
+                g[p:p + u * c] = np.tile(g[p:p + u], c)
+            if seqs:
+                p, n = int(rng.integers(100, genome_len - 400)), int(rng.integers(60, 300))
+                g[p:p + n] = seqs[0][p:p + n]
         s = g.copy()
         grid = np.arange(snp_every // 2, genome_len - 50, snp_every)
         pos = grid + rng.integers(-20, 20, size=grid.size)

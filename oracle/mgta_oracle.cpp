@@ -1278,7 +1278,7 @@ std::string path_label(const Graph &g, int64_t start, int64_t end, int length) {
     return s;
 }
 
-std::vector<Contig> unitigs(const Graph &g, int min_contig) {   // UnitigGraph::InitFromSdBG with a file, unitig_graph.cpp:208-303
+std::vector<Contig> unitigs(const Graph &g, int min_contig, bool verbose = false) {   // UnitigGraph::InitFromSdBG with a file, unitig_graph.cpp:208-303
     std::vector<Contig> out;
     Bits marked;
     marked.reset(g.size);
@@ -1307,11 +1307,89 @@ std::vector<Contig> unitigs(const Graph &g, int min_contig) {   // UnitigGraph::
         if (!add) continue;
         std::string label = path_label(g, cur, e, (int)length);
         if ((int)label.size() < min_contig) continue;
+        if (verbose) fprintf(stderr, "seq end=%lld start=%lld len=%lld rc=%lld\n", (long long)e, (long long)cur, (long long)length, (long long)rc_start);
         int flag = (edge_indegree(g, cur) == 0 && edge_outdegree(g, e) == 0) ? 1 : 0;     // contig_flag::kIsolated
         double multi = std::min(65535.0, (double)depth / (double)length);
         std::string rc(label.rbegin(), label.rend());
         for (auto &c : rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
         out.push_back(Contig{flag, multi, label < rc ? label : rc});
+    }
+    return out;
+}
+
+// The data-parallel formulation the device uses for the unitig step (denovo.hip), restated on the host so that it can be checked against
+// the sequential loop above without a GPU: tests only.
+std::vector<Contig> unitigs_claim_model(const Graph &g, int min_contig, bool verbose) {
+    struct Rec { int64_t end, start, rc_start, depth; int64_t length; int target; int64_t dist; };
+    std::vector<int64_t> ends;
+    for (int64_t e = 0; e < g.size; ++e)
+        if (g.valid(e) && next_simple(g, e) == -1) ends.push_back(e);
+    int n = (int)ends.size();
+    std::vector<Rec> rec((size_t)n);
+    std::vector<std::vector<int>> claims((size_t)n);
+    for (int p = 0; p < n; ++p) {
+        Rec &r = rec[(size_t)p];
+        r.end = ends[(size_t)p];
+        int64_t cur = r.end, prev;
+        r.depth = multiplicity(g, r.end); r.length = 1;
+        while ((prev = prev_simple(g, cur)) != -1) { cur = prev; r.depth += multiplicity(g, cur); ++r.length; }
+        r.start = cur;
+        r.rc_start = edge_reverse_complement(g, r.end);
+        r.target = -1; r.dist = 0;
+        if (r.rc_start >= 0 && g.valid(r.rc_start)) {
+            int64_t x = r.rc_start, nx, d = 0;
+            bool cyc = false;
+            while ((nx = next_simple(g, x)) != -1) { x = nx; ++d; if (x == r.rc_start) { cyc = true; break; } }
+            if (!cyc) {
+                auto it = std::lower_bound(ends.begin(), ends.end(), x);
+                if (it != ends.end() && *it == x) { r.target = int(it - ends.begin()); r.dist = d; }
+            }
+        }
+        if (r.target >= 0) claims[(size_t)r.target].push_back(p);
+    }
+    if (verbose) {
+        fprintf(stderr, "model: %d paths\n", n);
+        for (int p = 0; p < n; ++p) fprintf(stderr, "mrec p=%d end=%lld start=%lld len=%lld rc=%lld target=%d dist=%lld\n", p, (long long)rec[(size_t)p].end,
+                                            (long long)rec[(size_t)p].start, (long long)rec[(size_t)p].length, (long long)rec[(size_t)p].rc_start, rec[(size_t)p].target, (long long)rec[(size_t)p].dist);
+    }
+    std::vector<int> state((size_t)n, 0);
+    for (bool again = true; again;) {
+        again = false;
+        for (int p = 0; p < n; ++p) {
+            if (state[(size_t)p]) continue;
+            bool pending = false, skipped = false;
+            for (int q : claims[(size_t)p]) {
+                if (q == p || rec[(size_t)q].end >= rec[(size_t)p].end) continue;
+                if (state[(size_t)q] == 1) { skipped = true; break; }
+                if (state[(size_t)q] == 0) pending = true;
+            }
+            if (skipped) state[(size_t)p] = 2; else if (!pending) state[(size_t)p] = 1; else again = true;
+        }
+    }
+    std::vector<Contig> out;
+    for (int p = 0; p < n; ++p) {
+        if (state[(size_t)p] != 1) continue;
+        const Rec &r = rec[(size_t)p];
+        bool add = true;
+        if (r.target >= 0) {
+            int t = r.target;
+            bool locked = t == p || (state[(size_t)t] == 1 && rec[(size_t)t].end < r.end);
+            for (int q : claims[(size_t)t])
+                if (q != p && state[(size_t)q] == 1 && rec[(size_t)q].end < r.end && rec[(size_t)q].dist > r.dist) locked = true;
+            if (locked) {
+                int64_t rc_end = edge_reverse_complement(g, r.start);
+                if (std::max(r.end, r.start) < std::max(r.rc_start, rc_end)) add = false;
+            }
+        }
+        if (!add) continue;
+        std::string label = path_label(g, r.start, r.end, (int)r.length);
+        if ((int)label.size() < min_contig) continue;
+        int flag = (edge_indegree(g, r.start) == 0 && edge_outdegree(g, r.end) == 0) ? 1 : 0;
+        std::string rc(label.rbegin(), label.rend());
+        for (auto &c : rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        if (verbose) fprintf(stderr, "model p=%d end=%lld start=%lld len=%lld rc=%lld target=%d dist=%lld\n", p, (long long)r.end, (long long)r.start,
+                             (long long)r.length, (long long)r.rc_start, r.target, (long long)r.dist);
+        out.push_back(Contig{flag, std::min(65535.0, (double)r.depth / (double)r.length), label < rc ? label : rc});
     }
     return out;
 }
@@ -1522,6 +1600,16 @@ char *orc_denovo(orc_graph *g, int max_tip_len, int no_bubble, int min_contig, i
     memcpy(r, text.c_str(), text.size() + 1);
     return r;
 }
+// tests: the device's claim formulation of the unitig step vs the sequential loop on the graph as it is now; returns the number of
+// differing contigs (0 = identical lists)
+int64_t orc_denovo_unitig_model_check(orc_graph *g, int min_contig, int verbose) {
+    auto a = denovo::unitigs(*g, min_contig, verbose != 0), b = denovo::unitigs_claim_model(*g, min_contig, verbose != 0);
+    int64_t diff = (int64_t)a.size() > (int64_t)b.size() ? (int64_t)(a.size() - b.size()) : (int64_t)(b.size() - a.size());
+    for (size_t i = 0; i < std::min(a.size(), b.size()); ++i) diff += a[i].seq != b[i].seq || a[i].flag != b[i].flag || a[i].multi != b[i].multi;
+    return diff;
+}
+int64_t orc_denovo_remove_tips(orc_graph *g, int max_tip_len) { return denovo::remove_tips(*g, max_tip_len == -1 ? g->k * 2 : max_tip_len); }
+int64_t orc_denovo_pop_bubbles(orc_graph *g) { return denovo::pop_bubbles(*g); }
 void orc_free(void *p) { free(p); }
 const uint64_t *orc_graph_invalid_now(const orc_graph *g) { return g->invalid.data(); }
 

@@ -57,6 +57,7 @@ def lib():
         "orc_forward": (i64, [vp, i64]), "orc_backward": (i64, [vp, i64]),
         "orc_outgoing": (i32, [vp, i64, vp]), "orc_incoming": (i32, [vp, i64, vp]),
         "orc_label": (i32, [vp, i64, vp]), "orc_index_edge": (i64, [vp, vp]),
+        "orc_denovo_unitig_model_check": (i64, [vp, i32, i32]), "orc_denovo_remove_tips": (i64, [vp, i32]), "orc_denovo_pop_bubbles": (i64, [vp]),
         "orc_denovo": (vp, [vp, i32, i32, i32, vp, vp, vp, vp]), "orc_free": (None, [vp]), "orc_graph_invalid_now": (vp, [vp]),
         "orc_hmm_parse": (vp, [C.c_char_p]), "orc_hmm_free": (None, [vp]),
         "orc_hmm_M": (i32, [vp]), "orc_hmm_A": (i32, [vp]),

@@ -35,8 +35,10 @@ if __name__ == "__main__":
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 29
     ng = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     mc = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    tricky = len(sys.argv) > 5 and sys.argv[5] == "tricky"
+    snp = int(sys.argv[6]) if len(sys.argv) > 6 else 150
     w = tempfile.mkdtemp(dir="/tmp/dn")
-    write_fasta(strain_reads(seed, ng), os.path.join(w, "reads.fa"))
+    write_fasta(strain_reads(seed, ng, tricky=tricky, snp_every=snp), os.path.join(w, "reads.fa"))
     ref, info, log = reference_run(w, k, mc, min_contig=k + 2)
     g = oracle.Graph(oracle.Stream.read(os.path.join(w, "g")))
     mine, st = g.denovo(150, False, k + 2)

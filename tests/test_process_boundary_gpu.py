@@ -145,14 +145,14 @@ def test_findstart_binary_matches_reference_output(golden_dir, k, with_contigs):
 
 
 def test_multi_k_driver_run_stagewise_vs_reference(toy_inputs, oracle):
-    """`megagta.py -k 30,36,45`: every step ours except `denovo` (reference binary).  Each stage is checked against the reference binary fed
-    with the same inputs: the three graphs (two of them built with the previous k's contigs as assist sequences), the seeds found in reads
-    plus contigs, and the last step's filters."""
+    """`megagta.py -k 30,36,45`, every step ours.  Each stage is checked against the reference binary fed with the same inputs: the three
+    graphs (two of them built with the previous k's contigs as assist sequences), the contigs of the two intermediate k (`denovo`: the
+    reference run with one thread, byte for byte), the seeds found in reads plus contigs, and the last step's filters."""
     _need()
     d = toy_inputs
     out = d / "out_mk"
     r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "30,36,45", "-o", str(out),
-                        "-t", "4", "--min-contig-len", "150", "--ref-bin", REF], capture_output=True, text=True)
+                        "-t", "4", "--min-contig-len", "150"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
     run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
     lib = str(out / "tmp" / "reads.lib")
@@ -167,6 +167,12 @@ def test_multi_k_driver_run_stagewise_vs_reference(toy_inputs, oracle):
         ours, ref = oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges(), oracle.Stream.read(str(d / f"ref_mk_{k}")).edges()
         assert ours.md5() == ref.md5() and ours.records.size > 100000, k
         prev = k
+    for k, nxt in ((29, 35), (35, 44)):
+        run([REF, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(d / f"ref_mk_{k}"), "-t", "1", "--min_standalone", "400", "--max_tip_len", "150",
+             "--min_contig", str(nxt + 1)])
+        assert (out / f"k{k}" / f"{k}.contigs.fa").read_text() == (d / f"ref_mk_{k}.contigs.fa").read_text(), k
+        assert (out / f"k{k}" / f"{k}.contigs.fa.info").read_text() == (d / f"ref_mk_{k}.contigs.fa.info").read_text()
+        assert os.path.getsize(out / f"k{k}" / f"{k}.contigs.fa") > 1000
     faa = (d / "gene_list.txt").read_text().split()[3]
     ref_seeds = run([REF, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")]).stdout.decode().splitlines()
     ours_seeds = (out / "k44" / "44_rplB_starting_kmers.txt").read_text().splitlines()
