@@ -155,19 +155,24 @@ def test_fuzz_navigation_vs_oracle(ctx, oracle, seed):
 
 
 @pytest.mark.gpu
-def test_forward_of_minus_edge_at_line_start(ctx, oracle):
-    """an edge with W = a + 4 at the start of a 64-edge line forwards to the target of the last plain a of an EARLIER line, which can lie in a
-    line before the one the first plain a of its own line points to (found by the denovo parity runs; 74 k edges, every edge checked)"""
+def test_forward_of_minus_edge_before_first_plain_symbol_of_its_line(ctx, oracle):
+    """an edge with W = a + 4 that precedes every plain a of its 64-edge line forwards to the target of the last plain a of an EARLIER line,
+    which can lie in a line before the one the line's own first plain a points to (1 edge in 74 320 here; found by the denovo parity runs).
+    Every edge of the graph is checked."""
     from megagta_amd import api, synth
-    reads = synth.make_strain_mix(906, n_genomes=2, genome_len=3200, read_len=100, snp_every=60)
+    reads = synth.make_strain_mix(906, n_genomes=3, genome_len=2468, read_len=100, snp_every=150)
     packed, start = readlib.pack_for_build(reads)
     st = oracle.Stream.build(packed, start, 44, threads=4)
     og, g = oracle.Graph(st), api.Graph(ctx, st.edges())
     deg, out = g.outgoing(np.arange(g.size))
-    minus_at_start = 0
     w = og.bitvectors()["w"]
+    W = lambda e: (int(w[e >> 4]) >> ((e & 15) * 4)) & 15
+    needed = 0
     for e in range(g.size):
         n, ref = og.outgoing(e)
         assert deg[e] == n and out[e, :max(n, 0)].tolist() == ref, e
-        minus_at_start += (e & 63) == 0 and ((int(w[e >> 4]) >> ((e & 15) * 4)) & 15) > 4
-    assert minus_at_start > 5
+        c = W(e)
+        if c > 4 and not any(W(x) == c - 4 for x in range(e & ~63, e)):
+            nxt = next((x for x in range(e, og.size) if W(x) == c - 4), None)
+            needed += nxt is not None and (og.forward(e) >> 6) < (og.forward(nxt) >> 6)
+    assert needed >= 1
