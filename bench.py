@@ -150,6 +150,7 @@ def main():
     # ---- A* leg: graph + HMMs replicated, seeds dealt round-robin, one all-gather of contigs
     search = None
     findstart_leg = None
+    denovo_leg = None
     if args.seeds > 0:
         import tempfile
         from megagta_amd import hmm as hmmlib
@@ -198,6 +199,13 @@ def main():
                   "expansions_per_step": float(nexp[0]), "ms_per_step": float(nexp[1]) * 1e3, "cache_mode": "cold (every seed independent)",
                   "bytes_per_expansion_algorithmic": 510, "achieved_GBps": float(nexp[0]) * 510 / float(nexp[1]) / 1e9,
                   "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"]}
+        if world == 1:
+            # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits)
+            _, dst = graph.denovo(150, False, k + 2)
+            denovo_leg = {"edges": int(graph.size), "ms_tips": dst["ms_tips"], "ms_bubbles": dst["ms_bubbles"], "ms_unitigs": dst["ms_unitigs"],
+                          "tips": dst["n_tips"], "bubbles": dst["n_bubbles"], "bubble_rounds": dst["n_bubble_rounds"], "contigs": dst["n_contigs"],
+                          "edges_per_s": graph.size / max(1e-9, (dst["ms_tips"] + dst["ms_bubbles"] + dst["ms_unitigs"]) * 1e-3),
+                          "note": "mgta_denovo --max_tip_len 150 on the build leg's graph (one-thread-reference result, computed on the device)"}
 
     if rank == 0:
         s = stats[-1]
@@ -247,6 +255,8 @@ def main():
         if search is not None:
             out["search"] = search
             out["findstart"] = findstart_leg
+            if denovo_leg is not None:
+                out["denovo"] = denovo_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mg.reads, k, args.cpu_sample)
         print(json.dumps(out), flush=True)
