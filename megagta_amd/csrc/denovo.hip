@@ -6,11 +6,13 @@
 // The reference's OpenMP loops race (its 8-thread output differs from its 1-thread output on the same graph); the result reproduced
 // here is the ONE-thread run, byte for byte, and it is computed in parallel:
 //  * Trim marks on a snapshot and deletes afterwards, so every start node is an independent thread.
-//  * PopBubbles is order dependent (a pop changes what the next search sees).  Candidates are taken in windows of ascending edge id;
-//    every candidate of the window runs its search on the current graph and stamps every still-valid edge it looked at with
-//    (round, rank) by atomicMax; a candidate keeps its claim if it still holds all its stamps.  Everything below the FIRST candidate
-//    that lost a stamp has a footprint no lower candidate touches, so those searches see exactly what the sequential loop would
-//    show them: they commit (pop) together, the window restarts at the first loser.  No clearing: a newer round outranks old stamps.
+//  * PopBubbles is order dependent (a pop changes what the next search sees).  Pending candidates are taken in windows of ascending edge
+//    id.  Every candidate of the window stamps, by 64-bit atomicMax of (round, ~rank), every edge its search could EVER read or write
+//    while the graph only loses edges: all edges within max_bubble_len forward steps of its begin edge plus the edges into them (its
+//    "reach").  Then it runs its search on the current graph and commits (pops) iff every still-valid edge the search read carries its
+//    own stamp: no lower pending candidate can reach what it read or writes, now or after any later change, and its own writes stay
+//    outside every lower candidate's reach - so each committed search saw exactly what the sequential loop would have shown it.  The
+//    rest stay pending, in order; the lowest pending candidate always commits.  No clearing: a newer round outranks old stamps.
 //  * Unitigs: the reference walks every maximal simple path back from its end edge in ascending order, locking edges in a bit
 //    vector, then locks the path of the reverse complement forwards from RC(end).  With one thread the locks held inside a path are
 //    always a suffix of it that reaches its end edge, so the whole protocol collapses to: path P (end e) is skipped iff an earlier
@@ -28,7 +30,8 @@ namespace mgta {
 namespace {
 
 constexpr int kMaxBranches = 16;      // kMaxBranchesPerGroup, assembly_algorithms.cpp:248
-constexpr int kBubbleWindowMax = 16384;
+constexpr uint32_t kBubbleWindowMax = 1u << 18;
+constexpr int kReachHash = 4096, kReachMax = 2048, kReachFrontier = 512;   // per-candidate reach search: hash slots, edges, edges per level
 constexpr int kMaxK = 255;
 
 struct Dn {
@@ -332,43 +335,106 @@ __device__ bool bubble_pop(const Dn &d, unsigned long long *marked, const int64_
     return true;
 }
 
-__global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64_t *cand, uint64_t n, int max_len, int64_t *scratch, uint32_t *found) {
+__global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64_t *cand, uint64_t n, int max_len, int64_t *scratch, size_t per, uint32_t *found) {
     const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x, stride = (uint64_t)gridDim.x * 64;
-    int64_t *br = scratch + t * (size_t)kMaxBranches * max_len;
+    int64_t *br = scratch + t * per;
     for (uint64_t i = t; i < n; i += stride) {
         int mult[kMaxBranches], nb = 0, len = 0;
         SinkNone s;
         found[i] = bubble_search(g, cand[i], max_len, br, mult, nb, len, s) ? 1u : 0u;
     }
 }
-__global__ __launch_bounds__(64) void bubble_stamp_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
-                                                          unsigned long long *owner, unsigned long long round) {
+// Every edge a search from `begin` can read or write in ANY graph that has a subset of today's valid edges: the edges within max_len
+// forward steps and the valid edges into them.  Stamped with `key`; false when the region does not fit the scratch (the caller then
+// holds back every higher candidate of the round).
+__device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, unsigned long long *owner, unsigned long long key,
+                                   unsigned long long round, int reach_max) {
+    if (!g_valid(g, begin)) return true;
+    int64_t *hash = scratch, *cur = scratch + kReachHash, *nxt = cur + kReachFrontier;
+    // hash entries carry the round in their top 24 bits: whatever an earlier round or a search left in the scratch reads as empty
+    // (edge ids stay below 2^40), so nothing is cleared
+    const int64_t tag = (int64_t)((round & 0x3FFFFFull) + 1) << 40;
+    auto insert = [&](int64_t e) -> bool {           // true = new
+        uint32_t h = (uint32_t)(((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 52) & (kReachHash - 1);
+        for (;;) {
+            const int64_t v = hash[h];
+            if (v == (tag | e)) return false;
+            if ((v & ~0xFFFFFFFFFFll) != tag) { hash[h] = tag | e; return true; }
+            h = (h + 1) & (kReachHash - 1);
+        }
+    };
+    int n_seen = 1, n_cur = 1;
+    insert(begin);
+    cur[0] = begin;
+    atomicMax(&owner[begin], key);
+    for (int level = 0; level < max_len && n_cur > 0; ++level) {
+        int n_nxt = 0;
+        for (int i = 0; i < n_cur; ++i) {
+            int64_t out[8];
+            const int od = d_outgoing(g, cur[i], out);
+            for (int x = 0; x < od; ++x) {
+                if (!insert(out[x])) continue;
+                if (++n_seen > reach_max || n_nxt >= kReachFrontier) return false;
+                nxt[n_nxt++] = out[x];
+                atomicMax(&owner[out[x]], key);
+                int64_t in[8];
+                const int id = d_incoming(g, out[x], in);
+                for (int y = 0; y < id; ++y) atomicMax(&owner[in[y]], key);
+            }
+        }
+        int64_t *t = cur; cur = nxt; nxt = t;
+        n_cur = n_nxt;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
+                                                          unsigned long long *owner, unsigned long long round, int reach_max, uint32_t *barrier) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
+    if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max)) return;
+    // the region does not fit: nobody above may commit this round (what this one can reach is not known), and it stamps at least what
+    // its search reads today, so that it can still commit itself once nothing below reaches that
+    atomicMin(barrier, i);
     int mult[kMaxBranches], nb = 0, len = 0;
-    SinkStamp s{owner, (round << 32) | (0xFFFFFFFFull - i)};
-    bubble_search(g, cand[i], max_len, scratch + (size_t)i * kMaxBranches * max_len, mult, nb, len, s);
+    SinkStamp s{owner, key};
+    bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
 }
-__global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
-                                                          const unsigned long long *owner, unsigned long long round, uint32_t *first_loser) {
+__global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
+                                                          const unsigned long long *owner, unsigned long long round, uint32_t *ok) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkCheck s{owner, (round << 32) | (0xFFFFFFFFull - i), true};
-    bubble_search(g, cand[i], max_len, scratch + (size_t)i * kMaxBranches * max_len, mult, nb, len, s);
-    if (!s.ok) atomicMin(first_loser, i);
+    bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
+    ok[i] = s.ok ? 1u : 0u;
 }
-// status: 0 = the search fails now, 1 = popped, 2 = Pop undid itself (goes to the second list, assembly_algorithms.cpp:273-277)
-__global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch,
-                                                           unsigned long long *marked, uint32_t *status) {
+// status (by position in the candidate list): 0 = the search fails now, 1 = popped, 2 = Pop undid itself (goes to the second list,
+// assembly_algorithms.cpp:273-277).  keep[i] = 1: still pending after this round.
+__global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *cand, const uint32_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
+                                                           const uint32_t *ok, const uint32_t *barrier, unsigned long long *marked, uint32_t *status,
+                                                           uint32_t *keep, uint32_t *n_done) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    if (!ok[i] || i > *barrier) { keep[i] = 1; return; }
     int mult[kMaxBranches], nb = 0, len = 0;
-    int64_t *br = scratch + (size_t)i * kMaxBranches * max_len;
+    int64_t *br = scratch + (size_t)i * per;
     SinkNone s;
     uint32_t st = 0;
     if (bubble_search(d.g, cand[i], max_len, br, mult, nb, len, s)) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
-    status[i] = st;
+    status[pos[i]] = st;
+    keep[i] = 0;
+    atomicAdd(n_done, 1u);
+}
+__global__ __launch_bounds__(256) void window_fill_kernel(const int64_t *cand, uint64_t from, uint32_t take, uint32_t at, int64_t *win, uint32_t *pos) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < take) { win[at + i] = cand[from + i]; pos[at + i] = (uint32_t)(from + i); }
+}
+__global__ __launch_bounds__(256) void window_keep_kernel(const int64_t *win, const uint32_t *pos, const uint32_t *keep, const uint64_t *base, uint32_t n,
+                                                          int64_t *win2, uint32_t *pos2) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && keep[i]) { win2[base[i]] = win[i]; pos2[base[i]] = pos[i]; }
 }
 __global__ __launch_bounds__(256) void flag_equals_kernel(const uint32_t *status, uint64_t n, uint32_t want, uint32_t *flag, unsigned long long *count) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -576,68 +642,91 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
     return read_u64(w, counter.p);
 }
 
-// the ordered loop `for each candidate: Search, then Pop` (assembly_algorithms.cpp:266-279 and :283-292) in windows
-static void pop_in_order(Work &w, const DevBuf &cand, uint64_t n, int max_len, DevBuf &scratch, DevBuf &owner, DevBuf &marked, DevBuf &status,
-                         uint64_t &round, int64_t &n_rounds) {
+struct BubbleWork {
+    DevBuf scratch, owner, marked, status, win[2], pos[2], ok, keep, base, tmp, small;
+    size_t per = 0;          // int64 of scratch per candidate
+    uint32_t window = 0;
+    int reach_max = kReachMax;
+    uint64_t round = 0;
+};
+
+// the ordered loop `for each candidate: Search, then Pop` (assembly_algorithms.cpp:266-279 and :283-292)
+static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n, int max_len, int64_t &n_rounds) {
     const GraphDev &g = w.d.g;
-    DevBuf first;
-    first.alloc(64, w.live(), w.peak());
-    uint64_t p = 0;
-    uint32_t window = 2048;
-    while (p < n) {
-        const uint32_t m = (uint32_t)std::min<uint64_t>(window, n - p);
-        ++round; ++n_rounds;
-        const int64_t *c = cand.as<int64_t>() + p;
-        MGTA_HIP_CHECK(hipMemsetAsync(first.p, 0xFF, 4, w.st));
-        hipLaunchKernelGGL(bubble_stamp_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, scratch.as<int64_t>(),
-                           owner.as<unsigned long long>(), (unsigned long long)round);
-        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, scratch.as<int64_t>(),
-                           owner.as<unsigned long long>(), (unsigned long long)round, first.as<uint32_t>());
-        uint32_t f = 0;
-        MGTA_HIP_CHECK(hipMemcpyAsync(&f, first.p, 4, hipMemcpyDeviceToHost, w.st));
-        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
-        if (f > m) f = m;
-        if (f == 0) f = 1;        // the lowest candidate holds every stamp it made; never taken
-        hipLaunchKernelGGL(bubble_commit_kernel, dim3((f + 63) / 64), dim3(64), 0, w.st, w.d, c, f, max_len, scratch.as<int64_t>(),
-                           marked.as<unsigned long long>(), status.as<uint32_t>() + p);
-        p += f;
-        window = f == m ? std::min<uint32_t>(kBubbleWindowMax, window * 2) : std::max<uint32_t>(256, std::min<uint32_t>(kBubbleWindowMax, 2 * f));
+    uint64_t p = 0;           // next candidate of the list not yet in a window
+    uint32_t carry = 0;       // pending candidates kept from the previous window (front of win[cur])
+    int cur = 0;
+    uint32_t want = std::min<uint32_t>(4096, b.window);
+    uint32_t *barrier = b.small.as<uint32_t>(), *n_done = b.small.as<uint32_t>() + 1;
+    while (carry > 0 || p < n) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(std::max(want, carry), carry + (n - p)), take = m - carry;
+        if (take) hipLaunchKernelGGL(window_fill_kernel, dim3((take + 255) / 256), dim3(256), 0, w.st, cand.as<int64_t>(), p, take, carry, b.win[cur].as<int64_t>(),
+                                     b.pos[cur].as<uint32_t>());
+        p += take;
+        ++b.round; ++n_rounds;
+        const int64_t *c = b.win[cur].as<int64_t>();
+        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+        MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 8, hipMemcpyHostToDevice, w.st));
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
+                           b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.reach_max, barrier);
+        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
+                           b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.ok.as<uint32_t>());
+        hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint32_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
+                           b.ok.as<uint32_t>(), barrier, b.marked.as<unsigned long long>(), b.status.as<uint32_t>(), b.keep.as<uint32_t>(), n_done);
+        exclusive_scan_u32(w.st, b.keep.as<uint32_t>(), m, b.base.as<uint64_t>(), b.tmp.as<uint64_t>(), w.total.as<uint64_t>());
+        hipLaunchKernelGGL(window_keep_kernel, dim3((m + 255) / 256), dim3(256), 0, w.st, c, b.pos[cur].as<uint32_t>(), b.keep.as<uint32_t>(), b.base.as<uint64_t>(), m,
+                           b.win[cur ^ 1].as<int64_t>(), b.pos[cur ^ 1].as<uint32_t>());
+        carry = (uint32_t)read_u64(w, w.total.p);
+        cur ^= 1;
+        const uint32_t done = m - carry;
+        if (done == 0) { set_error("mgta_denovo: a bubble round committed nothing"); throw HipError{MGTA_EINTERNAL}; }   // the lowest always commits
+        want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * done));     // a round that commits few (a region that does not fit the reach scratch) shrinks the next
     }
-    MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
 }
 
 static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {   // assembly_algorithms.cpp:245-301
     const GraphDev &g = w.d.g;
     const int max_len = g.k * 2 + 4;
-    DevBuf branching, found, cand, scratch, owner, marked, status, flag, again, counter;
+    BubbleWork b;
+    DevBuf branching, found, cand, flag, again, counter;
     uint64_t nb = edges_where(w, PredBranching{}, branching);
-    const uint64_t per = (uint64_t)kMaxBranches * max_len;
-    scratch.alloc((size_t)kBubbleWindowMax * per * 8, w.live(), w.peak());
+    b.per = std::max<size_t>((size_t)kMaxBranches * max_len, (size_t)kReachHash + 2 * kReachFrontier);
+    b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, (6ull << 30) / (b.per * 8)));
+    // test knobs: tiny windows exercise the carry of pending candidates, a tiny reach limit the hold-back of a region that does not fit
+    if (const char *e = getenv("MGTA_DENOVO_WINDOW")) b.window = (uint32_t)std::max(64, atoi(e)) & ~63u;
+    if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));
+    b.scratch.alloc((size_t)b.window * b.per * 8, w.live(), w.peak());
     found.alloc(nb * 4 + 64, w.live(), w.peak());
     if (nb)
-        hipLaunchKernelGGL(bubble_find_kernel, dim3(kBubbleWindowMax / 64), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len,
-                           scratch.as<int64_t>(), found.as<uint32_t>());
+        hipLaunchKernelGGL(bubble_find_kernel, dim3(b.window / 64), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len, b.scratch.as<int64_t>(), b.per,
+                           found.as<uint32_t>());
     const uint64_t nc = compact_list(w, branching, found, nb, cand);
     n_candidates = (int64_t)nc;
     if (nc == 0) return 0;
-    owner.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
-    marked.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
-    status.alloc(nc * 4 + 64, w.live(), w.peak());
+    if (nc >= 0xFFFFFFFFull) { set_error("mgta_denovo: %llu bubble candidates exceed 32-bit positions", (unsigned long long)nc); throw HipError{MGTA_EUNSUPPORTED}; }
+    b.owner.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
+    b.marked.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
+    b.status.alloc(nc * 4 + 64, w.live(), w.peak());
+    for (int i = 0; i < 2; ++i) { b.win[i].alloc((size_t)b.window * 8, w.live(), w.peak()); b.pos[i].alloc((size_t)b.window * 4, w.live(), w.peak()); }
+    b.ok.alloc((size_t)b.window * 4, w.live(), w.peak());
+    b.keep.alloc((size_t)b.window * 4, w.live(), w.peak());
+    b.base.alloc((size_t)b.window * 8, w.live(), w.peak());
+    b.tmp.alloc(scan_tmp_elems(b.window) * 8, w.live(), w.peak());
+    b.small.alloc(64, w.live(), w.peak());
     flag.alloc(nc * 4 + 64, w.live(), w.peak());
     counter.alloc(64, w.live(), w.peak());
-    MGTA_HIP_CHECK(hipMemsetAsync(owner.p, 0, (size_t)g.size * 8 + 64, w.st));
-    MGTA_HIP_CHECK(hipMemsetAsync(marked.p, 0, (g.n_lines + 1) * 8, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(b.owner.p, 0, (size_t)g.size * 8 + 64, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(b.marked.p, 0, (g.n_lines + 1) * 8, w.st));
     MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 64, w.st));
-    uint64_t round = 0;
-    pop_in_order(w, cand, nc, max_len, scratch, owner, marked, status, round, n_rounds);
-    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), nc, 1u, flag.as<uint32_t>(),
+    pop_in_order(w, b, cand, nc, max_len, n_rounds);
+    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, b.status.as<uint32_t>(), nc, 1u, flag.as<uint32_t>(),
                        counter.as<unsigned long long>());
-    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), nc, 2u, flag.as<uint32_t>(),
+    hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, w.st, b.status.as<uint32_t>(), nc, 2u, flag.as<uint32_t>(),
                        (unsigned long long *)nullptr);
     const uint64_t na = compact_list(w, cand, flag, nc, again);
     if (na) {
-        pop_in_order(w, again, na, max_len, scratch, owner, marked, status, round, n_rounds);
-        hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, w.st, status.as<uint32_t>(), na, 1u, flag.as<uint32_t>(),
+        pop_in_order(w, b, again, na, max_len, n_rounds);
+        hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, w.st, b.status.as<uint32_t>(), na, 1u, flag.as<uint32_t>(),
                            counter.as<unsigned long long>());
     }
     return read_u64(w, counter.p);
