@@ -1,4 +1,4 @@
-"""`denovo` at scale against the reference binary on the same graph files: python scripts/bench_denovo.py [n_genomes] [genome_len] [k]
+"""`denovo` at scale against the reference binary on the same graph files: python scripts/bench_denovo.py [n_genomes] [genome_len] [k] [min_count]
 (reads = 2 strains x n_genomes x 20x coverage).  Prints our device times, the reference's wall time with 1 thread and with all cores, and
 whether our contigs equal the reference's one-thread contigs byte for byte."""
 import os, subprocess, sys, tempfile, time
@@ -11,6 +11,7 @@ REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
 ng = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 gl = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 29
+mc = sys.argv[4] if len(sys.argv) > 4 else "2"
 w = tempfile.mkdtemp(dir="/tmp")
 t0 = time.time()
 reads = synth.make_strain_mix(5, n_genomes=ng, genome_len=gl, read_len=100, cov=20, snp_every=120, err=0.003)
@@ -22,7 +23,7 @@ with open(os.path.join(w, "reads.lib"), "w") as f:
 print(f"{len(reads)} reads written in {time.time() - t0:.1f} s", flush=True)
 run = lambda cmd: subprocess.run(cmd, check=True, capture_output=True, text=True)
 run([BIN, "buildlib", os.path.join(w, "reads.lib"), os.path.join(w, "reads.lib")])
-r = run([BIN, "buildgraph", "-k", str(k), "-m", "2", "--host_mem", "64000000000", "--mem_flag", "1", "--num_cpu_threads", "32", "--num_output_threads", "8",
+r = run([BIN, "buildgraph", "-k", str(k), "-m", mc, "--host_mem", "64000000000", "--mem_flag", "1", "--num_cpu_threads", "32", "--num_output_threads", "8",
          "--read_lib_file", os.path.join(w, "reads.lib"), "--output_prefix", os.path.join(w, "g")])
 print([l for l in r.stderr.splitlines() if "device build" in l][-1:], flush=True)
 t0 = time.time()
