@@ -16,8 +16,10 @@
 //  * Unitigs: the reference walks every maximal simple path back from its end edge in ascending order, locking edges in a bit
 //    vector, then locks the path of the reverse complement forwards from RC(end).  With one thread the locks held inside a path are
 //    always a suffix of it that reaches its end edge, so the whole protocol collapses to: path P (end e) is skipped iff an earlier
-//    processed (q < e), not skipped path Q has RC(q) inside P.  That recursion over ascending ids is resolved by a few data-parallel
-//    sweeps; the rarely taken "RC(end) already locked" branch (:243-252) is evaluated from the same claims.
+//    processed (q < e), not skipped path Q has RC(q) inside P.  One serial walk per path notes (path, distance to the end) on every
+//    edge; RC(end) looked up in that table is the claim; the recursion over ascending ids is resolved by a few data-parallel
+//    sweeps; the rarely taken "RC(end) already locked" branch (:243-252) is evaluated from the same claims; labels are written by one
+//    thread per edge.
 //    (PopBubbles keeps the LAST branch on equal multiplicities, which is a different allele on the two strands: the graph is not
 //    strand-symmetric afterwards, so none of this may assume that RC(path) is a path.)
 #include <algorithm>
@@ -453,44 +455,40 @@ struct PathRec {
     int32_t next;         // next claim on the same target
 };
 
-__device__ inline int32_t find_path(const int64_t *ends, uint32_t n, int64_t e) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (ends[mid] < e) lo = mid + 1; else hi = mid;
-    }
-    return lo < n && ends[lo] == e ? (int32_t)lo : -1;
-}
-
-__global__ __launch_bounds__(64) void unitig_walk_kernel(GraphDev g, const int64_t *ends, uint32_t n, PathRec *rec, int32_t *head) {
+// The one serial walk per path: back from its end edge, noting on every edge which path it is on and how far from the end
+// (uint2: path id, edges to the end).  Everything after this is a look-up in that table.
+__global__ __launch_bounds__(64) void unitig_walk_kernel(GraphDev g, const int64_t *ends, uint32_t n, PathRec *rec, uint2 *on_path) {
     const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
     if (pid >= n) return;
     const int64_t e = ends[pid];
     int64_t cur = e, p;
     int64_t depth = multiplicity(g, e);
     uint32_t length = 1;
+    on_path[e] = make_uint2(pid, 0u);
     while ((p = prev_simple(g, cur)) != -1) {       // unitig_graph.cpp:229-239 (never a cycle: e has no simple successor)
         cur = p;
+        on_path[cur] = make_uint2(pid, length);
         depth += multiplicity(g, cur);
         ++length;
     }
     PathRec r;
     r.end = e; r.start = cur; r.depth = depth; r.length = length;
-    r.rc_start = edge_reverse_complement(g, e);
-    r.target = -1; r.dist = 0; r.next = -1;
-    if (r.rc_start >= 0 && g_valid(g, r.rc_start)) {     // :262-273: lock forwards from RC(end) to the end of the path it lies on
-        int64_t x = r.rc_start, nx;
-        uint32_t dist = 0;
-        bool cycle = false;
-        while ((nx = next_simple(g, x)) != -1) {
-            x = nx;
-            ++dist;
-            if (x == r.rc_start) { cycle = true; break; }
-        }
-        if (!cycle) { r.target = find_path(ends, n, x); r.dist = dist; }
-    }
-    if (r.target >= 0) r.next = atomicExch(&head[r.target], (int32_t)pid);
+    r.rc_start = -1; r.target = -1; r.dist = 0; r.next = -1;
     rec[pid] = r;
+}
+// unitig_graph.cpp:241-273: the walk that locks forwards from RC(end) ends at the end edge of the path RC(end) lies on (an edge of a
+// pure cycle lies on no path that ends: nothing to claim)
+__global__ __launch_bounds__(64) void unitig_claim_kernel(GraphDev g, uint32_t n, PathRec *rec, const uint2 *on_path, int32_t *head) {
+    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    if (pid >= n) return;
+    const int64_t r = edge_reverse_complement(g, rec[pid].end);
+    rec[pid].rc_start = r;
+    if (r < 0 || !g_valid(g, r)) return;
+    const uint2 at = on_path[r];
+    if (at.x == 0xFFFFFFFFu) return;
+    rec[pid].target = (int32_t)at.x;
+    rec[pid].dist = at.y;
+    rec[pid].next = atomicExch(&head[at.x], (int32_t)pid);
 }
 
 // state: 0 = not known yet, 1 = processed (its edges get locked by its own walk), 2 = skipped at `marked.try_lock(edge_idx)`
@@ -535,20 +533,25 @@ __global__ __launch_bounds__(64) void unitig_decide_kernel(GraphDev g, const Pat
 
 struct ContigMeta { int64_t depth; uint32_t length, len; int32_t flag; uint32_t pad; uint64_t offset; };
 
-__global__ __launch_bounds__(64) void unitig_emit_kernel(GraphDev g, const PathRec *rec, const uint32_t *emit, const uint64_t *idx, const uint64_t *off,
-                                                         uint32_t n, ContigMeta *meta, char *text) {
+// VertexToDNAString (unitig_graph.cpp:80-112), one thread per EDGE: the label is the start node's k symbols followed by the W symbol
+// of every edge of the path
+__global__ __launch_bounds__(256) void unitig_chars_kernel(GraphDev g, const PathRec *rec, const uint2 *on_path, const uint32_t *emit, const uint64_t *off,
+                                                           char *text) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (x >= g.size) return;
+    const uint2 at = on_path[x];
+    if (at.x == 0xFFFFFFFFu || !emit[at.x]) return;
+    const int w = g_W(g, x);
+    text[off[at.x] + (uint64_t)g.k + (rec[at.x].length - 1 - at.y)] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
+}
+__global__ __launch_bounds__(64) void unitig_finish_kernel(GraphDev g, const PathRec *rec, const uint32_t *emit, const uint64_t *idx, const uint64_t *off,
+                                                           uint32_t n, ContigMeta *meta, char *text) {
     const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
     if (pid >= n || !emit[pid]) return;
     const PathRec r = rec[pid];
     const int k = g.k;
     const uint32_t len = r.length + (uint32_t)k;
     char *s = text + off[pid];
-    int64_t cur = r.end;
-    for (uint32_t i = r.length; i-- > 0;) {          // VertexToDNAString, unitig_graph.cpp:80-112
-        int w = g_W(g, cur);
-        s[k + i] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
-        if (i) cur = prev_simple(g, cur);
-    }
     uint8_t lab[kMaxK + 1];
     d_label(g, r.start, lab);
     for (int i = 0; i < k; ++i) s[i] = "ACGT"[lab[i] - 1];
@@ -740,7 +743,7 @@ struct Contigs {
 
 static void unitigs(Work &w, int min_contig, Contigs &out) {
     const GraphDev &g = w.d.g;
-    DevBuf ends, rec, head, state, undecided, emit, emit_len, idx, off, tmp, meta, text;
+    DevBuf ends, rec, head, state, undecided, emit, emit_len, idx, off, tmp, meta, text, on_path;
     const uint64_t n64 = edges_where(w, PredPathEnd{}, ends);
     if (n64 >= 0x7FFFFFFFull) { set_error("mgta_denovo: %llu paths exceed 31-bit path ids", (unsigned long long)n64); throw HipError{MGTA_EUNSUPPORTED}; }
     const uint32_t n = (uint32_t)n64;
@@ -752,7 +755,10 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
     undecided.alloc(64, w.live(), w.peak());
     MGTA_HIP_CHECK(hipMemsetAsync(head.p, 0xFF, (size_t)n * 4, w.st));
     MGTA_HIP_CHECK(hipMemsetAsync(state.p, 0, (size_t)n * 4, w.st));
-    hipLaunchKernelGGL(unitig_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), head.as<int32_t>());
+    on_path.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
+    MGTA_HIP_CHECK(hipMemsetAsync(on_path.p, 0xFF, (size_t)g.size * 8 + 64, w.st));
+    hipLaunchKernelGGL(unitig_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), on_path.as<uint2>());
+    hipLaunchKernelGGL(unitig_claim_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, n, rec.as<PathRec>(), on_path.as<uint2>(), head.as<int32_t>());
     for (;;) {
         MGTA_HIP_CHECK(hipMemsetAsync(undecided.p, 0, 4, w.st));
         hipLaunchKernelGGL(unitig_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, w.st, rec.as<PathRec>(), head.as<int32_t>(), n, state.as<uint32_t>(),
@@ -788,7 +794,9 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
     if (n_contigs == 0) return;
     meta.alloc(n_contigs * sizeof(ContigMeta), w.live(), w.peak());
     text.alloc(n_chars + 64, w.live(), w.peak());
-    hipLaunchKernelGGL(unitig_emit_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), emit.as<uint32_t>(), idx.as<uint64_t>(), off.as<uint64_t>(), n,
+    hipLaunchKernelGGL(unitig_chars_kernel, dim3((unsigned)((g.size + 255) / 256)), dim3(256), 0, w.st, g, rec.as<PathRec>(), on_path.as<uint2>(), emit.as<uint32_t>(),
+                       off.as<uint64_t>(), text.as<char>());
+    hipLaunchKernelGGL(unitig_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), emit.as<uint32_t>(), idx.as<uint64_t>(), off.as<uint64_t>(), n,
                        meta.as<ContigMeta>(), text.as<char>());
     out.meta.resize(n_contigs);
     out.text.resize(n_chars);
