@@ -48,6 +48,12 @@ int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
  * 2 = the segment-local sort runs LSD passes over every remaining digit instead of finishing short runs by comparison
  *     (also the fallback for tiles whose runs are long) */
 int mgta_ctx_set_full_lsd(mgta_ctx *, int on);
+/* Shared-cache searches (mgta_astar_batch with cache_mode = B >= 1): the path found by seed j after c_j node expansions is seen by
+ * exactly the seeds >= j + B + c_j / expansions_per_seed.  0 (default) = no cost term: seed i sees the seeds <= i - B, and every
+ * later seed waits for the longest unfinished search.  > 0: a search that has already run r expansions cannot become visible to the
+ * seeds below j + B + r / expansions_per_seed any more, so those start without waiting for it.  Either way the result is a function
+ * of (seed order, B, expansions_per_seed) only, never of timing. */
+int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);
 
 /* ------------------------------------------------------------------------------------------------
  * SdBG construction  (replaces CX1::run() with the s2 plug-ins: cx1.h:443-623,

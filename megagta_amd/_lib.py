@@ -80,6 +80,7 @@ SYMBOLS = {
     "mgta_findstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgta_ctx_set_search_cost_rate": (C.c_int, [C.c_void_p, C.c_int]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgta_host_free": (None, [C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

@@ -68,9 +68,10 @@ struct HashEnt {
 
 struct CacheEnt {
     unsigned long long key;       // parent key (0 = empty)
-    unsigned long long val;       // ~(owner seed << 16 | em_state of the child (nucl_emission | state << 9)); 0 = unset.
-                                  // One atomicMax of the complement keeps the lowest owner = "first insert wins" of the
-                                  // sequential reference (and lets the table start as all-zero bytes).
+    unsigned long long val;       // ~(first seed that sees the entry << 16 | em_state of the child (nucl_emission | state << 9)); 0 = unset.
+                                  // One atomicMax of the complement keeps the entry that becomes visible first (window B, no cost
+                                  // term: the lowest owner = "first insert wins" of the sequential reference) and lets the table start
+                                  // as all-zero bytes.
 };
 
 struct HmmView {
@@ -102,14 +103,19 @@ struct AstarArgs {
     char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
     int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = arena overflow, 3 = bad seed, 4 = gate timeout
     int use_lds;
-    // shared term_nodes caches (search.cpp:182), one per direction.  window = 0: off (cold).  window = B >= 1: the
-    // search of seed j sees exactly the paths committed by seeds <= j - B (B = 1: the reference's sequential run).
+    // shared term_nodes caches (search.cpp:182), one per direction.  window = 0: off (cold).  window = B >= 1: the path found by
+    // seed j (c_j expansions) is seen by exactly the seeds >= j + B + c_j / cost_rate (cost_rate = 0: no cost term; B = 1 then is
+    // the reference's sequential run).  The cost term lets later seeds start while a long search is still running: it cannot
+    // become visible to them any more, however soon it ends.
     int window;
+    int cost_rate;
     CacheEnt *cache[2];
     uint64_t cache_mask[2];
     unsigned long long *prof;     // [8] diagnostic cycle sums (MGTA_ASTAR_PROFILE builds only)
-    unsigned long long *frontier; // [2] number of leading seeds whose search of that direction has committed
-    uint32_t *committed;          // [2][n] flags
+    long long *run_seed;          // [slots] seed a wave is working on (a lower bound while it is taking one from the queue), -1 = none
+    unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
+    unsigned long long *start_limit;    // [2] highest seed index known to be allowed to start (monotone cache of the gate)
+    uint32_t n_slots;
 };
 
 __device__ __forceinline__ int to_fval(double x) {   // (int)x as x86-64 cvttsd2si does it (INT_MIN when out of range / NaN)
@@ -229,7 +235,7 @@ __device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
     return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// child descriptor cached for `key` and visible to seed `seed` under window B, or -1
+// child descriptor cached for `key` and visible to seed `seed`, or -1
 __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
     const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
     const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
@@ -241,17 +247,16 @@ __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_
             unsigned long long v = ld_agent(&tab[i].val);
             if (v == 0ull) return -1;
             v = ~v;
-            int64_t owner = (int64_t)(v >> 16);
-            return owner <= seed - a.window ? (int)(v & 0xFFFF) : -1;
+            return (int64_t)(v >> 16) <= seed ? (int)(v & 0xFFFF) : -1;
         }
         i = (i + 1) & cmask;
     }
 }
-__device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t seed, int em_state) {
+__device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t visible_from, int em_state) {
     CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
     const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
     uint64_t i = mix64(key) & cmask;
-    unsigned long long v = ((unsigned long long)seed << 16) | (unsigned long long)(em_state & 0xFFFF);
+    unsigned long long v = ((unsigned long long)visible_from << 16) | (unsigned long long)(em_state & 0xFFFF);
     while (true) {
         unsigned long long k = ld_agent(&tab[i].key);
         if (k == 0) {
@@ -316,26 +321,47 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     while (true) {
         // ---- next search of this direction
         long long qi = 0;
-        if (lane == 0) qi = (long long)atomicAdd(&a.queue[dir], 1ull);
+        if (lane == 0) {
+            if (a.window > 0) {
+                // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also sees
+                // a wave that holds it (or its committed paths)
+                __hip_atomic_store(&a.run_progress[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&a.run_seed[slot], (long long)ld_agent(&a.queue[dir]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                qi = (long long)atomicAdd(&a.queue[dir], 1ull);
+            }
+        }
         qi = __shfl(qi, 0, 64);
         if (qi >= (dir ? a.n_todo[1] : a.n_todo[0])) break;
         const int64_t seed = (dir ? a.todo[1] : a.todo[0])[qi];
         const int64_t sid = seed * 2 + dir;
         if (a.window > 0) {
-            // seeds are taken in order; wait until every seed <= seed - window has committed its path.
-            // The seed at the frontier is always held by a running wave, so this terminates; the spin is bounded anyway.
+            if (lane == 0) __hip_atomic_store(&a.run_seed[slot], (long long)seed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // Seed i may start once no unfinished search j can still become visible to it: i < j + B + progress_j / cost_rate for every
+            // running j, and i < q + B for the next seed q of the queue.  The lowest running search always passes, so this terminates;
+            // the wait is bounded anyway.
             int gate_ok = 1;
-            if (lane == 0) {
-                long long need = (long long)seed - a.window + 1;
-                unsigned long long spins = 0;
-                while ((long long)ld_agent(&a.frontier[dir]) < need) {
-                    __builtin_amdgcn_s_sleep(32);
-                    if (++spins > (1ull << 28)) { gate_ok = 0; break; }
+            unsigned long long spins = 0;
+            while ((long long)__hip_atomic_load(&a.start_limit[dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (long long)seed) {
+                const long long head = (long long)__hip_atomic_load(&a.queue[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                long long bound = head + a.window - 1;
+                for (uint32_t s = (uint32_t)lane; s < a.n_slots; s += 64) {
+                    if (((s / kAstarWaves) & 1u) != (uint32_t)dir) continue;
+                    const long long js = __hip_atomic_load(&a.run_seed[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (js < 0) continue;
+                    const unsigned long long pr = __hip_atomic_load(&a.run_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const long long b = js + a.window - 1 + (a.cost_rate > 0 ? (long long)(pr / (unsigned)a.cost_rate) : 0ll);
+                    bound = b < bound ? b : bound;
                 }
+                bound = wave_min_ll(bound);
+                if (lane == 0) __hip_atomic_fetch_max(&a.start_limit[dir], (unsigned long long)(bound < 0 ? 0 : bound), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bound >= (long long)seed) break;
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > (1ull << 24)) { gate_ok = 0; break; }
             }
-            gate_ok = __shfl(gate_ok, 0, 64);
             if (!gate_ok) {
-                if (lane == 0) a.status[sid] = 4;
+                if (lane == 0) { a.status[sid] = 4; __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
                 break;
             }
         }
@@ -460,6 +486,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
             }
             n_expanded++;
+            if (a.window > 0 && a.cost_rate > 0 && (n_expanded & 63) == 0 && lane == 0)
+                __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             PROF(4)
 
             // ---- children (node_enumerator.h:131-244): every lane scores ITS codon's match / insert child
@@ -623,7 +651,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     }
                     const ANode par = nodes[nd.parent];
                     if (a.window > 0 && lane == 0)
-                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9), seed, nd.em_state);
+                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
+                                     seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
                     nd = par;
                 }
                 if (lane == 0)
@@ -633,17 +662,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 a.sides[sid] = r;
                 a.out_len[sid] = len;
                 a.status[sid] = status;
-                if (a.window > 0) {
+                if (a.window > 0) {      // the paths are in the cache: this search no longer holds anybody back
                     __threadfence();
-                    __hip_atomic_store(&a.committed[(size_t)dir * a.n_seeds + seed], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    while (true) {                                                      // advance the commit frontier
-                        unsigned long long F = ld_agent(&a.frontier[dir]);
-                        if ((long long)F >= a.n_seeds) break;
-                        unsigned int c = __hip_atomic_fetch_add(&a.committed[(size_t)dir * a.n_seeds + F], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!c) break;
-                        unsigned long long e = F;
-                        __hip_atomic_compare_exchange_strong(&a.frontier[dir], &e, F + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -651,7 +672,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
     PROF_FLUSH
-    if (lane == 0) a.slot_tag[slot] = tag;
+    if (lane == 0) {
+        a.slot_tag[slot] = tag;
+        if (a.window > 0) __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace mgta
@@ -788,8 +812,9 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         std::vector<int32_t> h_status((size_t)n * 2);
         uint32_t cap_nodes = 1u << 17;                                              // cold: searches that still overflow are re-run with 8x
         // warm modes: seeds must run in order in ONE launch (no re-runs), so the arenas are sized generously up front
-        DevBuf d_cache[2], d_frontier, d_committed;
+        DevBuf d_cache[2], d_run_seed, d_run_progress, d_start_limit;
         a.window = cache_mode;
+        a.cost_rate = cache_mode > 0 ? ctx->search_cost_rate : 0;
         if (cache_mode > 0) {
             cap_nodes = 1u << 18;
             for (int d = 0; d < 2; ++d) {
@@ -799,18 +824,17 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, cap * sizeof(CacheEnt), st));
                 a.cache[d] = d_cache[d].as<CacheEnt>(); a.cache_mask[d] = cap - 1;
             }
-            d_frontier.alloc(16); d_committed.alloc((size_t)n * 2 * 4);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_frontier.p, 0, 16, st));
-            MGTA_HIP_CHECK(hipMemsetAsync(d_committed.p, 0, (size_t)n * 2 * 4, st));
-            a.frontier = d_frontier.as<unsigned long long>(); a.committed = d_committed.as<uint32_t>();
+            d_start_limit.alloc(16);
+            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 16, st));
+            a.start_limit = d_start_limit.as<unsigned long long>();
         }
         for (int attempt = 0; attempt < (cache_mode > 0 ? 1 : 5); ++attempt) {
             int64_t work = (int64_t)std::max(todo[0].size(), todo[1].size());
             if (work == 0) break;
             // persistent grid: one workgroup per CU and direction pair, fewer when there is little work
             int blocks = std::min<int64_t>((int64_t)ctx->num_cus * (a.use_lds ? 1 : 2), 2 * ((work + kAstarWaves - 1) / kAstarWaves));
-            if (cache_mode > 0) {   // at most `window` searches of a direction can be in flight; cap the arena footprint
-                blocks = std::min<int64_t>(blocks, 2 * (((int64_t)cache_mode + kAstarWaves - 1) / kAstarWaves));
+            if (cache_mode > 0) {   // without the cost term at most `window` searches of a direction can be in flight; cap the arena footprint
+                if (a.cost_rate == 0) blocks = std::min<int64_t>(blocks, 2 * (((int64_t)cache_mode + kAstarWaves - 1) / kAstarWaves));
                 size_t free_b = 0, total_b = 0;
                 MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
                 uint64_t per_slot = (uint64_t)cap_nodes * (sizeof(ANode) + sizeof(HeapEnt) + 2 * sizeof(HashEnt));
@@ -819,6 +843,12 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             blocks = std::max(2, blocks + (blocks & 1));
             uint64_t slots = (uint64_t)blocks * kAstarWaves;
             uint32_t cap_hash = cap_nodes * 2;
+            if (cache_mode > 0) {
+                d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
+                MGTA_HIP_CHECK(hipMemsetAsync(d_run_seed.p, 0xFF, slots * 8, st));
+                MGTA_HIP_CHECK(hipMemsetAsync(d_run_progress.p, 0, slots * 8, st));
+                a.run_seed = d_run_seed.as<long long>(); a.run_progress = d_run_progress.as<unsigned long long>(); a.n_slots = (uint32_t)slots;
+            }
             // per-search arenas live in the context between calls: hash entries are tag-versioned and the tag counters
             // persist, so a re-used arena needs neither clearing nor re-allocation (only a geometry change does)
             AstarArenas &ar = ctx->astar;

@@ -73,6 +73,7 @@ struct mgta_ctx {
     uint64_t mem_limit = 0;       // 0 = auto
     int force_full_lsd = 0;
     int lsd_skip_left = 0;       // sorts left that go straight to LSD passes in LDS (the last look found mostly long runs)
+    int search_cost_rate = 0;    // shared-cache searches: a path found with c expansions becomes visible c / rate seeds later (0 = no cost term)
     int force_lsd_tiles = 0;     // segment-local sort: LSD passes over every digit, no finish by comparison
     uint64_t live_bytes = 0, peak_bytes = 0;
     int num_cus = 256;

@@ -55,6 +55,12 @@ int mgta_ctx_set_full_lsd(mgta_ctx *ctx, int on) {
     return MGTA_OK;
 }
 
+int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
+    if (!ctx || expansions_per_seed < 0) return MGTA_EINVAL;
+    ctx->search_cost_rate = expansions_per_seed;
+    return MGTA_OK;
+}
+
 int mgta_ctx_set_mem_limit(mgta_ctx *ctx, uint64_t bytes) {
     if (!ctx) return MGTA_EINVAL;
     ctx->mem_limit = bytes;

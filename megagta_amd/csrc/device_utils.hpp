@@ -35,6 +35,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
+__device__ __forceinline__ long long wave_min_ll(long long v) {   // every lane gets the minimum over the wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int lo = __shfl_xor((int)(v & 0xFFFFFFFFll), off, 64), hi = __shfl_xor((int)(v >> 32), off, 64);
+        const long long o = ((long long)hi << 32) | (unsigned int)lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; }

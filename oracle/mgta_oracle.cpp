@@ -781,10 +781,11 @@ struct Searcher {
     double low_cov_penalty;                                 // -log(low_cov_pen), node_enumerator.h:42
     double exit_prob[3000];                                 // hmm_graph_search.h:48-52
     Cache cache[2];
-    // windowed warm mode: seed j sees the paths of seeds <= j - window (window 1 == the reference's sequential sharing)
-    int window = 1;
+    // windowed warm mode: the path seed j found with c_j expansions is seen by the seeds >= j + window + c_j / cost_rate (cost_rate 0:
+    // no cost term; window 1 then == the reference's sequential sharing)
+    int window = 1, cost_rate = 0;
     int64_t seed_counter = 0;
-    struct Pending { int64_t seed; int dir; Key parent, child; };
+    struct Pending { int64_t seed; int dir; Key parent, child; int em; int64_t visible_from; };
     std::vector<Pending> pending;
     int cur_dir = 0;
     std::vector<Node *> pool;
@@ -950,7 +951,8 @@ std::string path_string(Searcher &S, int dir, Node *goal) {
         if (p->state != 'd')
             for (int i = 0; i < 3; ++i) s.push_back("acgt-"[(p->nucl_emission >> (3 * i)) & 7]);
         // term_nodes.insert keeps the first value of a key (hash_table_st.h:309-331); applied when the window allows
-        S.pending.push_back(Searcher::Pending{S.seed_counter, dir, key_of(*p->from), key_of(*p)});
+        S.pending.push_back(Searcher::Pending{S.seed_counter, dir, key_of(*p->from), key_of(*p),
+                                              p->nucl_emission | ((p->state == 'm' ? 0 : p->state == 'i' ? 1 : 2) << 9), -1});
     }
     std::reverse(s.begin(), s.end());
     return s;
@@ -1541,20 +1543,26 @@ orc_searcher *orc_searcher_new(const orc_graph *g, const orc_hmm *fwd, const orc
 void orc_searcher_free(orc_searcher *s) { s->release(); delete s; }
 void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); s->pending.clear(); s->seed_counter = 0; }
 void orc_searcher_set_window(orc_searcher *s, int window) { s->window = window < 1 ? 1 : window; }
+void orc_searcher_set_cost_rate(orc_searcher *s, int rate) { s->cost_rate = rate < 0 ? 0 : rate; }
 
 int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, orc_astar_result *right, orc_astar_result *left,
                         char *contig, int64_t cap) {
     std::string kmer(kmer_c);
     for (auto &c : kmer) c = (char)tolower(c);                              // search.cpp:156
     if ((int)kmer.size() < s->g->k + 1) return -1;
-    {   // make the paths of seeds <= j - window visible, in seed order (first insert wins)
+    {   // make visible what this seed may see; of two entries for one key the one that became visible first stays (ties: the smaller
+        // child descriptor, as the device's single atomicMax decides it)
+        std::vector<Searcher::Pending> now;
         size_t keep = 0;
         for (size_t i = 0; i < s->pending.size(); ++i) {
             const auto &p = s->pending[i];
-            if (p.seed <= s->seed_counter - s->window) s->cache[p.dir].emplace(p.parent, p.child);
+            if (p.visible_from <= s->seed_counter) now.push_back(p);
             else s->pending[keep++] = p;
         }
         s->pending.resize(keep);
+        std::stable_sort(now.begin(), now.end(), [](const Searcher::Pending &a, const Searcher::Pending &b) {
+            return a.visible_from != b.visible_from ? a.visible_from < b.visible_from : a.em < b.em; });
+        for (const auto &p : now) s->cache[p.dir].emplace(p.parent, p.child);
     }
     AstarOut o1, o2;
     Node *g1 = astar_from_kmer(*s, 0, start_state, kmer, o1);               // hmm_graph_search.h:67
@@ -1564,6 +1572,11 @@ int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, or
     Node *g2 = astar_from_kmer(*s, 1, lstate, kmer, o2);
     std::string ls = g2 ? path_string(*s, 1, g2) : std::string();
     fill_result(left, o2, g2);
+    for (auto &p : s->pending)
+        if (p.visible_from < 0) {
+            const int64_t c = p.dir == 0 ? o1.expanded : o2.expanded;
+            p.visible_from = p.seed + s->window + (s->cost_rate > 0 ? c / s->cost_rate : 0);
+        }
     s->release();
     s->seed_counter++;
     std::string out = revcomp(ls) + kmer + rs;                              // :77-79

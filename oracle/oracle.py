@@ -65,7 +65,7 @@ def lib():
         "orc_hmm_h": (vp, [vp]), "orc_hmm_alpha": (vp, [vp]),
         "orc_searcher_new": (vp, [vp, vp, vp, i32, dbl]), "orc_searcher_free": (None, [vp]),
         "orc_searcher_clear_cache": (None, [vp]),
-        "orc_searcher_set_window": (None, [vp, i32]),
+        "orc_searcher_set_window": (None, [vp, i32]), "orc_searcher_set_cost_rate": (None, [vp, i32]),
         "orc_search_seed": (i64, [vp, C.c_char_p, i32, C.POINTER(AstarResult), C.POINTER(AstarResult), C.c_char_p, i64]),
     }
     for name, (res, args) in sig.items():
@@ -242,6 +242,10 @@ class Searcher:
 
     def clear_cache(self):
         lib().orc_searcher_clear_cache(self.h)
+
+    def set_cost_rate(self, rate: int):
+        """the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j // rate (0 = no cost term)"""
+        lib().orc_searcher_set_cost_rate(self.h, rate)
 
     def set_window(self, window: int):
         """seed j sees the paths of seeds <= j - window (1 = sequential sharing like `search ... 1`)"""

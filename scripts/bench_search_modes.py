@@ -3,7 +3,7 @@ import sys, time, json, os, tempfile, subprocess
 sys.path.insert(0, '.')
 import numpy as np
 from megagta_amd import api, synth, hmm as hmmlib
-n = int(sys.argv[1]); modes = [int(x) for x in sys.argv[2].split(",")]; nseeds = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+n = int(sys.argv[1]); modes = [tuple(int(y) for y in (x + ":0").split(":")[:2]) for x in sys.argv[2].split(",")]   # window[:cost_rate]; nseeds = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 M = 277
 mg = synth.make_metagenome(n, 150, (("rplB", M),), seed=1)
 td = tempfile.mkdtemp()
@@ -22,13 +22,13 @@ g = api.Graph(ctx, stream)
 fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))
 rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "rev_enone.hmm")))
 base = None
-for mode in modes:
+for mode, rate in modes:
     t = time.time()
-    res, st = api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=mode)
+    res, st = api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=mode, cost_rate=rate)
     dt = time.time() - t
     contigs = [r.contig(s[0]) for r, s in zip(res, seeds)]
     if base is None: base = contigs
     same = sum(a == b for a, b in zip(contigs, base))
-    print(json.dumps({"cache_mode": mode, "wall_s": round(dt, 3), "ms_kernel": round(st["ms_kernel"], 1), "expansions": st["n_expansions"],
+    print(json.dumps({"cache_mode": mode, "cost_rate": rate, "wall_s": round(dt, 3), "ms_kernel": round(st["ms_kernel"], 1), "expansions": st["n_expansions"],
                       "Mexp_per_s": round(st["n_expansions"] / st["ms_kernel"] / 1e3, 2), "seeds_per_s": round(len(seeds) / dt, 1),
                       "retries": st["n_retries"], "same_contigs_as_first_mode": same, "distinct_contigs": len(set(contigs))}), flush=True)

@@ -114,9 +114,10 @@ def test_warm_sequential_equals_reference_search_1thread(toy):
     assert st["n_expansions"] < sum(c["R"]["closed"] + c["L"]["closed"] for c in cold) / 3      # the cache really short-cuts
 
 
-@pytest.mark.parametrize("window", [1, 4, 64])
-def test_windowed_warm_vs_oracle(ctx, oracle, window):
-    """cache_mode B: seed j sees the paths of seeds <= j-B; deterministic whatever the GPU scheduling; == oracle with the same window"""
+@pytest.mark.parametrize("window,rate", [(1, 0), (4, 0), (64, 0), (1, 1), (4, 16), (16, 64), (64, 4)])
+def test_windowed_warm_vs_oracle(ctx, oracle, window, rate):
+    """cache_mode B (+ cost rate R): the path seed j found with c_j expansions is seen by the seeds >= j + B + c_j // R (R = 0: no cost term);
+    deterministic whatever the GPU scheduling; == the oracle run sequentially with the same rule"""
     from megagta_amd import api
     import tempfile
     mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
@@ -128,16 +129,17 @@ def test_windowed_warm_vs_oracle(ctx, oracle, window):
         seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
         g = api.Graph(ctx, stream)
         fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
-        runs = [api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=window) for _ in range(2)]
+        runs = [api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=window, cost_rate=rate) for _ in range(2)]
         og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
         S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), 20, 0.5)
         S.clear_cache()
         S.set_window(window)
+        S.set_cost_rate(rate)
         for i, (kmer, pos) in enumerate(seeds):
             contig, R, L = S.search(kmer, pos - 1, cold=False)
             for res, _ in runs:
                 r = res[i]
-                assert r.contig(kmer) == contig, (window, i)
+                assert r.contig(kmer) == contig, (window, rate, i)
                 for got, ref in ((r.right_side, R), (r.left_side, L)):
                     assert got["ok"] == ref.ok and got["n_closed"] == ref.n_closed and got["n_expanded"] == ref.n_expanded
                     if ref.ok:
