@@ -114,7 +114,7 @@ struct AstarArgs {
     unsigned long long *prof;     // [8] diagnostic cycle sums (MGTA_ASTAR_PROFILE builds only)
     long long *run_seed;          // [slots] seed a wave is working on (a lower bound while it is taking one from the queue), -1 = none
     unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
-    unsigned long long *start_limit;    // [2] highest seed index known to be allowed to start (monotone cache of the gate)
+    unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last refresh by a waiting wave
     uint32_t n_slots;
 };
 
@@ -235,6 +235,23 @@ __device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
     return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Protocol words (queue, table of running searches, start limit) are only ever touched by agent-scope atomics performed at the
+// coherence point; they are ordered by waiting for the returning atomic before the next one is issued.  No acquire / release
+// fences: on this part an agent-scope acquire invalidates, and a release writes back, the whole L2 of the XCD, and a gate that does
+// that at polling rate slows every running search by an order of magnitude (measured: 5.3 s -> 257 s).
+__device__ __forceinline__ void st_agent(long long *p, long long v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ long long ld_agent_ll(const long long *p) {
+    long long v = __hip_atomic_fetch_add(const_cast<long long *>(p), 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return v;
+}
 // child descriptor cached for `key` and visible to seed `seed`, or -1
 __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
     const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
@@ -273,6 +290,39 @@ __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64
         }
         i = (i + 1) & cmask;
     }
+}
+
+// Highest seed that may start now: no unfinished search can still become visible to it (see AstarArgs::window).  Every lane returns
+// the same value; start_limit keeps the maximum ever computed (the bound only grows).  The table reads are atomics performed at the
+// coherence point, four in flight per lane.
+__device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, int lane) {
+    const long long head = (long long)ld_agent(&a.queue[dir]);       // the queue first: every seed below it is in the table by now
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long bound = head + a.window - 1;
+    const uint32_t n_dir = a.n_slots / 2;                            // this direction's waves: workgroups 2b + dir
+    for (uint32_t t0 = 0; t0 < n_dir; t0 += 256) {
+        long long js[4];
+        unsigned long long pr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + u * 64 + (uint32_t)lane;
+            const uint32_t sl = (2 * (t / kAstarWaves) + (uint32_t)dir) * kAstarWaves + t % kAstarWaves;
+            js[u] = -1; pr[u] = 0;
+            if (t < n_dir) {
+                js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.cost_rate > 0) pr[u] = __hip_atomic_fetch_add(&a.run_progress[sl], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (js[u] >= 0) {
+                const long long b = js[u] + a.window - 1 + (a.cost_rate > 0 ? (long long)(pr[u] / (unsigned)a.cost_rate) : 0ll);
+                bound = b < bound ? b : bound;
+            }
+    }
+    bound = wave_min_ll(bound);
+    if (lane == 0 && bound > 0) __hip_atomic_fetch_max(&a.start_limit[dir], (unsigned long long)bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return bound;
 }
 
 #ifdef MGTA_ASTAR_PROFILE   // diagnostic build only: per-phase cycle sums (s_memtime), lane 0 of every wave
@@ -325,9 +375,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (a.window > 0) {
                 // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also sees
                 // a wave that holds it (or its committed paths)
-                __hip_atomic_store(&a.run_progress[slot], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&a.run_seed[slot], (long long)ld_agent(&a.queue[dir]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                st_agent(&a.run_progress[slot], 0ull);
+                st_agent(&a.run_seed[slot], (long long)ld_agent(&a.queue[dir]));
+                qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 qi = (long long)atomicAdd(&a.queue[dir], 1ull);
             }
@@ -337,31 +387,39 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         const int64_t seed = (dir ? a.todo[1] : a.todo[0])[qi];
         const int64_t sid = seed * 2 + dir;
         if (a.window > 0) {
-            if (lane == 0) __hip_atomic_store(&a.run_seed[slot], (long long)seed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) st_agent(&a.run_seed[slot], (long long)seed);
             // Seed i may start once no unfinished search j can still become visible to it: i < j + B + progress_j / cost_rate for every
             // running j, and i < q + B for the next seed q of the queue.  The lowest running search always passes, so this terminates;
             // the wait is bounded anyway.
+            // The limit moves when a search ends (its wave recomputes it) and, with a cost term, as the running searches progress: for that
+            // ONE waiting wave per direction and ~50 us re-reads the table (ticket = time of the last refresh); the others poll one word.
             int gate_ok = 1;
             unsigned long long spins = 0;
-            while ((long long)__hip_atomic_load(&a.start_limit[dir], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (long long)seed) {
-                const long long head = (long long)__hip_atomic_load(&a.queue[dir], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                long long bound = head + a.window - 1;
-                for (uint32_t s = (uint32_t)lane; s < a.n_slots; s += 64) {
-                    if (((s / kAstarWaves) & 1u) != (uint32_t)dir) continue;
-                    const long long js = __hip_atomic_load(&a.run_seed[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (js < 0) continue;
-                    const unsigned long long pr = __hip_atomic_load(&a.run_progress[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const long long b = js + a.window - 1 + (a.cost_rate > 0 ? (long long)(pr / (unsigned)a.cost_rate) : 0ll);
-                    bound = b < bound ? b : bound;
+            if (start_bound(a, dir, lane) < (long long)seed) {
+                while (true) {
+                    long long lim = 0;
+                    int refresh = 0;
+                    if (lane == 0) {
+                        lim = (long long)ld_agent(&a.start_limit[dir]);
+                        if (lim < (long long)seed) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                            unsigned long long last = ld_agent(&a.start_limit[2 + dir]);
+                            if (now - last > 5000ull)
+                                refresh = __hip_atomic_compare_exchange_strong(&a.start_limit[2 + dir], &last, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    lim = __shfl(lim, 0, 64);
+                    if (lim >= (long long)seed) break;
+                    refresh = __shfl(refresh, 0, 64);
+                    if (refresh && start_bound(a, dir, lane) >= (long long)seed) break;
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+                    if (++spins > (1ull << 21)) { gate_ok = 0; break; }
                 }
-                bound = wave_min_ll(bound);
-                if (lane == 0) __hip_atomic_fetch_max(&a.start_limit[dir], (unsigned long long)(bound < 0 ? 0 : bound), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bound >= (long long)seed) break;
-                __builtin_amdgcn_s_sleep(32);
-                if (++spins > (1ull << 24)) { gate_ok = 0; break; }
             }
             if (!gate_ok) {
-                if (lane == 0) { a.status[sid] = 4; __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+                if (lane == 0) { a.status[sid] = 4; st_agent(&a.run_seed[slot], -1ll); }
                 break;
             }
         }
@@ -662,11 +720,12 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 a.sides[sid] = r;
                 a.out_len[sid] = len;
                 a.status[sid] = status;
-                if (a.window > 0) {      // the paths are in the cache: this search no longer holds anybody back
-                    __threadfence();
-                    __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.window > 0) {      // the paths are in the cache (atomics, all performed): this search no longer holds anybody back
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_agent(&a.run_seed[slot], -1ll);
                 }
             }
+            if (a.window > 0) (void)start_bound(a, dir, lane);       // whoever finishes a search moves the limit for the waiting ones
         }
         PROF(7)
         __builtin_amdgcn_wave_barrier();
@@ -674,7 +733,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     PROF_FLUSH
     if (lane == 0) {
         a.slot_tag[slot] = tag;
-        if (a.window > 0) __hip_atomic_store(&a.run_seed[slot], -1ll, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.window > 0) st_agent(&a.run_seed[slot], -1ll);
     }
 }
 
@@ -824,8 +883,8 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, cap * sizeof(CacheEnt), st));
                 a.cache[d] = d_cache[d].as<CacheEnt>(); a.cache_mask[d] = cap - 1;
             }
-            d_start_limit.alloc(16);
-            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 16, st));
+            d_start_limit.alloc(32);                                                // [0..1] limit per direction, [2..3] scan lock
+            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 32, st));
             a.start_limit = d_start_limit.as<unsigned long long>();
         }
         for (int attempt = 0; attempt < (cache_mode > 0 ? 1 : 5); ++attempt) {

@@ -3,7 +3,8 @@ import sys, time, json, os, tempfile, subprocess
 sys.path.insert(0, '.')
 import numpy as np
 from megagta_amd import api, synth, hmm as hmmlib
-n = int(sys.argv[1]); modes = [tuple(int(y) for y in (x + ":0").split(":")[:2]) for x in sys.argv[2].split(",")]   # window[:cost_rate]; nseeds = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+n = int(sys.argv[1]); modes = [tuple(int(y) for y in (x + ":0").split(":")[:2]) for x in sys.argv[2].split(",")]   # window[:cost_rate]
+nseeds = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 M = 277
 mg = synth.make_metagenome(n, 150, (("rplB", M),), seed=1)
 td = tempfile.mkdtemp()
