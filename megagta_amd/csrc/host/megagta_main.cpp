@@ -181,12 +181,15 @@ static int main_search(int argc, char **argv) {
     // window), 16384 21 s (1.4 G), 65536 24 s (3.0 G, little sharing left)
     int cache_window = 16384;
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
+    int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (measured: no gain at this window)
+    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
     double t0 = now_s();
     logf("Loading SdBG...");
     EdgeStream s;
     read_sdbg(argv[1], s);
     mgta_ctx *ctx = mgta_ctx_create(0);
     if (!ctx) die("%s", mgta_last_error());
+    if (mgta_ctx_set_search_cost_rate(ctx, cost_rate) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
     mgta_sdbg *g = nullptr;
     if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
                        s.words_per_tip, &g) != MGTA_OK)
