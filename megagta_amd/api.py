@@ -175,8 +175,8 @@ class Graph:
         from ._lib import DenovoStats
         text, n, st = C.c_void_p(), C.c_uint64(), DenovoStats()
         check(self.ctx._L.mgta_denovo(self.h, max_tip_len, int(no_bubble), min_contig, C.byref(text), C.byref(n), C.byref(st)), "mgta_denovo")
-        try:
-            fasta = C.string_at(text, n.value).decode()
+        try:      # (ctypes.string_at takes a C int: a 100 M-read graph gives > 2^31 characters)
+            fasta = bytes(memoryview((C.c_char * n.value).from_address(text.value))).decode() if n.value else ""
         finally:
             self.ctx._L.mgta_host_free(text)
         return fasta, st.as_dict()

@@ -23,6 +23,7 @@
 //    (PopBubbles keeps the LAST branch on equal multiplicities, which is a different allele on the two strands: the graph is not
 //    strand-symmetric afterwards, so none of this may assume that RC(path) is a path.)
 #include <algorithm>
+#include <chrono>
 #include <memory>
 
 #include "graph.hpp"
@@ -176,12 +177,15 @@ struct PredPathEnd {       // unitig_graph.cpp:223
 
 template <class Pred>
 __global__ __launch_bounds__(256) void edge_mask_kernel(GraphDev g, Pred pred, unsigned long long *mask, uint32_t *count) {
-    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;     // one wave = one line of 64 edges
-    const bool p = x < g.size && pred(g, x);
-    const unsigned long long m = __ballot(p);
-    if ((threadIdx.x & 63) == 0 && (uint64_t)(x >> 6) < g.n_lines) {
-        mask[x >> 6] = m;
-        count[x >> 6] = (uint32_t)__popcll(m);
+    // one wave = one line of 64 edges; capped grid (a dispatch holds < 2^32 work-items, a graph can hold more edges)
+    for (uint64_t li = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); li < g.n_lines; li += (uint64_t)gridDim.x * 4) {
+        const int64_t x = (int64_t)(li << 6) + (threadIdx.x & 63);
+        const bool p = x < g.size && pred(g, x);
+        const unsigned long long m = __ballot(p);
+        if ((threadIdx.x & 63) == 0) {
+            mask[li] = m;
+            count[li] = (uint32_t)__popcll(m);
+        }
     }
 }
 __global__ __launch_bounds__(256) void mask_expand_kernel(const unsigned long long *mask, const uint64_t *base, uint64_t n_lines, int64_t *list) {
@@ -537,12 +541,12 @@ struct ContigMeta { int64_t depth; uint32_t length, len; int32_t flag; uint32_t 
 // of every edge of the path
 __global__ __launch_bounds__(256) void unitig_chars_kernel(GraphDev g, const PathRec *rec, const uint2 *on_path, const uint32_t *emit, const uint64_t *off,
                                                            char *text) {
-    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (x >= g.size) return;
-    const uint2 at = on_path[x];
-    if (at.x == 0xFFFFFFFFu || !emit[at.x]) return;
-    const int w = g_W(g, x);
-    text[off[at.x] + (uint64_t)g.k + (rec[at.x].length - 1 - at.y)] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < g.size; x += (int64_t)gridDim.x * 256) {
+        const uint2 at = on_path[x];
+        if (at.x == 0xFFFFFFFFu || !emit[at.x]) continue;
+        const int w = g_W(g, x);
+        text[off[at.x] + (uint64_t)g.k + (rec[at.x].length - 1 - at.y)] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
+    }
 }
 __global__ __launch_bounds__(64) void unitig_finish_kernel(GraphDev g, const PathRec *rec, const uint32_t *emit, const uint64_t *idx, const uint64_t *off,
                                                            uint32_t n, ContigMeta *meta, char *text) {
@@ -584,6 +588,19 @@ struct Work {
     uint64_t *peak() { return &ctx->peak_bytes; }
 };
 
+static bool verbose() { static const bool v = getenv("MGTA_DENOVO_VERBOSE") != nullptr; return v; }
+static void note(Work &w, const char *fmt, ...) {      // MGTA_DENOVO_VERBOSE: one line per step on stderr, after the stream has drained
+    if (!verbose()) return;
+    (void)hipStreamSynchronize(w.st);
+    static const auto t0 = std::chrono::steady_clock::now();
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[denovo %8.3f s] ", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+
 static uint64_t read_u64(Work &w, const void *p) {
     uint64_t v = 0;
     MGTA_HIP_CHECK(hipMemcpyAsync(&v, p, 8, hipMemcpyDeviceToHost, w.st));
@@ -594,8 +611,9 @@ static uint64_t read_u64(Work &w, const void *p) {
 template <class Pred>
 static uint64_t edges_where(Work &w, Pred pred, DevBuf &list) {   // ascending ids of the edges that satisfy pred
     const GraphDev &g = w.d.g;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mask_kernel<Pred>), dim3((unsigned)((g.size + 255) / 256)), dim3(256), 0, w.st, g, pred,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(edge_mask_kernel<Pred>), dim3((unsigned)std::min<uint64_t>((g.n_lines + 3) / 4, 1u << 22)), dim3(256), 0, w.st, g, pred,
                        w.mask.as<unsigned long long>(), w.count.as<uint32_t>());
+    MGTA_HIP_CHECK(hipGetLastError());
     exclusive_scan_u32(w.st, w.count.as<uint32_t>(), g.n_lines, w.base.as<uint64_t>(), w.tmp.as<uint64_t>(), w.total.as<uint64_t>());
     const uint64_t n = read_u64(w, w.total.p);
     list.alloc(n * 8 + 64, w.live(), w.peak());
@@ -639,6 +657,7 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
                                removed.as<unsigned long long>(), counter.as<unsigned long long>());
         hipLaunchKernelGGL(trim_delete_kernel, dim3((unsigned)((g.n_lines + 255) / 256)), dim3(256), 0, w.st, w.d, removed.as<unsigned long long>());
         MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+        note(w, "trim len %d: %llu in-degree-0 starts", len, (unsigned long long)n);
     };
     for (int len = 2; len < max_tip_len; len *= 2) trim(len);
     trim(max_tip_len);
@@ -683,7 +702,8 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         cur ^= 1;
         const uint32_t done = m - carry;
         if (done == 0) { set_error("mgta_denovo: a bubble round committed nothing"); throw HipError{MGTA_EINTERNAL}; }   // the lowest always commits
-        want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * done));     // a round that commits few (a region that does not fit the reach scratch) shrinks the next
+        want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * done));
+        if ((n_rounds & 15) == 1) note(w, "bubble round %lld: window %u, committed %u, %llu of %llu taken", (long long)n_rounds, m, done, (unsigned long long)p, (unsigned long long)n);     // a round that commits few (a region that does not fit the reach scratch) shrinks the next
     }
 }
 
@@ -705,6 +725,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
                            found.as<uint32_t>());
     const uint64_t nc = compact_list(w, branching, found, nb, cand);
     n_candidates = (int64_t)nc;
+    note(w, "bubbles: %llu branching edges, %llu candidates, window %u", (unsigned long long)nb, (unsigned long long)nc, b.window);
     if (nc == 0) return 0;
     if (nc >= 0xFFFFFFFFull) { set_error("mgta_denovo: %llu bubble candidates exceed 32-bit positions", (unsigned long long)nc); throw HipError{MGTA_EUNSUPPORTED}; }
     b.owner.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
@@ -758,6 +779,7 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
     on_path.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
     MGTA_HIP_CHECK(hipMemsetAsync(on_path.p, 0xFF, (size_t)g.size * 8 + 64, w.st));
     hipLaunchKernelGGL(unitig_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), on_path.as<uint2>());
+    note(w, "unitigs: %u paths walked", n);
     hipLaunchKernelGGL(unitig_claim_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, n, rec.as<PathRec>(), on_path.as<uint2>(), head.as<int32_t>());
     for (;;) {
         MGTA_HIP_CHECK(hipMemsetAsync(undecided.p, 0, 4, w.st));
@@ -769,6 +791,7 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
         MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
         if (left == 0) break;
     }
+    note(w, "unitigs: claims resolved in %lld sweeps", (long long)out.n_sweeps);
     emit.alloc((size_t)n * 4, w.live(), w.peak());
     emit_len.alloc((size_t)n * 4, w.live(), w.peak());
     idx.alloc((size_t)n * 8, w.live(), w.peak());
@@ -794,10 +817,11 @@ static void unitigs(Work &w, int min_contig, Contigs &out) {
     if (n_contigs == 0) return;
     meta.alloc(n_contigs * sizeof(ContigMeta), w.live(), w.peak());
     text.alloc(n_chars + 64, w.live(), w.peak());
-    hipLaunchKernelGGL(unitig_chars_kernel, dim3((unsigned)((g.size + 255) / 256)), dim3(256), 0, w.st, g, rec.as<PathRec>(), on_path.as<uint2>(), emit.as<uint32_t>(),
+    hipLaunchKernelGGL(unitig_chars_kernel, dim3((unsigned)std::min<int64_t>((g.size + 255) / 256, 1 << 22)), dim3(256), 0, w.st, g, rec.as<PathRec>(), on_path.as<uint2>(), emit.as<uint32_t>(),
                        off.as<uint64_t>(), text.as<char>());
     hipLaunchKernelGGL(unitig_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), emit.as<uint32_t>(), idx.as<uint64_t>(), off.as<uint64_t>(), n,
                        meta.as<ContigMeta>(), text.as<char>());
+    note(w, "unitigs: %llu contigs, %llu characters written", (unsigned long long)n_contigs, (unsigned long long)n_chars);
     out.meta.resize(n_contigs);
     out.text.resize(n_chars);
     MGTA_HIP_CHECK(hipMemcpyAsync(out.meta.data(), meta.p, n_contigs * sizeof(ContigMeta), hipMemcpyDeviceToHost, w.st));
@@ -837,6 +861,7 @@ int mgta_denovo(mgta_sdbg *graph, int max_tip_len, int no_bubble, int min_contig
             for (auto &e : ev) MGTA_HIP_CHECK(hipEventCreate(&e));
             MGTA_HIP_CHECK(hipEventRecord(ev[0], w.st));
             if (max_tip_len == -1) max_tip_len = g.k * 2;                           // assembler.cpp:125-127
+            note(w, "%lld edges", (long long)g.size);
             if (max_tip_len > 0) s.n_tips = (int64_t)remove_tips(w, max_tip_len);
             MGTA_HIP_CHECK(hipEventRecord(ev[1], w.st));
             if (!no_bubble) s.n_bubbles = (int64_t)pop_bubbles(w, s.n_bubble_rounds, s.n_bubble_candidates);

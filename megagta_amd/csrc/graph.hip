@@ -18,9 +18,9 @@ namespace mgta {
 // G1: pack 64 records into a line, count ones per line: cnt[c*n_lines + line], c = 0 last, 1 tip, 2..5 symbols 1..4
 __global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, int64_t size, GLine *lines, uint64_t n_lines,
                                                          uint32_t *cnt) {
-    uint64_t li = (uint64_t)blockIdx.x * 4 + wave_id();   // one wave per line, one lane per edge
-    if (li >= n_lines) return;
-    int lane = lane_id();
+    // one wave per line, one lane per edge; the grid is capped (a dispatch holds < 2^32 work-items: 6.3 G edges do not fit one lane each)
+    const int lane = lane_id();
+    for (uint64_t li = (uint64_t)blockIdx.x * 4 + wave_id(); li < n_lines; li += (uint64_t)gridDim.x * 4) {
     int64_t e = (int64_t)(li << 6) + lane;
     uint32_t it = e < size ? recs[e] : 0;
     bool in = e < size;
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, i
         cnt[1 * n_lines + li] = (uint32_t)__popcll(b_tip);
 #pragma unroll
         for (int a = 0; a < 4; ++a) cnt[(2 + a) * n_lines + li] = (uint32_t)__popcll(sym[a]);
+    }
     }
 }
 
@@ -164,8 +165,9 @@ static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, 
             d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
             d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
             d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)((n_lines + 3) / 4)), dim3(256), 0, st, dev_recs, size,
+            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_lines + 3) / 4, 1u << 22)), dim3(256), 0, st, dev_recs, size,
                                g->lines.as<GLine>(), n_lines, d_cnt.as<uint32_t>());
+            MGTA_HIP_CHECK(hipGetLastError());
             uint64_t tot[6];
             for (int c = 0; c < 6; ++c)
                 exclusive_scan_u32(st, d_cnt.as<uint32_t>() + c * n_lines, n_lines, d_base.as<uint64_t>() + c * n_lines, d_tmp.as<uint64_t>(),
@@ -187,6 +189,7 @@ static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, 
             MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
             hipLaunchKernelGGL(graph_hint_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d, g->lines.as<GLine>());
+            MGTA_HIP_CHECK(hipGetLastError());
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
         }
         ctx_retain(ctx);
