@@ -36,4 +36,21 @@ kmers = [seqs[i][p:p + k + 1] for i in pick for p in range(0, len(seqs[i]) - k, 
 ids = g2.index_edges(kmers)
 print(f"{len(kmers)} (k+1)-mers of {len(pick)} sampled contigs looked up: {int((ids < 0).sum())} missing; max edge id {int(ids.max())}")
 assert (ids >= 0).all()
+# the A* leg on the same graph: every contig it returns must be a path of the graph
+import os, tempfile
+from megagta_amd import hmm as hmmlib
+td = tempfile.mkdtemp()
+synth.write_gene_models(mg.genes, td)
+fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))
+rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "rev_enone.hmm")))
+seeds = synth.synthetic_seeds(mg.genes[0], 45, 2000, seed=4)
+t0 = time.time()
+res, sst = api.astar_search(g2, fw, rv, [x[0] for x in seeds], [x[1] - 1 for x in seeds], 20, 0.5)
+contigs = [r.contig(x[0]).upper() for r, x in zip(res, seeds)]
+# (a seed whose own (k+1)-mer no read covers is returned as it is: 0.995^45 error-free x 15x coverage leaves ~2e-4 of them uncovered)
+km = [c[p:p + k + 1] for c in contigs if len(c) > k + 1 for p in range(0, len(c) - k, 7)]
+ids = g2.index_edges(km)
+print(f"A*: {len(seeds)} seeds, {sst['n_expansions']} expansions in {sst['ms_kernel']:.0f} ms; {len(km)} (k+1)-mers of the contigs looked up: "
+      f"{int((ids < 0).sum())} missing; ids above 2^32: {int((ids >= 2**32).sum())}; mean contig {np.mean([len(c) for c in contigs]):.0f} nt")
+assert (ids >= 0).all() and (ids >= 2**32).any()
 print("OK")
