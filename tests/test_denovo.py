@@ -140,3 +140,20 @@ def test_device_edge_cases(ctx, oracle):
     est = oracle.Stream.build(packed, start, 31, threads=1)
     text, s = api.Graph(ctx, est.edges()).denovo(150, False, 0)
     assert text == "" and s["n_contigs"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_bubble", [True, False])
+def test_device_validity_bits_after_cleaning(ctx, oracle, no_bubble):
+    """not only the contigs: the graph itself (which edges tips and bubbles removed) is the oracle's, bit for bit"""
+    from megagta_amd import api
+    reads = synth.make_strain_mix(321, n_genomes=4, genome_len=3000, snp_every=45, tricky=True)
+    st = _oracle_stream(oracle, reads, 31, 2)
+    og, g = oracle.Graph(st), api.Graph(ctx, st.edges())
+    assert np.array_equal(og.invalid_now(), g.invalid_bits())                       # tips and $ edges after the load
+    before = int(np.unpackbits(g.invalid_bits().view(np.uint8)).sum())
+    og.denovo(150, no_bubble, 0)
+    g.denovo(150, no_bubble, 0)
+    a, b = og.invalid_now(), g.invalid_bits()
+    assert np.array_equal(a, b)
+    assert int(np.unpackbits(b.view(np.uint8)).sum()) > before + 100
