@@ -392,6 +392,99 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W>
     for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
 }
 
+// Closed-form key generation (see item_write_closed_kernel) cut along the census tiles of the first global sort pass: workgroup t
+// writes exactly the keys [t kBlockTile, (t+1) kBlockTile) and counts their first-pass digit in LDS on the way, so the keys are not
+// read back for that census (one of the 11 HBM crossings of the key array).  A read owns npos + 2 PAIRS of keys (left $ pair, one pair
+// per position, right $ pair); read bases and tile bounds are even, so a pair never straddles a tile: lane = pair, 24 contiguous
+// bytes per lane, consecutive lanes consecutive pairs.  The reads of a tile are found from block_base (first key of every 64 reads).
+template <int W>
+__global__ __launch_bounds__(kScanBlock) void item_write_tiled_kernel(ScanArgs a, uint64_t n_blocks, uint64_t n_items, int digit_shift,
+                                                                      uint64_t n_tiles, uint64_t *hist) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_read_base[kReadsPerBlock];
+    __shared__ uint64_t s_start[kReadsPerBlock + 1];
+    const int k = a.k;
+    const int lane = lane_id(), wv = wave_id();
+    for (int i = threadIdx.x; i < 256; i += kScanBlock) s_hist[i] = 0;
+    const uint64_t lo = (uint64_t)blockIdx.x * kBlockTile;
+    const uint64_t hi = lo + kBlockTile < n_items ? lo + kBlockTile : n_items;
+    // last group of 64 reads whose first key is at or before `lo`: 64-ary search, every wave on its own (block_base[0] = 0 <= lo)
+    uint64_t left = 0, right = n_blocks;
+    while (right - left > 1) {
+        const uint64_t step = (right - left + 63) / 64, idx = left + (uint64_t)lane * step;
+        const bool ok = idx < right && a.block_base[idx] <= lo;
+        const unsigned long long m = __ballot(ok);                     // a prefix of lanes: block_base is non-decreasing
+        const uint64_t nl = left + (uint64_t)(__popcll(m) - 1) * step;
+        right = nl + step < right ? nl + step : right;
+        left = nl;
+    }
+    Key<W> *out = reinterpret_cast<Key<W> *>(a.out);
+    const int pad_bits = 2 * (16 * W - (k + 1));
+    for (uint64_t b = left; b < n_blocks; ++b) {
+        const uint64_t bb = a.block_base[b];
+        if (bb >= hi) break;
+        const uint64_t r0 = b * kReadsPerBlock;
+        const uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
+        __syncthreads();                                               // the previous group's table is no longer read
+        if (wv == 0) {
+            const uint64_t st = r0 + lane <= r1 ? a.start[r0 + lane] : 0, st_next = r0 + lane < r1 ? a.start[r0 + lane + 1] : st;
+            s_start[lane] = st;
+            if (r0 + lane + 1 == r1) s_start[lane + 1] = st_next;
+            uint32_t items = 0;
+            if (r0 + lane < r1) {
+                const int len = (int)(st_next - st);
+                if (len >= k + 1) items = 2u * (uint32_t)(len - k) + 4u;
+            }
+            s_read_base[lane] = wave_incl_scan(items) - items;
+        }
+        __syncthreads();
+        for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
+            const uint64_t s0 = s_start[r - r0];
+            const int len = (int)(s_start[r - r0 + 1] - s0);
+            if (len < k + 1) continue;
+            const int npos = len - k;
+            const uint64_t rb = bb + s_read_base[r - r0], re = rb + 2ull * (uint64_t)npos + 4ull;
+            if (re <= lo || rb >= hi) continue;
+            const int j_lo = rb >= lo ? 0 : (int)((lo - rb) >> 1), j_hi = re <= hi ? npos + 2 : (int)((hi - rb) >> 1);
+            Key<W> *ro = out + rb;
+            for (int c0 = j_lo; c0 < j_hi; c0 += 64) {
+                const int j = c0 + lane;
+                if (j >= j_hi) continue;
+                const int p = j == 0 ? 0 : (j == npos + 1 ? npos - 1 : j - 1);
+                const uint64_t q = s0 + (uint64_t)p, wi = q >> 4;
+                const int sh = (int)(q & 15) * 2;
+                uint32_t raw[W + 1], e[W], rc[W];
+#pragma unroll
+                for (int i = 0; i <= W; ++i) raw[i] = (wi + i < a.n_words) ? a.packed[wi + i] : 0u;
+#pragma unroll
+                for (int i = 0; i < W; ++i) e[i] = sh ? ((raw[i] << sh) | (raw[i + 1] >> (32 - sh))) : raw[i];
+                keep_chars<W>(e, k + 1);
+#pragma unroll
+                for (int i = 0; i < W; ++i) rc[i] = rev_chars(~e[W - 1 - i]);
+                shl_bits<W>(rc, pad_bits);
+                const int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+                Key<W> ka, kb;
+                if (j == 0) {                                           // left $  (s2.cpp:531-540)
+                    ka = make_key<W>(e, 0, k, k, kDollar);
+                    kb = make_key<W>(rc, 2, k - 1, k, r1c);
+                } else if (j == npos + 1) {                             // right $ (s2.cpp:553-562)
+                    ka = make_key<W>(e, 2, k - 1, k, e1);
+                    kb = make_key<W>(rc, 0, k, k, kDollar);
+                } else {                                                // solid   (s2.cpp:543-550)
+                    ka = make_key<W>(e, 1, k, k, e0);
+                    kb = make_key<W>(rc, 1, k, k, r0c);
+                }
+                ro[2 * j] = ka;
+                ro[2 * j + 1] = kb;
+                atomicAdd(&s_hist[(ka.w[0] >> digit_shift) & 255u], 1u);
+                atomicAdd(&s_hist[(kb.w[0] >> digit_shift) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kScanBlock) hist[(uint64_t)i * n_tiles + blockIdx.x] = s_hist[i];
+}
+
 // one workgroup per digit value: exclusive scan of its row of tile counts, in place; row total -> totals[digit]
 __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uint64_t n_tiles, uint64_t *totals) {
     __shared__ uint64_t scratch[1024 / 64 + 1];
@@ -1349,19 +1442,32 @@ static uint64_t pool_bytes(const mgta_ctx *ctx) {
 // Sort n keys of WT words ascending on the digits that matter: `max_top` leading bytes may be used for global passes;
 // low_plan_for(P) lists the remaining significant digits (least significant first).  Returns the buffer (a or b) that
 // holds the result, nullptr on an unsupported input (error set).
+// P: smallest number of leading bytes that leaves segments of <= 256 keys on average — up to 1024 rather than a fourth
+// global pass: a 4096-key tile still holds several such segments, and the comparison route needs key bits left in word 0.
+// prefix_frac: share of the leading-byte values the keys can take (a pass over a bucket sub-range only holds that share of
+// the prefixes, so its segments are as long as those of the whole key set)
+static double avg_segment_len(uint64_t n_items, int p, double prefix_frac) { return (double)n_items / std::max(1.0, std::pow(256.0, p) * prefix_frac); }
+static int choose_top_bytes(const mgta_ctx *ctx, uint64_t n_items, int max_top, double prefix_frac) {
+    if (ctx->force_full_lsd) return 0;
+    int P = 0;
+    while (P < max_top && avg_segment_len(n_items, P, prefix_frac) > (P >= 3 ? 700.0 : 256.0)) ++P;
+    return P;
+}
+
+// first_census_done: the census of the first global pass (digit top_digit(WT, P-1), tiles of kBlockTile keys of `a`) is already in
+// the S_HIST buffer (item_write_tiled_kernel counted while it wrote the keys)
 template <int WT, class LowPlanFn>
 static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
                             std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, double prefix_frac = 1.0,
-                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u) {
-    // prefix_frac: share of the leading-byte values the keys can take (a pass over a bucket sub-range only holds that share of
-    // the prefixes, so its segments are as long as those of the whole key set)
+                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u, bool first_census_done = false) {
     const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
     uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
     uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
     Key<WT> *src = a, *dst = b;
-    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg) {
+    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg, bool have_census) {
         uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
-        hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+        if (!have_census)
+            hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, tiles, d_totals);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (scatter_ev) {
@@ -1377,13 +1483,9 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             if (S) S->n_sort_launches++;
         }
     };
-    // P: smallest number of leading bytes that leaves segments of <= 256 keys on average — up to 1024 rather than a fourth
-    // global pass: a 4096-key tile still holds several such segments, and the comparison route needs key bits left in word 0
-    int P = 0;
-    auto avg_segment = [&](int p) { return (double)n_items / std::max(1.0, std::pow(256.0, p) * prefix_frac); };
-    while (P < max_top && avg_segment(P) > (P >= 3 ? 700.0 : 256.0)) ++P;
-    if (ctx->force_full_lsd) P = 0;
-    for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(WT, i)); std::swap(src, dst); }
+    const int P = choose_top_bytes(ctx, n_items, max_top, prefix_frac);
+    auto avg_segment = [&](int p) { return avg_segment_len(n_items, p, prefix_frac); };
+    for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(WT, i), first_census_done && i == P - 1); std::swap(src, dst); }
     const std::vector<Digit> low = low_plan_for(P);
     if (low.size() > 64) { set_error("too many sort digits"); return nullptr; }
     Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
@@ -1724,16 +1826,25 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             // ---- 3. write keys
             t_ph.start();
             sa.out = d_a;
-            if (closed_form)
+            const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
+            const double prefix_frac = (double)(b_hi - b_lo) / MGTA_NUM_BUCKETS;
+            // closed form + at least one global sort pass: the key writer works tile by tile of that pass and leaves its census behind
+            const int P_top = choose_top_bytes(ctx, n_items, max_top, prefix_frac);
+            static const bool tiled_keygen = !(getenv("MGTA_KEYGEN_TILED") && atoi(getenv("MGTA_KEYGEN_TILED")) == 0);
+            const bool fused_census = closed_form && P_top >= 1 && tiled_keygen && n_tiles <= 0x7FFFFFFFull;
+            if (fused_census) {
+                uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);   // the buffer device_sort uses
+                hipLaunchKernelGGL((item_write_tiled_kernel<W>), dim3((unsigned)n_tiles), dim3(kScanBlock), 0, stream, sa, n_blocks, n_items,
+                                   32 - 8 * P_top, n_tiles, d_hist);
+            } else if (closed_form)
                 hipLaunchKernelGGL((item_write_closed_kernel<W>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             else
                 hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             S.ms_gen += t_ph.stop();
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
-            const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
             Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int P) { return low_digit_plan(k, W, P); }, &scatter_ev, &S,
-                                           (double)(b_hi - b_lo) / MGTA_NUM_BUCKETS);
+                                           prefix_frac, ~0u, ~0u, fused_census);
             if (!src) return MGTA_EUNSUPPORTED;
             Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();

@@ -347,3 +347,31 @@ def test_fuzz_small_inputs_vs_oracle(ctx, oracle, seed):
         os_ = oracle.Stream.build_solid(packed, start, k, m, mercy, threads=2)
         _same(gs, os_.edges())
         assert np.array_equal(ctx.last_counting(), os_.counting)
+
+
+@pytest.mark.parametrize("k", [30, 44])
+def test_tiled_key_writer_many_tiles_vs_oracle(ctx, oracle, k):
+    """closed-form builds (k+1 odd, -m 1, every bucket) write the keys tile by tile of the first sort pass and count that pass's
+    census on the way: tens of tiles, reads cut by tile bounds, reads longer than a tile, whole groups of 64 reads too short to
+    yield a key, a ragged tail"""
+    rng = np.random.default_rng(1000 + k)
+    genome = rng.integers(0, 4, 200_000).astype(np.uint8)
+    reads = []
+
+    def take(L):
+        p = int(rng.integers(0, genome.size - L))
+        r = genome[p:p + L].copy()
+        return (3 - r[::-1]).astype(np.uint8) if rng.random() < 0.5 else r
+
+    for i in range(9000):
+        if 2000 <= i < 2200 or 5000 <= i < 5064:
+            reads.append(take(int(rng.integers(1, k + 1))))            # no key at all (>= one whole group of 64 reads)
+        else:
+            reads.append(take(int(rng.integers(k - 2, 260))))
+    reads.insert(3000, take(40_000))                                    # longer than a tile of 32768 keys
+    reads.insert(3001, take(17_000))
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    assert g.stats["n_items"] > 40 * 32768
+    o = oracle.Stream.build(packed, start, k, threads=8).edges()
+    _same(g, o)
