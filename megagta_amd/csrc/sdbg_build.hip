@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W>
             bool ghead = true, bhead = true;
             if (idx == 0) head = true;
             else {
-                Key<W> prv = keys[idx - 1];
+                Key<W> prv = keys[idx - 1];                              // (taking it from the neighbouring lane by a shuffle was slower: 9.3 -> 11.2 ms)
                 head = !keys_equal<W>(cur, prv);
                 ghead = !same_km1<W>(cur, prv, k);
                 bhead = (cur.w[0] >> 16) != (prv.w[0] >> 16);             // first key of its bucket
@@ -1272,7 +1272,8 @@ __global__ __launch_bounds__(kEmitThreads) void emit_compact_kernel(const Key<W>
 // rec = w | last<<4 | tip<<5 | min(mult,255)<<8, or 0xFFFF when the run is suppressed.
 constexpr int kDecideThreads = 256;
 constexpr int kDecidePerThread = 4;
-constexpr int kDecideTile = kDecideThreads * kDecidePerThread;   // 1024 runs per workgroup, thread owns 4 consecutive
+constexpr int kDecideTile = kDecideThreads * kDecidePerThread;   // 1024 runs per workgroup
+constexpr int kDecideHalo = 32;
 
 __device__ __forceinline__ bool run_suppressed(int a, int b, int has_a, int has_b) {
     return (a == kDollar && ((has_b >> b) & 1)) || (b == kDollar && ((has_a >> a) & 1));
@@ -1282,28 +1283,36 @@ __global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(RunStarts s
                                                                       uint64_t n_items, uint16_t *rec, uint32_t *cnt_e,
                                                                       uint32_t *cnt_l, uint32_t *cnt_t) {
     __shared__ uint32_t s_e[kDecideThreads / 64], s_l[kDecideThreads / 64], s_t[kDecideThreads / 64];
-    uint64_t s0 = (uint64_t)blockIdx.x * kDecideTile + (uint64_t)threadIdx.x * kDecidePerThread;
+    // the tile's descriptors and a halo of one group on either side, staged once: the group walks below are chains of dependent
+    // byte loads (a walk that leaves the window, which no real group does, falls back to global memory)
+    __shared__ uint8_t s_info[kDecideTile + 2 * kDecideHalo];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kDecideTile;
+    const uint64_t w_lo = t0 >= (uint64_t)kDecideHalo ? t0 - kDecideHalo : 0;
+    const uint64_t w_hi = t0 + kDecideTile + kDecideHalo < m ? t0 + kDecideTile + kDecideHalo : m;
+    for (uint64_t x = w_lo + threadIdx.x; x < w_hi; x += kDecideThreads) s_info[x - w_lo] = sub_info[x];
+    __syncthreads();
+    auto info_at = [&](uint64_t x) -> int { return (x >= w_lo && x < w_hi) ? (int)s_info[x - w_lo] : (int)sub_info[x]; };
     uint32_t ne = 0, nl = 0, nt = 0;
     for (int q = 0; q < kDecidePerThread; ++q) {
-        uint64_t s = s0 + q;
+        uint64_t s = t0 + (uint64_t)q * kDecideThreads + threadIdx.x;      // consecutive lanes, consecutive runs
         if (s >= m) break;
-        int inf = sub_info[s];
+        int inf = info_at(s);
         int a = inf & 7, b = (inf >> 3) & 7;
         // group extent [gs, ge): at most 24 runs share a (k-1)-mer
         uint64_t gs = s;
-        while (!(sub_info[gs] & 64)) --gs;
+        while (!(info_at(gs) & 64)) --gs;
         uint64_t ge = s + 1;
-        while (ge < m && !(sub_info[ge] & 64)) ++ge;
+        while (ge < m && !(info_at(ge) & 64)) ++ge;
         int has_a = 0, has_b = 0;
         for (uint64_t x = gs; x < ge; ++x) {
-            int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+            int xi = info_at(x), xa = xi & 7, xb = (xi >> 3) & 7;
             if (xa != kDollar && xb != kDollar) { has_a |= 1 << xa; has_b |= 1 << xb; }
         }
         uint16_t r = 0xFFFF;
         if (!run_suppressed(a, b, has_a, has_b)) {
             bool seen_b = false;                                   // outputed_b, s2.cpp:822-824
             for (uint64_t x = gs; x < s; ++x) {
-                int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+                int xi = info_at(x), xa = xi & 7, xb = (xi >> 3) & 7;
                 if (xb == b && !run_suppressed(xa, xb, has_a, has_b)) seen_b = true;
             }
             int w = (b == kDollar) ? 0 : (seen_b ? b + 5 : b + 1);
@@ -1311,7 +1320,7 @@ __global__ __launch_bounds__(kDecideThreads) void emit_decide_kernel(RunStarts s
             if (a != kDollar) {                                    // last_a[], s2.cpp:776-779,823
                 bool later = false;
                 for (uint64_t x = s + 1; x < ge; ++x) {
-                    int xi = sub_info[x], xa = xi & 7, xb = (xi >> 3) & 7;
+                    int xi = info_at(x), xa = xi & 7, xb = (xi >> 3) & 7;
                     if (xa == a && (xb != kDollar || !((has_a >> a) & 1))) later = true;
                 }
                 last = later ? 0 : 1;
