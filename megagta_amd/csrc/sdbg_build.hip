@@ -326,6 +326,8 @@ constexpr int kWaveChunk = kSubTile / kSortWaves;          // 512 consecutive ke
 struct Digit {
     int pos;     // bit position counted from the least significant bit of the whole key
     int bits;    // <= 8
+    uint32_t bias;   // subtracted from key word 0 before the bits are taken (0 except for the global passes of a bucket sub-range build,
+                     // where word 0 - (first bucket << 16) has leading zero bits that the digits skip)
 };
 
 template <int W>
@@ -338,8 +340,8 @@ __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         if (j == wi) {
-            lo = key.w[j];
-            hi = j > 0 ? key.w[j - 1] : 0u;
+            lo = key.w[j] - (j == 0 ? d.bias : 0u);
+            hi = j > 0 ? key.w[j - 1] - (j == 1 ? d.bias : 0u) : 0u;
             asm volatile("" : "+v"(lo), "+v"(hi));
         }
     }
@@ -358,8 +360,8 @@ __device__ __forceinline__ void get_digits(const Key<W> (&key)[N], Digit d, uint
         if (j == wi) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                lo[i] = key[i].w[j];
-                hi[i] = j > 0 ? key[i].w[j - 1] : 0u;
+                lo[i] = key[i].w[j] - (j == 0 ? d.bias : 0u);
+                hi[i] = j > 0 ? key[i].w[j - 1] - (j == 1 ? d.bias : 0u) : 0u;
                 asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
             }
         }
@@ -383,8 +385,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W>
     for (int i = 0; i < kBlockTile / kSortThreads; ++i) {
         uint64_t idx = base + (uint64_t)i * kSortThreads + threadIdx.x;
         if (idx < n) {
-            uint32_t v = keys[idx].w[wi] >> off;
-            if (straddle) v |= keys[idx].w[wi - 1] << (32 - off);
+            uint32_t v = (keys[idx].w[wi] - (wi == 0 ? d.bias : 0u)) >> off;
+            if (straddle) v |= (keys[idx].w[wi - 1] - (wi == 1 ? d.bias : 0u)) << (32 - off);
             atomicAdd(&h[v & mask], 1u);
         }
     }
@@ -711,13 +713,13 @@ struct CompareShared {
 };
 
 template <int W>
-__device__ __forceinline__ uint32_t key_prefix(const Key<W> &key, int P) { return P == 0 ? 0u : (key.w[0] >> (32 - 8 * P)); }
+__device__ __forceinline__ uint32_t key_prefix(const Key<W> &key, int T) { return T == 0 ? 0u : (key.w[0] >> (32 - T)); }   // leading T <= 32 bits
 
 // What the segment-local kernels need besides the keys (host-built, passed by value)
 struct LocalPlan {
     const Digit *low_plan;   // every significant digit below the 8P-bit prefix, least significant first
     int n_low;
-    int P;
+    int T;                   // bits of the prefix the global passes sorted on (8 per pass, + the leading zero bits a bucket sub-range skips)
     Digit upper;             // the (<= 8) key bits right below the prefix (inside the first two key words)
     uint32_t mask_last2;     // significant bits of key word W-2 / W-1 (stage 1 carries a payload there that must not be compared);
     uint32_t mask_last;      // the digits of low_plan never look at a masked-out bit
@@ -758,7 +760,7 @@ __device__ __forceinline__ bool key_less(const Key<W> &a, const Key<W> &b, uint3
 // loads the tile keys[first, first + nt) in (wave chunk, round, lane) order and ranks the segments inside the tile;
 // returns the number of LSD passes the segment rank needs (0: one segment).  All threads call.
 template <int W>
-__device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys, uint64_t first, uint32_t nt, int P, Key<W> (&key)[LocalCfg<W>::kIpt],
+__device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys, uint64_t first, uint32_t nt, int T, Key<W> (&key)[LocalCfg<W>::kIpt],
                                          uint32_t (&seg)[LocalCfg<W>::kIpt]) {
     constexpr int kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
     const int lane = lane_id(), wv = wave_id();
@@ -770,7 +772,7 @@ __device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys,
         bool valid = j < nt, head = false;
         if (valid) {
             key[it] = keys[first + j];
-            head = j == 0 || key_prefix<W>(key[it], P) != key_prefix<W>(keys[first + j - 1], P);
+            head = j == 0 || key_prefix<W>(key[it], T) != key_prefix<W>(keys[first + j - 1], T);
         }
         uint64_t bal = __ballot(head);
         seg[it] = running + (uint32_t)__popcll(bal & le_mask);         // heads at positions <= j inside this wave chunk
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
     static_assert(kWindows <= 64, "tile bounds are read off one 64-bit head mask per lane");
     const uint32_t kLocalStride = lp.stride;
     __shared__ CompareShared<W> sh;
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), P = lp.P;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id(), T = lp.T;
     const uint64_t lo = (uint64_t)blockIdx.x * kLocalStride;
     const uint32_t loaded = (uint32_t)(n - lo < (uint64_t)kTile ? n - lo : (uint64_t)kTile);   // the window [lo, lo + loaded)
     constexpr bool want_keys = WANT_KEYS;
@@ -965,10 +967,10 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
         if (inw) {
             if (want_keys) key[it] = keys[lo + j];
             else key[it].w[0] = keys[lo + j].w[0];
-            p = key_prefix<W>(key[it], P);
+            p = key_prefix<W>(key[it], T);
         }
         uint32_t pp = __shfl_up(p, 1, 64);
-        if (lane == 0) pp = it == 0 ? ((inw && lo + j > 0) ? key_prefix<W>(keys[lo + j - 1], P) : 0u) : carry;
+        if (lane == 0) pp = it == 0 ? ((inw && lo + j > 0) ? key_prefix<W>(keys[lo + j - 1], T) : 0u) : carry;
         carry = __shfl(p, 63, 64);
         const uint64_t hm = __ballot(inw && (lo + j == 0 || p != pp));
         if (lane == 0) sh.masks[wv * kIpt + it] = hm;                 // window m = positions [64m, 64m + 64)
@@ -1030,14 +1032,14 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_sort_kernel(Key<W> *key
     const uint32_t n_words = ((nseg << ub) + 1u) >> 1;
     for (uint32_t i = tid; i < n_words; i += kSortThreads) sh.hist[i] = 0;
     __syncthreads();
-    const int run_bits = 8 * P + ub;                                   // <= 40: the digit may reach into the second key word
+    const int run_bits = T + ub;                                       // <= 40: the digit may reach into the second key word
     uint32_t br[kIpt];                                                // bin | rank inside the bin << 16
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         const uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
         br[it] = ~0u;
         if (j - first_off < nt) {
-            const uint32_t dg = ub ? (uint32_t)((key_top<W, 2>(key[it]) << (8 * P)) >> (64 - ub)) : 0u;
+            const uint32_t dg = ub ? (uint32_t)((key_top<W, 2>(key[it]) << T) >> (64 - ub)) : 0u;
             const uint32_t bin = (seg[it] << ub) | dg, sh16 = (bin & 1u) * 16u;
             const uint32_t old = atomicAdd(&sh.hist[bin >> 1], 1u << sh16);
             br[it] = bin | (((old >> sh16) & 0xFFFFu) << 16);
@@ -1101,13 +1103,13 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_lsd_kernel(Key<W> *keys
     const uint32_t nt = (uint32_t)cnt;
     Key<W> key[kIpt];
     uint32_t seg[kIpt];
-    const int n_seg_pass = tile_load<W>(sh, keys, first, nt, lp.P, key, seg);
+    const int n_seg_pass = tile_load<W>(sh, keys, first, nt, lp.T, key, seg);
     const int n_pass = lp.n_low + n_seg_pass;
     tile_zero_counts<W>(sh);
     for (int pass = 0; pass < n_pass; ++pass) {
         const bool by_seg = pass >= lp.n_low;
         Digit d;
-        d.pos = 0; d.bits = 8;
+        d.pos = 0; d.bits = 8; d.bias = 0;
         if (!by_seg) d = lp.low_plan[pass];
         lds_pass<W>(sh, key, seg, nt, d, by_seg, by_seg ? 8 * (pass - lp.n_low) : 0, pass + 1 < n_pass);
     }
@@ -1121,17 +1123,17 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_lsd_kernel(Key<W> *keys
 
 // first segment head after `start` (end of a big segment): one workgroup per big segment
 template <int W>
-__global__ __launch_bounds__(256) void segment_end_kernel(const Key<W> *keys, uint64_t n, int P, const uint64_t *big, uint64_t *big_end) {
+__global__ __launch_bounds__(256) void segment_end_kernel(const Key<W> *keys, uint64_t n, int T, const uint64_t *big, uint64_t *big_end) {
     __shared__ unsigned long long s_end;
     const uint64_t start = big[blockIdx.x];
-    const uint32_t pre = key_prefix<W>(keys[start], P);
+    const uint32_t pre = key_prefix<W>(keys[start], T);
     if (threadIdx.x == 0) s_end = ~0ull;
     __syncthreads();
     for (uint64_t base = start + 1; base < n; base += 256 * 16) {
         unsigned long long found = ~0ull;
         for (int i = 0; i < 16; ++i) {
             uint64_t idx = base + (uint64_t)i * 256 + threadIdx.x;
-            if (idx < n && key_prefix<W>(keys[idx], P) != pre && (unsigned long long)idx < found) found = idx;
+            if (idx < n && key_prefix<W>(keys[idx], T) != pre && (unsigned long long)idx < found) found = idx;
         }
         if (found != ~0ull) atomicMin(&s_end, found);
         __syncthreads();
@@ -1418,10 +1420,10 @@ struct Timer {
 
 // most significant digits first: digit i = key bits [32W - 8(i+1), 32W - 8i)
 static Digit top_digit(int W, int i) { return Digit{32 * W - 8 * (i + 1), 8}; }
-// digits of the bits below 32W - 8P, least significant first (flags, then characters; the zero pad is skipped)
-static std::vector<Digit> low_digit_plan(int k, int W, int P) {
+// digits of the bits below 32W - T (T = prefix bits the global passes sorted on), least significant first (flags, then characters; the zero pad is skipped)
+static std::vector<Digit> low_digit_plan(int k, int W, int T) {
     std::vector<Digit> plan;
-    int pad = 32 * W - 2 * k - 4, top = 32 * W - 8 * P;
+    int pad = 32 * W - 2 * k - 4, top = 32 * W - T;
     if (top > 0) plan.push_back(Digit{0, std::min(4, top)});
     for (int pos = 4 + pad; pos < top; pos += 8) plan.push_back(Digit{pos, std::min(8, top - pos)});
     return plan;
@@ -1456,11 +1458,43 @@ static uint64_t pool_bytes(const mgta_ctx *ctx) {
 // prefix_frac: share of the leading-byte values the keys can take (a pass over a bucket sub-range only holds that share of
 // the prefixes, so its segments are as long as those of the whole key set)
 static double avg_segment_len(uint64_t n_items, int p, double prefix_frac) { return (double)n_items / std::max(1.0, std::pow(256.0, p) * prefix_frac); }
-static int choose_top_bytes(const mgta_ctx *ctx, uint64_t n_items, int max_top, double prefix_frac) {
-    if (ctx->force_full_lsd) return 0;
-    int P = 0;
-    while (P < max_top && avg_segment_len(n_items, P, prefix_frac) > (P >= 3 ? 700.0 : 256.0)) ++P;
-    return P;
+// The global passes of a build over the buckets [b_lo, b_hi) need not spend digit values on prefixes no key has: word 0 minus
+// (b_lo << 16) has `skip` leading zero bits, and P digits of 8 bits taken right below them order the keys by their leading
+// T = 8P + skip bits (a third of the buckets: skip = 1, so three passes leave the 645-key segments that otherwise take four).
+// T >= 16 is required: then the bias is a multiple of 2^(32 - T) and equal biased prefixes are equal key prefixes.
+struct TopPlan {
+    int P = 0, skip = 0;
+    uint32_t bias = 0;
+    double frac = 1.0;           // share of the 2^T prefix values the keys can take
+    int T() const { return 8 * P + skip; }
+};
+static TopPlan choose_top_plan(const mgta_ctx *ctx, uint64_t n_items, int max_top, double prefix_frac, uint32_t b_lo = 0, uint32_t b_hi = 0) {
+    TopPlan plain;
+    plain.frac = prefix_frac;
+    if (ctx->force_full_lsd) return plain;
+    auto passes = [&](double frac_of, int p_min) {
+        int P = p_min;
+        while (P < max_top && avg_segment_len(n_items, P, frac_of) > (P >= 3 ? 700.0 : 256.0)) ++P;
+        return P;
+    };
+    plain.P = passes(prefix_frac, 0);
+    static const int mode = getenv("MGTA_SORT_BIAS") ? atoi(getenv("MGTA_SORT_BIAS")) : 1;    // 0 never, 1 when it saves a pass, 2 whenever valid (tests)
+    if (mode == 0 || b_hi <= b_lo || (b_lo == 0 && b_hi >= (uint32_t)MGTA_NUM_BUCKETS)) return plain;
+    const uint32_t span = ((b_hi - b_lo) << 16) - 1u;                  // largest biased word 0
+    const int skip_full = __builtin_clz(span | 1u);
+    for (int P = 1; P <= max_top; ++P) {
+        const int skip = std::min(skip_full, 32 - 8 * P);
+        if (skip <= 0 || 8 * P + skip < 16) continue;
+        const double frac = std::min(1.0, prefix_frac * std::pow(2.0, skip));
+        if (P < max_top && avg_segment_len(n_items, P, frac) > (P >= 3 ? 700.0 : 256.0)) continue;
+        if (P < plain.P || (mode >= 2 && P <= plain.P)) {
+            TopPlan b;
+            b.P = P; b.skip = skip; b.bias = b_lo << 16; b.frac = frac;
+            return b;
+        }
+        break;
+    }
+    return plain;
 }
 
 // first_census_done: the census of the first global pass (digit top_digit(WT, P-1), tiles of kBlockTile keys of `a`) is already in
@@ -1468,7 +1502,7 @@ static int choose_top_bytes(const mgta_ctx *ctx, uint64_t n_items, int max_top, 
 template <int WT, class LowPlanFn>
 static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
                             std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, double prefix_frac = 1.0,
-                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u, bool first_census_done = false) {
+                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u, bool first_census_done = false, uint32_t b_lo = 0, uint32_t b_hi = 0) {
     const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
     uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
     uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
@@ -1492,15 +1526,21 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             if (S) S->n_sort_launches++;
         }
     };
-    const int P = choose_top_bytes(ctx, n_items, max_top, prefix_frac);
-    auto avg_segment = [&](int p) { return avg_segment_len(n_items, p, prefix_frac); };
-    for (int i = P - 1; i >= 0; --i) { global_pass(src, dst, n_items, top_digit(WT, i), first_census_done && i == P - 1); std::swap(src, dst); }
-    const std::vector<Digit> low = low_plan_for(P);
+    const TopPlan tp = choose_top_plan(ctx, n_items, max_top, prefix_frac, b_lo, b_hi);
+    const int P = tp.P, T = tp.T();
+    for (int i = P - 1; i >= 0; --i) {
+        Digit dg = top_digit(WT, i);
+        dg.pos -= tp.skip;
+        dg.bias = tp.bias;
+        global_pass(src, dst, n_items, dg, first_census_done && i == P - 1);
+        std::swap(src, dst);
+    }
+    const std::vector<Digit> low = low_plan_for(T);
     if (low.size() > 64) { set_error("too many sort digits"); return nullptr; }
     Digit *d_plan = pool_get<Digit>(ctx, S_PLAN, 64 * sizeof(Digit));
     MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
     // room behind the stride for the last segment of a tile: ~2.5 average segments, an eighth of the tile at least, half at most
-    const double avg_seg = avg_segment(P);
+    const double avg_seg = avg_segment_len(n_items, P, tp.frac);
     uint32_t margin = (uint32_t)std::min<double>(LocalCfg<WT>::kTile / 2, std::max<double>(LocalCfg<WT>::kTile / 8, 2.5 * avg_seg));
     margin = (margin + 63u) & ~63u;
     const uint32_t stride = (uint32_t)LocalCfg<WT>::kTile - margin;
@@ -1518,12 +1558,12 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     LocalPlan lp;
     lp.low_plan = d_plan;
     lp.n_low = (int)low.size();
-    lp.P = P;
+    lp.T = T;
     // the comparison route is skipped for a few sorts after one that found mostly long runs (highly redundant input)
     const bool skip_a = ctx->lsd_skip_left > 0;
     if (skip_a) --ctx->lsd_skip_left;
-    const int ub = ((ctx->force_lsd_tiles & 1) || skip_a) ? 0 : std::max(0, std::min(8, (WT > 1 ? 40 : 32) - 8 * P));
-    lp.upper = Digit{32 * WT - 8 * P - ub, ub};
+    const int ub = ((ctx->force_lsd_tiles & 1) || skip_a) ? 0 : std::max(0, std::min(8, (WT > 1 ? 40 : 32) - T));
+    lp.upper = Digit{32 * WT - T - ub, ub};
     lp.mask_last2 = mask_last2;
     lp.mask_last = mask_last;
     lp.stride = stride;
@@ -1553,7 +1593,7 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     if (n_big > 0) {
         // segments that did not fit a tile next to their neighbours: alone in LDS if they fit, else (hot k-mers, or the whole array
         // when it is tiny) one workgroup each with global ping-pong passes
-        hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, P, d_big, d_big + big_cap);
+        hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, T, d_big, d_big + big_cap);
         hipLaunchKernelGGL((local_lsd_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, d_big, d_big + big_cap, 1, lp);
         hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
                            (int)low.size(), (uint32_t)LocalCfg<WT>::kTile);
@@ -1648,9 +1688,9 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             hipLaunchKernelGGL((s1_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
             // sort on: key characters + head/tail (key words), then prev/next (low 6 bits of the payload); positions are ignored
             const int pad1 = 32 * W - 2 * (k - 1) - 6;
-            auto low_plan = [&](int P) {
+            auto low_plan = [&](int T) {
                 std::vector<Digit> plan;
-                int top = 32 * WT - 8 * P;
+                int top = 32 * WT - T;
                 plan.push_back(Digit{0, 6});
                 if (top > 64) plan.push_back(Digit{64, std::min(6, top - 64)});
                 for (int pos = 64 + 6 + pad1; pos < top; pos += 8) plan.push_back(Digit{pos, std::min(8, top - pos)});
@@ -1692,9 +1732,9 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         if (n_cand > mercy_cap) { set_error("mercy candidate list overflow"); return MGTA_ENOMEM; }
         if (n_cand > 0) {
             Key<2> *d_tmp = pool_get<Key<2>>(ctx, S_KEYS_A, n_cand * 8);
-            auto low64 = [&](int P) {
+            auto low64 = [&](int T) {
                 std::vector<Digit> plan;
-                for (int pos = 0; pos < 64 - 8 * P; pos += 8) plan.push_back(Digit{pos, std::min(8, 64 - 8 * P - pos)});
+                for (int pos = 0; pos < 64 - T; pos += 8) plan.push_back(Digit{pos, std::min(8, 64 - T - pos)});
                 return plan;
             };
             Key<2> *cs = device_sort<2>(ctx, stream, d_mercy, d_tmp, n_cand, 4, low64, nullptr, nullptr);
@@ -1838,7 +1878,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             const int max_top = (2 * k + 4 + 7) / 8 > 1 ? std::min(4, (32 * W - 8) / 8) : 0;
             const double prefix_frac = (double)(b_hi - b_lo) / MGTA_NUM_BUCKETS;
             // closed form + at least one global sort pass: the key writer works tile by tile of that pass and leaves its census behind
-            const int P_top = choose_top_bytes(ctx, n_items, max_top, prefix_frac);
+            const int P_top = choose_top_plan(ctx, n_items, max_top, prefix_frac).P;
             static const bool tiled_keygen = !(getenv("MGTA_KEYGEN_TILED") && atoi(getenv("MGTA_KEYGEN_TILED")) == 0);
             const bool fused_census = closed_form && P_top >= 1 && tiled_keygen && n_tiles <= 0x7FFFFFFFull;
             if (fused_census) {
@@ -1852,8 +1892,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             S.ms_gen += t_ph.stop();
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
-            Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int P) { return low_digit_plan(k, W, P); }, &scatter_ev, &S,
-                                           prefix_frac, ~0u, ~0u, fused_census);
+            Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int T) { return low_digit_plan(k, W, T); }, &scatter_ev, &S,
+                                           prefix_frac, ~0u, ~0u, fused_census, b_lo, b_hi);
             if (!src) return MGTA_EUNSUPPORTED;
             Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();
