@@ -1478,7 +1478,9 @@ static TopPlan choose_top_plan(const mgta_ctx *ctx, uint64_t n_items, int max_to
         return P;
     };
     plain.P = passes(prefix_frac, 0);
-    static const int mode = getenv("MGTA_SORT_BIAS") ? atoi(getenv("MGTA_SORT_BIAS")) : 1;    // 0 never, 1 when it saves a pass, 2 whenever valid (tests)
+    // 0 never, 1 (default) when it saves a pass and leaves short segments, 2 whenever valid (tests); read per call: scripts flip it between builds
+    const char *mode_env = getenv("MGTA_SORT_BIAS");
+    const int mode = mode_env ? atoi(mode_env) : 1;
     if (mode == 0 || b_hi <= b_lo || (b_lo == 0 && b_hi >= (uint32_t)MGTA_NUM_BUCKETS)) return plain;
     const uint32_t span = ((b_hi - b_lo) << 16) - 1u;                  // largest biased word 0
     const int skip_full = __builtin_clz(span | 1u);
@@ -1486,7 +1488,11 @@ static TopPlan choose_top_plan(const mgta_ctx *ctx, uint64_t n_items, int max_to
         const int skip = std::min(skip_full, 32 - 8 * P);
         if (skip <= 0 || 8 * P + skip < 16) continue;
         const double frac = std::min(1.0, prefix_frac * std::pow(2.0, skip));
-        if (P < max_top && avg_segment_len(n_items, P, frac) > (P >= 3 ? 700.0 : 256.0)) continue;
+        // measured at 100 M reads (7.2 G keys per pass, a third of the buckets): three biased passes leave 645-key segments and the LDS
+        // finish then costs 170 ms instead of 100 ms — exactly what the fourth scatter + census (45 + 17 ms) would have cost.  The pass is
+        // only worth skipping when the segments stay short (<= 400 keys).
+        const double limit = mode >= 2 ? (P >= 3 ? 700.0 : 256.0) : (P >= 3 ? 400.0 : 256.0);
+        if (P < max_top && avg_segment_len(n_items, P, frac) > limit) continue;
         if (P < plain.P || (mode >= 2 && P <= plain.P)) {
             TopPlan b;
             b.P = P; b.skip = skip; b.bias = b_lo << 16; b.frac = frac;
