@@ -330,7 +330,7 @@ struct Digit {
                      // where word 0 - (first bucket << 16) has leading zero bits that the digits skip)
 };
 
-template <int W>
+template <int W, bool BIASED = false>          // BIASED: honour d.bias (only the global passes of a sub-range build set it)
 __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
     // the word is picked by a wave-uniform branch on compile-time indices: a run-time index into key.w[] would push every
     // register-resident key of the caller into scratch memory, and a chain of selects costs 2W VALU ops per key
@@ -340,8 +340,8 @@ __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
         if (j == wi) {
-            lo = key.w[j] - (j == 0 ? d.bias : 0u);
-            hi = j > 0 ? key.w[j - 1] - (j == 1 ? d.bias : 0u) : 0u;
+            lo = key.w[j] - (BIASED && j == 0 ? d.bias : 0u);
+            hi = j > 0 ? key.w[j - 1] - (BIASED && j == 1 ? d.bias : 0u) : 0u;
             asm volatile("" : "+v"(lo), "+v"(hi));
         }
     }
@@ -349,7 +349,7 @@ __device__ __forceinline__ uint32_t get_digit(const Key<W> &key, Digit d) {
 }
 
 // the same digit of N register-resident keys: one wave-uniform branch chain for all of them
-template <int W, int N>
+template <int W, int N, bool BIASED = false>
 __device__ __forceinline__ void get_digits(const Key<W> (&key)[N], Digit d, uint32_t (&dg)[N]) {
     const int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
     uint32_t lo[N], hi[N];
@@ -360,8 +360,8 @@ __device__ __forceinline__ void get_digits(const Key<W> (&key)[N], Digit d, uint
         if (j == wi) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                lo[i] = key[i].w[j] - (j == 0 ? d.bias : 0u);
-                hi[i] = j > 0 ? key[i].w[j - 1] - (j == 1 ? d.bias : 0u) : 0u;
+                lo[i] = key[i].w[j] - (BIASED && j == 0 ? d.bias : 0u);
+                hi[i] = j > 0 ? key[i].w[j - 1] - (BIASED && j == 1 ? d.bias : 0u) : 0u;
                 asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
             }
         }
@@ -519,7 +519,7 @@ struct ScatterShared {
 
 // stable scatter of in[0..n) by digit d to out[gbase[digit]++...], sub-tile by sub-tile (gbase must be set and visible; all threads
 // call).  Four workgroup barriers per sub-tile; the next sub-tile's keys are on their way while the current one is placed.
-template <int W>
+template <int W, bool BIASED = false>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];               // wave-private row, updated lane-to-lane inside the wave
@@ -538,7 +538,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
         uint32_t n_valid = (uint32_t)((n - sub_base) < (uint64_t)kSubTile ? (n - sub_base) : (uint64_t)kSubTile);
         // phase 1: rank inside the wave chunk: digit + peers of every key, then the wave's running counts round by round
         uint32_t dr[kItemsPerThread], cnt[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
-        get_digits<W, kItemsPerThread>(key, d, dr);
+        get_digits<W, kItemsPerThread, BIASED>(key, d, dr);
 #pragma unroll
         for (int it = 0; it < kItemsPerThread; ++it) {
             uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
                 uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
                 if (j < n_valid) kk[it] = sh.keys[j];
             }
-            get_digits<W, kItemsPerThread>(kk, d, dg);
+            get_digits<W, kItemsPerThread, BIASED>(kk, d, dg);
 #pragma unroll
             for (int it = 0; it < kItemsPerThread; ++it) {
                 uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
@@ -611,7 +611,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
                 uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
                 if (j < n_valid) {
                     Key<W> kk = sh.keys[j];
-                    out[sh.gdelta[get_digit<W>(kk, d)] + j] = kk;
+                    out[sh.gdelta[get_digit<W, BIASED>(kk, d)] + j] = kk;
                 }
             }
             if (sub_base + kSubTile < n) load(key, sub_base + kSubTile);
@@ -620,7 +620,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 }
 
 // stable scatter of one 32768-key tile by the current digit
-template <int W>
+template <int W, bool BIASED>
 __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
                                                                       const uint64_t *totals) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Ke
     const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
     if (tile_base >= n) return;
     const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
-    scatter_subtiles<W>(sh, in + tile_base, out, cnt, d);
+    scatter_subtiles<W, BIASED>(sh, in + tile_base, out, cnt, d);
 }
 
 // One workgroup sorts ONE oversized segment [big[b], big_end[b]) on all the low digits: census, scan and scatter of
@@ -1524,8 +1524,12 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             MGTA_HIP_CHECK(hipEventCreate(&e1));
             MGTA_HIP_CHECK(hipEventRecord(e0, stream));
         }
-        hipLaunchKernelGGL((radix_scatter_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
-                           d_totals);
+        if (dg.bias)
+            hipLaunchKernelGGL((radix_scatter_kernel<WT, true>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+                               d_totals);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<WT, false>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
+                               d_totals);
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
             scatter_ev->emplace_back(e0, e1);
