@@ -112,6 +112,7 @@ struct ScanArgs {
     const unsigned long long *is_solid;    // stage-1 verdicts (bit num_k1_per_read*read + position), nullptr = every position solid
     int num_k1_per_read;
     uint64_t n_short;                      // reads >= n_short (assist sequences) are always solid (s2.cpp:276)
+    unsigned long long *n_sentinel;        // closed-form writers, k+1 even: number of sentinel keys written (see item_write_closed_kernel)
     uint32_t multi_width, multi_n;         // count mode: multi_n > 0 counts multi_n consecutive bucket ranges of multi_width buckets from
                                            // b_lo in one scan: block_count[range * gridDim.x + workgroup]
 };
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
 // Key generation when the item layout is known in closed form (k+1 odd: no palindromes; every position solid; every bucket
 // wanted): read r owns 2 npos + 4 consecutive keys [left $ of e, left $ of rc, then (e, rc) of every position, right $ of e,
 // right $ of rc], so every lane stores its two keys at a fixed place: no staging, no prefix sums, fully coalesced 24-byte pairs.
+// With k+1 even a (k+1)-mer can be its own reverse complement; the reference then emits the forward items only (s2.cpp:278).  The
+// layout stays closed: the rc slot of such a position takes a SENTINEL key (all ones: larger than any real key, whose low three bits
+// are a character code <= 4), the sentinels are counted, end up behind every real key in the sorted array and the emitter stops
+// before them.
 template <int W>
 __global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs a) {
     __shared__ uint32_t s_read_base[kReadsPerBlock];
@@ -275,15 +280,33 @@ __global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs 
             for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
             shl_bits<W>(rc, pad_bits);
             const int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+            bool pal = false;                                           // s2.cpp:278 (only possible when k+1 is even)
+            if (!((k + 1) & 1)) {
+                pal = true;
+#pragma unroll
+                for (int j = 0; j < W; ++j) pal = pal && e[j] == rc[j];
+            }
+            Key<W> sentinel;
+#pragma unroll
+            for (int j = 0; j < W; ++j) sentinel.w[j] = ~0u;
             ro[2 + 2 * p] = make_key<W>(e, 1, k, k, e0);                 // solid   (s2.cpp:543-550)
-            ro[3 + 2 * p] = make_key<W>(rc, 1, k, k, r0c);
+            ro[3 + 2 * p] = pal ? sentinel : make_key<W>(rc, 1, k, k, r0c);
             if (p == 0) {                                               // left $  (s2.cpp:531-540)
                 ro[0] = make_key<W>(e, 0, k, k, kDollar);
-                ro[1] = make_key<W>(rc, 2, k - 1, k, r1c);
+                ro[1] = pal ? sentinel : make_key<W>(rc, 2, k - 1, k, r1c);
             }
             if (p == npos - 1) {                                        // right $ (s2.cpp:553-562)
                 ro[2 + 2 * npos] = make_key<W>(e, 2, k - 1, k, e1);
-                ro[3 + 2 * npos] = make_key<W>(rc, 0, k, k, kDollar);
+                ro[3 + 2 * npos] = pal ? sentinel : make_key<W>(rc, 0, k, k, kDollar);
+            }
+            const unsigned long long pm = __ballot(pal);                 // rare: one atomic per wave that saw any
+            if (pm && lane == __ffsll((long long)pm) - 1) {
+                unsigned long long c = 0;
+                for (unsigned long long m = pm; m; m &= m - 1) {
+                    const int l = __ffsll((long long)m) - 1, pp = c0 + l;
+                    c += 1ull + (pp == 0) + (pp == npos - 1);
+                }
+                atomicAdd(a.n_sentinel, c);
             }
         }
     }
@@ -465,6 +488,12 @@ __global__ __launch_bounds__(kScanBlock) void item_write_tiled_kernel(ScanArgs a
                 for (int i = 0; i < W; ++i) rc[i] = rev_chars(~e[W - 1 - i]);
                 shl_bits<W>(rc, pad_bits);
                 const int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+                bool pal = false;                                       // s2.cpp:278: the rc slot takes a sentinel (item_write_closed_kernel)
+                if (!((k + 1) & 1)) {
+                    pal = true;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) pal = pal && e[i] == rc[i];
+                }
                 Key<W> ka, kb;
                 if (j == 0) {                                           // left $  (s2.cpp:531-540)
                     ka = make_key<W>(e, 0, k, k, kDollar);
@@ -476,6 +505,12 @@ __global__ __launch_bounds__(kScanBlock) void item_write_tiled_kernel(ScanArgs a
                     ka = make_key<W>(e, 1, k, k, e0);
                     kb = make_key<W>(rc, 1, k, k, r0c);
                 }
+                if (pal) {
+#pragma unroll
+                    for (int i = 0; i < W; ++i) kb.w[i] = ~0u;
+                }
+                const unsigned long long pm = __ballot(pal);
+                if (pm && lane == __ffsll((long long)pm) - 1) atomicAdd(a.n_sentinel, (unsigned long long)__popcll(pm));
                 ro[2 * j] = ka;
                 ro[2 * j + 1] = kb;
                 atomicAdd(&s_hist[(ka.w[0] >> digit_shift) & 255u], 1u);
@@ -1784,13 +1819,14 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
     uint32_t *d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
     uint64_t *d_block_base = pool_get<uint64_t>(ctx, S_BLOCK_BASE, std::max<uint64_t>(1, n_blocks) * 8);
-    uint64_t *d_small = pool_get<uint64_t>(ctx, S_SMALL, 4096);       // [0] total, [1] kmers, [2..4] emit totals, [8..263] digit totals
-    uint64_t *d_total = d_small, *d_kmers = d_small + 1, *d_tot3 = d_small + 2;
+    uint64_t *d_small = pool_get<uint64_t>(ctx, S_SMALL, 4096);       // [0] total, [1] kmers, [2..4] emit totals, [5] sentinels, [8..263] digit totals
+    uint64_t *d_total = d_small, *d_kmers = d_small + 1, *d_tot3 = d_small + 2, *d_sentinel = d_small + 5;
 
     ScanArgs sa;
     sa.packed = rd->d_packed; sa.n_words = rd->n_words; sa.start = rd->d_start; sa.n_reads = n_reads; sa.k = k;
     sa.block_count = d_block_count; sa.block_base = d_block_base; sa.out = nullptr;
     sa.n_kmers = (unsigned long long *)d_kmers;
+    sa.n_sentinel = (unsigned long long *)d_sentinel;
     sa.is_solid = nullptr; sa.num_k1_per_read = 0; sa.n_short = n_short;
     if (min_count > 1) {
         unsigned long long *sol = nullptr;
@@ -1831,7 +1867,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         else sa.n_kmers = nullptr;
         uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
         static_assert(kReadsPerBlock == 64, "item_count_closed_kernel: one lane per read of a workgroup");
-        const bool closed_form = ((k + 1) & 1) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
+        static const bool closed_even = !(getenv("MGTA_CLOSED_EVEN") && atoi(getenv("MGTA_CLOSED_EVEN")) == 0);   // 0: k+1 even takes the scans
+        const bool closed_form = (((k + 1) & 1) || closed_even) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
         const uint32_t *counts = d_block_count;
         sa.multi_n = 0; sa.multi_width = 0;
         if (n_blocks && closed_form)
@@ -1891,6 +1928,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             const int P_top = choose_top_plan(ctx, n_items, max_top, prefix_frac).P;
             static const bool tiled_keygen = !(getenv("MGTA_KEYGEN_TILED") && atoi(getenv("MGTA_KEYGEN_TILED")) == 0);
             const bool fused_census = closed_form && P_top >= 1 && tiled_keygen && n_tiles <= 0x7FFFFFFFull;
+            if (closed_form) MGTA_HIP_CHECK(hipMemsetAsync(d_sentinel, 0, 8, stream));
             if (fused_census) {
                 uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);   // the buffer device_sort uses
                 hipLaunchKernelGGL((item_write_tiled_kernel<W>), dim3((unsigned)n_tiles), dim3(kScanBlock), 0, stream, sa, n_blocks, n_items,
@@ -1907,6 +1945,14 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             if (!src) return MGTA_EUNSUPPORTED;
             Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();
+            if (closed_form && !((k + 1) & 1)) {
+                // sentinel keys (rc slots of palindromic (k+1)-mers) sorted behind every real key: the emitter stops before them
+                unsigned long long n_sent = 0;
+                MGTA_HIP_CHECK(hipMemcpy(&n_sent, d_sentinel, 8, hipMemcpyDeviceToHost));
+                if (n_sent >= n_items) { set_error("internal: %llu sentinel keys among %llu items", n_sent, (unsigned long long)n_items); return MGTA_EINTERNAL; }
+                n_items -= n_sent;
+                S.n_items -= (int64_t)n_sent;
+            }
             // ---- 5. emit.  `src` holds the sorted keys; the other buffer is scratch.
             t_ph.start();
             const Key<W> *sorted = src;

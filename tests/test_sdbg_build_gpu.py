@@ -377,3 +377,32 @@ def test_tiled_key_writer_many_tiles_vs_oracle(ctx, oracle, k):
     assert g.stats["n_items"] > 40 * 32768
     o = oracle.Stream.build(packed, start, k, threads=8).edges()
     _same(g, o)
+
+
+@pytest.mark.parametrize("k", [21, 29, 35, 43])
+def test_closed_form_even_k1_palindromes_vs_oracle(ctx, oracle, k):
+    """k+1 even: a (k+1)-mer can equal its reverse complement (s2.cpp:278: forward items only).  The closed-form key layout keeps the rc
+    slot of such a position and fills it with a sentinel key that sorts behind every real key; (AT)n / (CG)n / (ACGT)n stretches, whole
+    reads of them, stretches at read ends (the $ items) and poly-T next to the sentinels' prefix"""
+    rng = np.random.default_rng(7000 + k)
+    reads = []
+    at, cg, acgt = np.array([0, 3], np.uint8), np.array([1, 2], np.uint8), np.array([0, 1, 2, 3], np.uint8)
+    for i in range(6000):
+        L = int(rng.integers(k - 2, 220))
+        r = rng.integers(0, 4, L).astype(np.uint8)
+        u = rng.random()
+        if u < 0.25:
+            unit = (at, cg, acgt)[int(rng.integers(0, 3))]
+            n = int(rng.integers(k + 1, max(k + 2, L)))
+            p = int(rng.integers(0, max(1, L - n + 1))) if rng.random() < 0.6 else (0 if rng.random() < 0.5 else max(0, L - n))
+            rep = np.tile(unit, n // unit.size + 2)[int(rng.integers(0, unit.size)):][:min(n, L - p)]
+            r[p:p + rep.size] = rep
+        elif u < 0.3:
+            r[:] = 3                                                    # poly-T: shares every leading byte with the sentinel
+        elif u < 0.35:
+            r = np.tile(at, L)[:L].copy()                               # every position palindromic
+        reads.append(r)
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k)
+    o = oracle.Stream.build(packed, start, k, threads=8).edges()
+    _same(g, o)
