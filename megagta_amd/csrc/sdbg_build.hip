@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     }
 }
 
-// Key generation when the item layout is known in closed form (k+1 odd: no palindromes; every position solid; every bucket
+// Key generation when the item layout is known in closed form (every position solid; k+1 odd: no palindromes, k+1 even: see below; every bucket
 // wanted): read r owns 2 npos + 4 consecutive keys [left $ of e, left $ of rc, then (e, rc) of every position, right $ of e,
 // right $ of rc], so every lane stores its two keys at a fixed place: no staging, no prefix sums, fully coalesced 24-byte pairs.
 // With k+1 even a (k+1)-mer can be its own reverse complement; the reference then emits the forward items only (s2.cpp:278).  The
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kScanBlock) void item_write_closed_kernel(ScanArgs 
     }
 }
 
-// Items per workgroup of item_scan_kernel in closed form.  With k+1 odd no (k+1)-mer equals its reverse complement, so when
+// Items per workgroup of item_scan_kernel in closed form.  With k+1 odd no (k+1)-mer equals its reverse complement (with k+1 even the
+// slot of the missing item takes a sentinel key, item_write_closed_kernel), so when
 // every position is solid and every bucket is wanted a read with npos = len - k >= 1 positions yields exactly
 // 2 npos + 4 items (two per position, two more at each end of the read): no edge has to be built to count them.
 __global__ __launch_bounds__(256) void item_count_closed_kernel(const uint64_t *start, uint64_t n_reads, uint64_t n_blocks, int k,
