@@ -48,6 +48,11 @@ int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
  * 2 = the segment-local sort runs LSD passes over every remaining digit instead of finishing short runs by comparison
  *     (also the fallback for tiles whose runs are long) */
 int mgta_ctx_set_full_lsd(mgta_ctx *, int on);
+/* diagnostic, host only (no device needed): the global sort passes a build of `n_items` keys of `words_per_key` 32-bit words over the
+ * buckets [bucket_begin, bucket_end) takes: *n_passes 8-bit digits taken below *skip_bits leading bits that every key of the range shares
+ * once (bucket_begin << 16) is subtracted from key word 0 (0 for a whole-range build); the segment-local finish then sees segments of
+ * equal leading 8 * n_passes + skip_bits bits.  Honours MGTA_SORT_BIAS. */
+int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, uint32_t bucket_end, int *n_passes, int *skip_bits);
 /* Shared-cache searches (mgta_astar_batch with cache_mode = B >= 1): the path found by seed j after c_j node expansions is seen by
  * exactly the seeds >= j + B + c_j / expansions_per_seed.  0 (default) = no cost term: seed i sees the seeds <= i - B, and every
  * later seed waits for the longest unfinished search.  > 0: a search that has already run r expansions cannot become visible to the

@@ -68,6 +68,7 @@ SYMBOLS = {
     "mgta_ctx_destroy": (None, [C.c_void_p]),
     "mgta_ctx_set_mem_limit": (C.c_int, [C.c_void_p, C.c_uint64]),
     "mgta_ctx_set_full_lsd": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgta_sort_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mgta_reads_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mgta_reads_adopt_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mgta_reads_free": (None, [C.c_void_p]),

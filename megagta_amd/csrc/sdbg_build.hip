@@ -1507,7 +1507,7 @@ struct TopPlan {
 static TopPlan choose_top_plan(const mgta_ctx *ctx, uint64_t n_items, int max_top, double prefix_frac, uint32_t b_lo = 0, uint32_t b_hi = 0) {
     TopPlan plain;
     plain.frac = prefix_frac;
-    if (ctx->force_full_lsd) return plain;
+    if (ctx && ctx->force_full_lsd) return plain;
     auto passes = [&](double frac_of, int p_min) {
         int P = p_min;
         while (P < max_top && avg_segment_len(n_items, P, frac_of) > (P >= 3 ? 700.0 : 256.0)) ++P;
@@ -2132,6 +2132,18 @@ int mgta_sdbg_last_counting(mgta_ctx *ctx, int64_t *hist) {
     if (!ctx || !hist) { set_error("mgta_sdbg_last_counting: null argument"); return MGTA_EINVAL; }
     if (ctx->edge_counting.size() != 65536) { set_error("no stage-1 run (min_count > 1) on this context yet"); return MGTA_EINVAL; }
     std::copy(ctx->edge_counting.begin(), ctx->edge_counting.end(), hist);
+    return MGTA_OK;
+}
+
+int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, uint32_t bucket_end, int *n_passes, int *skip_bits) {
+    if (!n_passes || !skip_bits || words_per_key < 2 || bucket_end > (uint32_t)MGTA_NUM_BUCKETS || bucket_begin >= bucket_end) {
+        set_error("mgta_sort_plan: bad argument");
+        return MGTA_EINVAL;
+    }
+    const TopPlan tp = choose_top_plan(nullptr, n_items, std::min(4, (32 * words_per_key - 8) / 8), (double)(bucket_end - bucket_begin) / MGTA_NUM_BUCKETS,
+                                       bucket_begin, bucket_end);
+    *n_passes = tp.P;
+    *skip_bits = tp.skip;
     return MGTA_OK;
 }
 

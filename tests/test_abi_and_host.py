@@ -66,3 +66,59 @@ def test_sdbg_files_roundtrip(tmp_path, oracle, golden_dir):
         back = api.read_sdbg(prefix)
         assert back.md5() == s.md5()
         assert oracle.Stream.read(prefix).edges().md5() == s.md5()
+
+
+def _plan(n_items, W, b0, b1, mode=None):
+    L = _lib.load()
+    old = os.environ.get("MGTA_SORT_BIAS")
+    try:
+        if mode is None:
+            os.environ.pop("MGTA_SORT_BIAS", None)
+        else:
+            os.environ["MGTA_SORT_BIAS"] = str(mode)
+        P, s = ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.mgta_sort_plan(n_items, W, b0, b1, ctypes.byref(P), ctypes.byref(s)), "mgta_sort_plan")
+        return P.value, s.value
+    finally:
+        os.environ.pop("MGTA_SORT_BIAS", None)
+        if old is not None:
+            os.environ["MGTA_SORT_BIAS"] = old
+
+
+def test_sort_plan_of_sub_range_builds():
+    """host logic of the global sort passes (no device): the digits of a bucket sub-range build skip the leading bits its keys share, but
+    only where that saves a pass and leaves short segments; the measured cases of DESIGN.md §5"""
+    assert _plan(2_160_000_000, 3, 0, 65536) == (3, 0)                       # 10 M reads, one pass over every bucket
+    assert _plan(2_160_000_000, 3, 0, 65536, mode=2) == (3, 0)               # nothing to skip in a whole-range build
+    third = (65536 + 2) // 3
+    assert _plan(7_200_000_000, 3, 0, third) == (4, 0)                       # 100 M reads, full memory: 645-key segments are not worth a pass
+    assert _plan(7_200_000_000, 3, 0, third, mode=2) == (3, 1)
+    assert _plan(7_200_000_000, 3, 0, third, mode=0) == (4, 0)
+    w11 = (65536 + 10) // 11
+    assert _plan(1_963_636_363, 3, 3 * w11, 4 * w11) == (3, 3)               # 100 M reads under 64 GB: 11 ranges, 161-key segments
+    assert _plan(1_963_636_363, 3, 3 * w11, 4 * w11, mode=0) == (4, 0)
+    assert _plan(185_000, 3, 777, 778) == (2, 16)                            # one crowded bucket: two digits below the 16 bucket bits
+    assert _plan(185_000, 3, 777, 778, mode=0) == (4, 0)
+    assert _plan(100, 3, 0, 65536) == (0, 0)
+    rng = np.random.default_rng(11)
+    for _ in range(3000):                                                    # invariants: prefix of 16..32 bits whenever bits are skipped
+        b0 = int(rng.integers(0, 65536))
+        b1 = int(rng.integers(b0 + 1, 65537))
+        n = int(10 ** rng.uniform(1, 10.5))
+        W = int(rng.integers(2, 10))
+        for mode in (0, 1, 2):
+            P, s = _plan(n, W, b0, b1, mode)
+            assert 0 <= P <= 4 and 0 <= s <= 24
+            if mode == 0 or (b0 == 0 and b1 == 65536):
+                assert s == 0
+            if s:
+                assert 16 <= 8 * P + s <= 32 and ((b1 - b0) << 16) - 1 < (1 << (32 - s))
+        assert _plan(n, W, b0, b1, 1)[0] <= _plan(n, W, b0, b1, 0)[0]        # the bias never adds a pass
+
+
+def test_sort_plan_rejects_bad_arguments():
+    L = _lib.load()
+    P, s = ctypes.c_int(), ctypes.c_int()
+    assert L.mgta_sort_plan(10, 3, 5, 5, ctypes.byref(P), ctypes.byref(s)) != 0
+    assert L.mgta_sort_plan(10, 3, 0, 70000, ctypes.byref(P), ctypes.byref(s)) != 0
+    assert L.mgta_sort_plan(10, 1, 0, 65536, ctypes.byref(P), ctypes.byref(s)) != 0
