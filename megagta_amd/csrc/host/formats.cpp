@@ -107,18 +107,29 @@ struct FastxReader::Impl {
     gzFile f = nullptr;
     std::string path, line, pending;     // pending: a header line already consumed
     bool have_pending = false, eof = false;
+    std::vector<char> buf = std::vector<char>(1 << 20);              // inflated text, refilled by gzread; lines are cut out of it with memchr
+    size_t pos = 0, len = 0;
+    bool fill() {
+        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) return false;
+        pos = 0; len = (size_t)n;
+        return true;
+    }
+    // one line without its '\n' (and without a '\r' before it); false at the end of the file unless text without a final '\n' is left
     bool getline(std::string &out) {
         out.clear();
-        char buf[65536];
         for (;;) {
-            if (!gzgets(f, buf, sizeof(buf))) return !out.empty();
-            size_t n = strlen(buf);
-            if (n && buf[n - 1] == '\n') {
-                out.append(buf, n - 1);
+            if (pos == len && !fill()) return !out.empty();
+            const char *p = buf.data() + pos;
+            const char *nl = static_cast<const char *>(memchr(p, '\n', len - pos));
+            if (nl) {
+                out.append(p, (size_t)(nl - p));
+                pos = (size_t)(nl - buf.data()) + 1;
                 if (!out.empty() && out.back() == '\r') out.pop_back();
                 return true;
             }
-            out.append(buf, n);
+            out.append(p, len - pos);
+            pos = len;
         }
     }
 };
@@ -127,6 +138,7 @@ FastxReader::FastxReader(const std::string &path) : p_(new Impl) {
     p_->path = path;
     p_->f = gzopen(path.c_str(), "rb");
     if (!p_->f) die("cannot open %s", path.c_str());
+    gzbuffer(p_->f, 1u << 20);
 }
 FastxReader::~FastxReader() {
     if (p_->f) gzclose(p_->f);
@@ -136,15 +148,15 @@ FastxReader::~FastxReader() {
 // one record: a header line ('>' or '@'), sequence lines up to the next line that starts with '>', '@' or '+'; after '+' as many
 // quality characters as the sequence has are skipped (kseq.h kseq_read).  Codes: sequence_package.h:67-69 (N -> G)
 bool FastxReader::next(std::vector<uint8_t> &codes) {
-    static const auto code = [](char c) -> uint8_t {
-        switch (c) {
-        case 'A': case 'a': return 0;
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': case 'N': case 'n': return 2;
-        case 'T': case 't': return 3;
-        default: return 0;                                   // (the reference indexes an uninitialised table here)
+    static const struct CodeTable {
+        uint8_t t[256];
+        CodeTable() {
+            memset(t, 0, sizeof(t));                         // anything else: 0 (the reference indexes an uninitialised table here)
+            t[(int)'C'] = t[(int)'c'] = 1;
+            t[(int)'G'] = t[(int)'g'] = t[(int)'N'] = t[(int)'n'] = 2;
+            t[(int)'T'] = t[(int)'t'] = 3;
         }
-    };
+    } code;
     codes.clear();
     Impl &r = *p_;
     if (r.eof) return false;
@@ -165,7 +177,9 @@ bool FastxReader::next(std::vector<uint8_t> &codes) {
             while (got < codes.size() && r.getline(r.line)) got += r.line.size();
             return true;
         }
-        for (char ch : r.line) codes.push_back(code(ch));
+        const size_t at = codes.size();
+        codes.resize(at + r.line.size());
+        for (size_t i = 0; i < r.line.size(); ++i) codes[at + i] = code.t[(unsigned char)r.line[i]];
     }
 }
 
@@ -192,7 +206,14 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix) 
     auto write_read = [&](const std::vector<uint8_t> &c, int &max_len) {
         const uint32_t len = (uint32_t)c.size();
         words.assign((len + 15) / 16, 0u);
-        for (uint32_t i = 0; i < len; ++i) words[i >> 4] |= (uint32_t)c[i] << (30 - 2 * (i & 15));
+        const uint8_t *cp = c.data();
+        uint32_t i = 0;
+        for (; i + 16 <= len; i += 16) {
+            uint32_t w = 0;
+            for (int j = 0; j < 16; ++j) w = (w << 2) | cp[i + j];
+            words[i >> 4] = w;
+        }
+        for (; i < len; ++i) words[i >> 4] |= (uint32_t)cp[i] << (30 - 2 * (i & 15));
         fwrite(&len, 4, 1, bin);
         if (!words.empty()) fwrite(words.data(), 4, words.size(), bin);
         ++total_reads;

@@ -33,3 +33,26 @@ def test_buildlib_matches_reference(tmp_path, golden_dir):
     assert r.returncode != 0 and "Valid types" in r.stderr
     r = subprocess.run([BIN, "buildlib"], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage" in r.stderr
+
+
+def test_buildlib_reader_across_buffer_refills(tmp_path):
+    """the FASTA/FASTQ reader cuts lines out of 1 MiB refills: a file of several refills with CRLF line ends and no final newline gives
+    the records the format defines (uint32 length + ceil(len / 16) words, base j of a word at bits 30 - 2j)"""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    n, L = 30_000, 101
+    codes = rng.integers(0, 4, (n, L)).astype(np.uint8)
+    text = "\r\n".join(f">r{i}\r\n" + "".join("ACGT"[c] for c in codes[i]) for i in range(n))       # ~3.4 MB, no newline at the end
+    open(tmp_path / "big.fa", "w", newline="").write(text)
+    open(tmp_path / "big.lib", "w").write(f"big\nse {tmp_path}/big.fa\n")
+    r = subprocess.run([BIN, "buildlib", str(tmp_path / "big.lib"), str(tmp_path / "big")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nw = (L + 15) // 16
+    padded = np.zeros((n, nw * 16), np.uint32)
+    padded[:, :L] = codes
+    words = (padded.reshape(n, nw, 16) << (30 - 2 * np.arange(16, dtype=np.uint32))).sum(axis=2, dtype=np.uint32)
+    rec = np.empty((n, nw + 1), np.uint32)
+    rec[:, 0] = L
+    rec[:, 1:] = words
+    assert open(tmp_path / "big.bin", "rb").read() == rec.tobytes()
+    assert open(tmp_path / "big.lib_info").read().splitlines()[0] == f"{n * L} {n}"
