@@ -45,6 +45,27 @@ void PackedReads::append(const uint8_t *codes, size_t n, bool reverse) {
     start.push_back(n_bases_);
     max_len = std::max<int>(max_len, (int)n);
 }
+// the same as append() of the unpacked codes, 16 bases at a time
+void PackedReads::append_packed(const uint32_t *w, size_t n, bool reverse) {
+    if (start.empty()) start.push_back(0);
+    const size_t nw = (n + 15) / 16;
+    const int tail = (int)(n - (nw ? (nw - 1) * 16 : 0));               // bases in the last word (1..16), 0 for an empty read
+    auto rev16 = [](uint32_t x) {                                       // the 16 characters of a word in reverse order
+        x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+        x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+        return __builtin_bswap32(x);
+    };
+    if (reverse) {
+        if (nw) push_bits(rev16(w[nw - 1]), 2 * tail);                  // its characters end up in the low 2 * tail bits
+        for (size_t j = nw - 1; j-- > 0;) push_bits(rev16(w[j]), 32);
+    } else {
+        for (size_t j = 0; j + 1 < nw; ++j) push_bits(w[j], 32);
+        if (nw) push_bits(tail == 16 ? w[nw - 1] : w[nw - 1] >> (32 - 2 * tail), 2 * tail);
+    }
+    n_bases_ += n;
+    start.push_back(n_bases_);
+    max_len = std::max<int>(max_len, (int)n);
+}
 void PackedReads::finish() {
     if (start.empty()) start.push_back(0);
     if (acc_bits_ > 0) { words.push_back((uint32_t)(acc_ << (32 - acc_bits_))); acc_ = 0; acc_bits_ = 0; }
@@ -57,19 +78,17 @@ void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out) {
     if (!(info >> total_bases >> num_reads)) die("cannot read %s.lib_info", prefix.c_str());
     FILE *f = fopen((prefix + ".bin").c_str(), "rb");
     if (!f) die("cannot open %s.bin", prefix.c_str());
+    setvbuf(f, nullptr, _IOFBF, 1 << 20);
     out.words.reserve((size_t)total_bases / 16 + 16);
     out.start.reserve((size_t)num_reads + 2);
     std::vector<uint32_t> w;
-    std::vector<uint8_t> codes;
     for (long long r = 0; r < num_reads; ++r) {
         uint32_t len;
         if (fread(&len, 4, 1, f) != 1) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
         size_t nw = (len + 15) / 16;
         w.resize(nw);
         if (nw && fread(w.data(), 4, nw, f) != nw) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
-        codes.resize(len);
-        for (uint32_t i = 0; i < len; ++i) codes[i] = (w[i >> 4] >> (30 - 2 * (i & 15))) & 3;   // sequence_package.h:126-129
-        out.append(codes.data(), len, reverse);
+        out.append_packed(w.data(), len, reverse);                                              // sequence_package.h:126-129
     }
     fclose(f);
     out.n_short = (uint64_t)num_reads;
@@ -78,17 +97,15 @@ void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out) {
 void load_read_bin(const std::string &bin_path, bool reverse, PackedReads &out) {
     FILE *f = fopen(bin_path.c_str(), "rb");
     if (!f) die("cannot open %s", bin_path.c_str());
+    setvbuf(f, nullptr, _IOFBF, 1 << 20);
     std::vector<uint32_t> w;
-    std::vector<uint8_t> codes;
     uint32_t len;
     uint64_t n = 0;
     while (fread(&len, 4, 1, f) == 1) {                                                      // until EOF, sequence_manager.cpp:375-410
         size_t nw = (len + 15) / 16;
         w.resize(nw);
         if (nw && fread(w.data(), 4, nw, f) != nw) die("%s: truncated at read %llu", bin_path.c_str(), (unsigned long long)n);
-        codes.resize(len);
-        for (uint32_t i = 0; i < len; ++i) codes[i] = (w[i >> 4] >> (30 - 2 * (i & 15))) & 3;
-        out.append(codes.data(), len, reverse);
+        out.append_packed(w.data(), len, reverse);
         ++n;
     }
     fclose(f);

@@ -21,11 +21,18 @@ struct PackedReads {
     uint64_t n_short = 0;            // reads that came from the library (the rest are assist sequences)
     int max_len = 0;
     void append(const uint8_t *codes, size_t n, bool reverse);
+    void append_packed(const uint32_t *w, size_t n, bool reverse);   // n bases as the .bin files hold them (base j of a word at bits 30-2j)
     void finish();
   private:
     uint64_t acc_ = 0;
     int acc_bits_ = 0;
     uint64_t n_bases_ = 0;
+    void push_bits(uint32_t v, int nbits) {                          // nbits <= 32, acc_bits_ < 32 on entry
+        if (nbits == 0) return;
+        acc_ = (acc_ << nbits) | (nbits == 32 ? (uint64_t)v : (uint64_t)(v & ((1u << nbits) - 1u)));
+        acc_bits_ += nbits;
+        if (acc_bits_ >= 32) { acc_bits_ -= 32; words.push_back((uint32_t)(acc_ >> acc_bits_)); acc_ &= (1ull << acc_bits_) - 1ull; }
+    }
     void push2(unsigned c) {
         acc_ = (acc_ << 2) | c; acc_bits_ += 2; ++n_bases_;
         if (acc_bits_ == 32) { words.push_back((uint32_t)acc_); acc_ = 0; acc_bits_ = 0; }

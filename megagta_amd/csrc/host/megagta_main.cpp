@@ -455,6 +455,21 @@ int main(int argc, char **argv) {
         build_read_lib(argv[2], argv[3]);
         return 0;
     }
+    if (sub == "libdump") {      // host-only check of the read loaders (tests): writes what buildgraph / findstart would upload
+        if (argc < 5) { fprintf(stderr, "Usage %s <read_lib_prefix> lib|bin <out_prefix> [assist.fa]\n", argv[1]); return 1; }
+        PackedReads pr;
+        if (std::string(argv[3]) == "bin") load_read_bin(std::string(argv[2]) + ".bin", true, pr);
+        else load_read_lib(argv[2], true, pr);
+        if (argc > 5) load_assist_fasta(argv[5], true, pr);
+        pr.finish();
+        FILE *fw = fopen((std::string(argv[4]) + ".words").c_str(), "wb"), *fs = fopen((std::string(argv[4]) + ".start").c_str(), "wb");
+        if (!fw || !fs) die("cannot write %s.words / .start", argv[4]);
+        fwrite(pr.words.data(), 4, pr.words.size(), fw);
+        fwrite(pr.start.data(), 8, pr.start.size(), fs);
+        fclose(fw); fclose(fs);
+        printf("%zu %zu %d %llu\n", pr.start.size() - 1, pr.words.size(), pr.max_len, (unsigned long long)pr.n_short);
+        return 0;
+    }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
     fprintf(stderr, "sub-command '%s' is not built here (buildlib, buildgraph, denovo, findstart, search, filterbylen, translate are): run it with the reference's megagta binary\n", sub.c_str());
     return 1;

@@ -56,3 +56,46 @@ def test_buildlib_reader_across_buffer_refills(tmp_path):
     rec[:, 1:] = words
     assert open(tmp_path / "big.bin", "rb").read() == rec.tobytes()
     assert open(tmp_path / "big.lib_info").read().splitlines()[0] == f"{n * L} {n}"
+
+
+def _libdump(tmp_path, prefix, mode, assist=None):
+    import numpy as np
+    out = str(tmp_path / ("dump_" + mode + ("_a" if assist else "")))
+    cmd = [BIN, "libdump", prefix, mode, out] + ([assist] if assist else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n_reads, n_words, max_len, n_short = (int(x) for x in r.stdout.split())
+    w, s = np.fromfile(out + ".words", np.uint32), np.fromfile(out + ".start", np.uint64)
+    assert w.size == n_words and s.size == n_reads + 1
+    return w, s, max_len, n_short
+
+
+def test_host_read_loaders_match_python_packers(tmp_path, golden_dir):
+    """what `megagta buildgraph` / `findstart` upload (reads reversed, 2 bit/base, concatenated; loaded 16 bases at a time) equals what the
+    Python packers give the GPU tests: ragged lengths, empty reads, the bare .bin reader, an assist FASTA appended base by base"""
+    import numpy as np
+    from megagta_amd import readlib
+    from tests import helpers as H
+    prefixes = [os.path.join(golden_dir, "toy", "reads.lib"), os.path.join(golden_dir, "ragged", "reads.lib")]
+    lib = H.write_buildlib_inputs(str(tmp_path))                      # lengths 0..300, N, lower case
+    r = subprocess.run([BIN, "buildlib", lib, str(tmp_path / "mixed")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    prefixes.append(str(tmp_path / "mixed"))
+    for prefix in prefixes:
+        reads = readlib.load_lib_bin(prefix)
+        packed, start = readlib.pack_for_build(reads)
+        for mode in ("lib", "bin"):
+            w, s, max_len, n_short = _libdump(tmp_path, prefix, mode)
+            assert np.array_equal(s, start) and np.array_equal(w, packed), (prefix, mode)
+            assert max_len == max(r.size for r in reads) and n_short == len(reads)
+    # assist sequences (buildgraph --assist_seq): appended after the library, through the FASTA reader
+    rng = np.random.default_rng(2)
+    assist = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in (37, 500, 1, 64, 129)]
+    with open(tmp_path / "assist.fa", "w") as f:
+        for i, a in enumerate(assist):
+            f.write(f">c{i}\n" + "".join("ACGT"[c] for c in a) + "\n")
+    open(tmp_path / "assist.fa.info", "w").write(f"{len(assist)} {sum(a.size for a in assist)}\n")
+    reads = readlib.load_lib_bin(prefixes[1])
+    packed, start = readlib.pack_for_build(reads + assist)
+    w, s, _, n_short = _libdump(tmp_path, prefixes[1], "lib", str(tmp_path / "assist.fa"))
+    assert np.array_equal(s, start) and np.array_equal(w, packed) and n_short == len(reads)
