@@ -293,21 +293,25 @@ void write_sdbg(const std::string &prefix, const EdgeStream &s) {
     for (int b = 0; b < 65536; ++b) {
         int64_t n = s.bucket_items[b];
         if (n == 0) { fprintf(info, "%d -1 0 0 0 0\n", b); continue; }
-        buf.clear();
+        const size_t worst = (size_t)n * (size_t)(4 + 4 * s.words_per_tip);      // record + large multiplicity + tip label
+        if (buf.size() < worst) buf.resize(worst);
+        unsigned char *q = buf.data();
         int64_t nt = 0, nl = 0;
+        const uint16_t *rp = s.recs.data() + ri;
         for (int64_t i = 0; i < n; ++i) {
-            uint16_t it = s.recs[ri++];
-            buf.insert(buf.end(), (unsigned char *)&it, (unsigned char *)&it + 2);
-            if ((it >> 8) == 255) { uint16_t m = s.large[li++]; buf.insert(buf.end(), (unsigned char *)&m, (unsigned char *)&m + 2); ++nl; }
+            const uint16_t it = rp[i];
+            memcpy(q, &it, 2); q += 2;
+            if ((it >> 8) == 255) { const uint16_t m = s.large[li++]; memcpy(q, &m, 2); q += 2; ++nl; }
             if ((it >> 5) & 1) {
-                const unsigned char *p = (const unsigned char *)&s.tips[ti];
-                buf.insert(buf.end(), p, p + 4 * s.words_per_tip);
+                memcpy(q, &s.tips[ti], 4 * (size_t)s.words_per_tip); q += 4 * (size_t)s.words_per_tip;
                 ti += s.words_per_tip; ++nt;
             }
         }
-        if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) die("write error on %s.sdbg.0", prefix.c_str());
+        ri += (size_t)n;
+        const size_t bytes = (size_t)(q - buf.data());
+        if (fwrite(buf.data(), 1, bytes, f) != bytes) die("write error on %s.sdbg.0", prefix.c_str());
         fprintf(info, "%d 0 %lld %lld %lld %lld\n", b, off, (long long)n, (long long)nt, (long long)nl);
-        off += (long long)buf.size();
+        off += (long long)bytes;
     }
     fclose(f);
     fclose(info);
@@ -344,21 +348,27 @@ void read_sdbg(const std::string &prefix, EdgeStream &s) {
         fclose(f);
     }
     s.recs.clear(); s.large.clear(); s.tips.clear();
-    s.recs.reserve((size_t)total);
+    long long listed = 0;
+    for (int b = 0; b < nb; ++b) if (recs[b].tid >= 0) listed += recs[b].items;
+    if (listed != total) die("%s: the bucket lines hold %lld records, the header says %lld", prefix.c_str(), listed, total);
+    s.recs.resize((size_t)total);
+    s.large.reserve((size_t)std::max(0ll, nlarge));
+    s.tips.reserve((size_t)std::max(0ll, ntips) * (size_t)std::max(0, s.words_per_tip));
+    uint16_t *out = s.recs.data();
     for (int b = 0; b < nb; ++b) {
         s.bucket_items[b] = recs[b].items; s.bucket_tips[b] = recs[b].tips; s.bucket_large[b] = recs[b].large;
         if (recs[b].tid < 0 || recs[b].items == 0) continue;
+        if (recs[b].tid >= nf) die("%s.sdbg_info: bucket %d names file %d of %d", prefix.c_str(), b, recs[b].tid, nf);
         const unsigned char *p = files[recs[b].tid].data() + recs[b].off;
         for (long long i = 0; i < recs[b].items; ++i) {
             uint16_t it;
             memcpy(&it, p, 2); p += 2;
-            s.recs.push_back(it);
+            *out++ = it;
             if ((it >> 8) == 255) { uint16_t m; memcpy(&m, p, 2); p += 2; s.large.push_back(m); }
             if ((it >> 5) & 1)
                 for (int t = 0; t < s.words_per_tip; ++t) { uint32_t w; memcpy(&w, p, 4); p += 4; s.tips.push_back(w); }
         }
     }
-    if ((long long)s.recs.size() != total) die("%s: %zu records decoded, header says %lld", prefix.c_str(), s.recs.size(), total);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -470,6 +470,16 @@ int main(int argc, char **argv) {
         printf("%zu %zu %d %llu\n", pr.start.size() - 1, pr.words.size(), pr.max_len, (unsigned long long)pr.n_short);
         return 0;
     }
+    if (sub == "sdbgcopy") {     // host-only check of the graph file reader + writer (tests): <in_prefix> -> <out_prefix> (one .sdbg.0 file)
+        if (argc < 4) { fprintf(stderr, "Usage %s <in_prefix> <out_prefix>\n", argv[1]); return 1; }
+        EdgeStream s;
+        double t0 = now_s();
+        read_sdbg(argv[2], s);
+        double t1 = now_s();
+        write_sdbg(argv[3], s);
+        logf("%zu records: read %.3f s, write %.3f s", s.recs.size(), t1 - t0, now_s() - t1);
+        return 0;
+    }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }
     fprintf(stderr, "sub-command '%s' is not built here (buildlib, buildgraph, denovo, findstart, search, filterbylen, translate are): run it with the reference's megagta binary\n", sub.c_str());
     return 1;

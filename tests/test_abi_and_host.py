@@ -122,3 +122,19 @@ def test_sort_plan_rejects_bad_arguments():
     assert L.mgta_sort_plan(10, 3, 5, 5, ctypes.byref(P), ctypes.byref(s)) != 0
     assert L.mgta_sort_plan(10, 3, 0, 70000, ctypes.byref(P), ctypes.byref(s)) != 0
     assert L.mgta_sort_plan(10, 1, 0, 65536, ctypes.byref(P), ctypes.byref(s)) != 0
+
+
+def test_host_sdbg_reader_and_writer(tmp_path, oracle, golden_dir):
+    """the C++ graph-file reader and writer of bin/megagta (buildgraph writes, denovo / search read): a 3-file graph goes through
+    `megagta sdbgcopy` and comes back as the same stream, for our Python reader and for the oracle's reader of the reference format"""
+    import subprocess
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "ragged", "reads.lib"))
+    o = oracle.Stream.build(packed, start, 29, threads=2).edges()
+    s = api.EdgeStream(k=o.k, words_per_tip=o.words_per_tip, bucket_items=o.bucket_items, records=o.records, large=o.large, tips=o.tips)
+    assert s.large.size > 0 and s.tips.size > 0                      # multiplicities > 254 and tip labels are in the file
+    api.write_sdbg(str(tmp_path / "in"), s, num_files=3)
+    exe = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
+    r = subprocess.run([exe, "sdbgcopy", str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert api.read_sdbg(str(tmp_path / "out")).md5() == s.md5()
+    assert oracle.Stream.read(str(tmp_path / "out")).edges().md5() == s.md5()
