@@ -236,13 +236,19 @@ static int main_search(int argc, char **argv) {
 // FASTA/FASTQ records with name and comment as kseq.h splits them (name = header up to the first blank)
 struct TextRecord { std::string name, comment, seq; bool has_comment; };
 static bool next_text_record(FILE *f, std::string &pending, TextRecord &r) {
-    auto getline = [&](std::string &out) {
+    static bool pending_cr = false;                                      // goes with `pending` (one input stream per process)
+    bool cr = false;                                                     // the last line ended in "\r\n"
+    auto getline = [&](std::string &out) {                               // one line without its end ('\n' or "\r\n"); false at the end of the file
+        static char *lp = nullptr;
+        static size_t cap = 0;
+        ssize_t n = ::getline(&lp, &cap, f);
         out.clear();
-        int c;
-        bool any = false;
-        while ((c = fgetc(f)) != EOF) { any = true; if (c == '\n') break; out.push_back((char)c); }
-        if (!out.empty() && out.back() == '\r') out.pop_back();
-        return any;
+        if (n <= 0) return false;
+        if (lp[n - 1] == '\n') --n;
+        out.assign(lp, (size_t)n);
+        cr = !out.empty() && out.back() == '\r';
+        if (cr) out.pop_back();
+        return true;
     };
     std::string line;
     if (pending.empty()) {
@@ -250,16 +256,16 @@ static bool next_text_record(FILE *f, std::string &pending, TextRecord &r) {
             if (!getline(line)) return false;
             if (!line.empty() && (line[0] == '>' || line[0] == '@')) break;
         }
-    } else { line = pending; pending.clear(); }
+    } else { line = pending; pending.clear(); cr = pending_cr; }
     size_t sp = line.find_first_of(" \t");
     r.name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-    r.has_comment = sp != std::string::npos;
-    r.comment = r.has_comment ? line.substr(sp + 1) : "";
+    r.has_comment = sp != std::string::npos || cr;                       // kseq.h: the '\r' of a bare "name\r\n" header is a blank, the comment is empty
+    r.comment = sp != std::string::npos ? line.substr(sp + 1) : "";
     r.seq.clear();
     for (;;) {
         if (!getline(line)) return true;
         if (line.empty()) continue;
-        if (line[0] == '>' || line[0] == '@') { pending = line; return true; }
+        if (line[0] == '>' || line[0] == '@') { pending = line; pending_cr = cr; return true; }
         if (line[0] == '+') {
             size_t got = 0;
             while (got < r.seq.size() && getline(line)) got += line.size();

@@ -99,3 +99,34 @@ def test_host_read_loaders_match_python_packers(tmp_path, golden_dir):
     packed, start = readlib.pack_for_build(reads + assist)
     w, s, _, n_short = _libdump(tmp_path, prefixes[1], "lib", str(tmp_path / "assist.fa"))
     assert np.array_equal(s, start) and np.array_equal(w, packed) and n_short == len(reads)
+
+
+def test_filterbylen_and_translate_match_reference(tmp_path):
+    """the driver's two text filters (host only): same bytes as the reference binary on multi-line records, CRLF, comments, a record
+    shorter than the limit, lengths not divisible by three, no newline at the end"""
+    import numpy as np
+    import pytest
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/megagta not built")
+    rng = np.random.default_rng(4)
+    parts = []
+    for i in range(400):
+        L = int(rng.integers(1, 1400))
+        s = "".join("acgtACGTn"[c] for c in rng.integers(0, 9 if i % 17 == 0 else 4, L))
+        head = f">g_contig_{2 * i}_contig_{2 * i + 1}" + (" some comment" if i % 5 == 0 else "")
+        eol = "\r\n" if i % 7 == 0 else "\n"
+        body = eol.join(s[j:j + 70] for j in range(0, L, 70)) if i % 3 == 0 else s
+        parts.append(head + eol + body + eol)
+    text = "".join(parts)
+    open(tmp_path / "c.fa", "w", newline="").write(text[:-1])            # no newline at the end
+    outs = {}
+    for tag, exe in (("ours", BIN), ("ref", REF)):
+        with open(tmp_path / "c.fa", "rb") as fin:
+            r = subprocess.run([exe, "filterbylen", "450"], stdin=fin, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        open(tmp_path / f"f_{tag}.fa", "wb").write(r.stdout)
+        t = subprocess.run([exe, "translate", str(tmp_path / f"f_{tag}.fa")], capture_output=True)
+        assert t.returncode == 0, t.stderr
+        outs[tag] = (r.stdout, t.stdout)
+    assert outs["ours"][0] == outs["ref"][0] and len(outs["ours"][0]) > 10_000
+    assert outs["ours"][1] == outs["ref"][1] and len(outs["ours"][1]) > 3_000
