@@ -59,6 +59,12 @@ int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, u
  * seeds below j + B + r / expansions_per_seed any more, so those start without waiting for it.  Either way the result is a function
  * of (seed order, B, expansions_per_seed) only, never of timing. */
 int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);
+/* Work memory of the searches.  The reference's node pool, open list and hash maps grow without bound (pool_st.h:43,
+ * hash_table_st.h:559-568); here every search slot owns a base arena of 1 << log2_base_nodes nodes (0 = default 12; 7..20) and a search
+ * that outgrows it takes further chunks from a device-side pool of pool_bytes (0 = sized from the number of searches in flight), its
+ * hash table being re-built at twice the size when half full: no search is ever re-run for lack of room.  Small values exercise the
+ * growth paths on small inputs (tests). */
+int mgta_ctx_set_search_arena(mgta_ctx *, int log2_base_nodes, uint64_t pool_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * SdBG construction  (replaces CX1::run() with the s2 plug-ins: cx1.h:443-623,
@@ -204,8 +210,10 @@ typedef struct mgta_astar_side {
 } mgta_astar_side;
 
 typedef struct mgta_astar_stats {
-    int64_t n_seeds, n_expansions, n_opened, n_retries;
+    int64_t n_seeds, n_expansions, n_opened, n_retries;   /* n_retries: searches run again because the pool was exhausted (normally 0) */
     double ms_total, ms_kernel;
+    int64_t n_grown, n_rehash, n_recycled;                /* searches that outgrew their base arena, hash tables re-built, chunks re-used */
+    uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / high-water mark of its bump pointer */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */

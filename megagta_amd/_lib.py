@@ -49,7 +49,8 @@ class AstarSide(C.Structure):
 
 class AstarStats(C.Structure):
     _fields_ = [("n_seeds", C.c_int64), ("n_expansions", C.c_int64), ("n_opened", C.c_int64), ("n_retries", C.c_int64),
-                ("ms_total", C.c_double), ("ms_kernel", C.c_double)]
+                ("ms_total", C.c_double), ("ms_kernel", C.c_double), ("n_grown", C.c_int64), ("n_rehash", C.c_int64),
+                ("n_recycled", C.c_int64), ("pool_bytes", C.c_uint64), ("pool_used", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -82,6 +83,7 @@ SYMBOLS = {
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_ctx_set_search_cost_rate": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgta_ctx_set_search_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgta_host_free": (None, [C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

@@ -71,6 +71,11 @@ class Context:
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 
+    def set_search_arena(self, log2_base_nodes: int = 0, pool_bytes: int = 0):
+        """work memory of the A* searches: base arena of 1 << log2_base_nodes nodes per search slot (0 = default), pool the searches
+        grow into (0 = auto).  Small values exercise the in-place growth on small inputs."""
+        check(self._L.mgta_ctx_set_search_arena(self.h, int(log2_base_nodes), int(pool_bytes)), "mgta_ctx_set_search_arena")
+
     # ---- SdBG build ---------------------------------------------------------------------------
     def upload_reads(self, packed: np.ndarray, start_idx: np.ndarray) -> "Reads":
         packed = np.ascontiguousarray(packed, dtype=np.uint32)

@@ -1,0 +1,1021 @@
+// astar_kernel.hpp — device side of the batched HMM-guided A* (included by astar.hip only).
+//
+// Mapping (gfx950, wave64): a wavefront carries 64 / G searches at once, G lanes each (G = 16 by default: one DPP row).
+// The searches of a wave run in lockstep through the phases of one expansion (pop, closed-set probe, graph walk, child scoring,
+// open-set probes, ordered commit), so the instruction stream that used to serve one search serves four, and the dependent
+// memory round trips of the four overlap.  Inside a search:
+//   * frontier expansion: lane (i, j) of the group walks OutgoingEdges(curr)[i] -> [j] and owns the <= 4 codon paths that
+//     continue from there (k = 0..3); reference order of the children = ascending (lane, k), match before insert, delete last;
+//   * open list = binary heap with libstdc++'s exact push_heap / pop_heap sift sequence (equal priorities leave in the
+//     reference's order); the top levels sit in LDS; a pop reads log2(G) levels of sibling PAIRS per memory round trip;
+//   * closed set + open_hash: one open-addressing table, empty = key 0;
+//   * node pool, heap and hash table GROW IN PLACE (PoolST / HashMapST of the reference have no bound: pool_st.h:43,
+//     hash_table_st.h:559-568): node index -> (level, offset) with level l >= 1 covering [B0 << (l-1), B0 << l), one chunk per
+//     level drawn from a device-side pool (bump pointer + per-size free lists); the hash table is re-hashed into a table of
+//     twice the size when half full.  Nothing is ever re-run; a search fails (status 2) only when the pool itself is exhausted.
+#pragma once
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "graph.hpp"
+
+namespace mgta {
+
+constexpr int kAstarWaves = 8;                 // waves per workgroup (one workgroup per CU: the HMM tables take most of the LDS)
+constexpr int kAstarThreads = kAstarWaves * 64;
+constexpr uint32_t kNone = 0x7FFFFFFFu;
+constexpr int kMaxKmer = 160;
+constexpr int kMaxLevels = 32;                 // arena levels per search (level l >= 1 doubles the capacity)
+constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
+constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+constexpr uint32_t kMaxNew = 132;              // children one expansion can open (64 codons x {match, insert} + delete), rounded up
+
+enum { T_MM = 0, T_MI = 1, T_MD = 2, T_IM = 3, T_II = 4, T_DM = 5, T_DD = 6 };   // profile_hmm.h:25
+enum { ST_M = 0, ST_I = 1, ST_D = 2 };
+enum { S_IDLE = 0, S_WAIT = 1, S_START = 2, S_RUN = 3, S_DONE = 4, S_EXIT = 5 };
+
+struct ANode {                    // AStarNode, a_star_node.h:9-33
+    double score, real_score, max_score;
+    int64_t node_id;
+    int32_t parent;               // index in the search's pool, -1 = none
+    int32_t fval;
+    int16_t state_no, length, negative_count;
+    uint16_t em_state;            // nucl_emission (9 bits) | state << 9
+};
+static_assert(sizeof(ANode) == 48, "node layout");
+
+struct HeapEnt {                  // 16 bytes; the priority (fval, -state_no, state rank) is rebuilt from key + fval
+    uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1)
+    int32_t fval;
+    uint32_t node;                // index in the search's node pool
+};
+struct HashEnt {
+    uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1); 0 = empty
+    uint32_t val;                 // open-list node index (kNone = none) | closed << 31
+    uint32_t pad;
+};
+static_assert(sizeof(HeapEnt) == 16 && sizeof(HashEnt) == 16, "entry layout");
+
+struct CacheEnt {
+    unsigned long long key;       // parent key (0 = empty)
+    unsigned long long val;       // ~(first seed that sees the entry << 16 | em_state of the child (nucl_emission | state << 9)); 0 = unset.
+                                  // One atomicMax of the complement keeps the entry that becomes visible first (window B, no cost
+                                  // term: the lowest owner = "first insert wins" of the sequential reference) and lets the table start
+                                  // as all-zero bytes.
+};
+
+struct HmmView {
+    const double *tab;
+    int M, A;
+    const int8_t *col_fwd;        // [64] codonTable -> column
+    const int8_t *col_enum;       // [64] table used by the enumerator of this direction (codonTable / rc_codonTable)
+};
+
+// Device-side chunk pool.  Every word below is touched by agent-scope atomics only (the allocator is shared by all CUs).
+struct PoolDev {
+    char *base;
+    unsigned long long bytes;     // size of the region the bump pointer may hand out
+    unsigned long long *bump;     // next never-used byte offset
+    unsigned int *lock, *cnt;     // [kNumClasses] spin lock and number of free chunks per class
+    unsigned int *stack;          // free chunks (4 KB units) of class c at stack[meta[c] .. meta[c] + meta[kNumClasses + c])
+    const unsigned int *meta;
+    unsigned long long *stat;     // [0] chunks served by the free lists, [1] failed allocations, [2] re-hashes, [3] searches that grew
+};
+
+struct AstarArgs {
+    GraphDev g;
+    HmmView hm[2];
+    const char *kmers;            // n x klen, lower/upper ACGT
+    const int32_t *start_state;
+    const int64_t *start_node;    // [2n]: IndexBinarySearchEdge of the k-mer (dir 0) and of its reverse complement (dir 1)
+    int64_t n_seeds;
+    int klen;                     // k + 1
+    int prune;
+    double low_cov_penalty;       // -log(low_cov_pen)
+    double log2v;
+    const double *exit_prob;      // [3000]
+    const int64_t *todo[2];       // seed indices still to run per direction
+    int64_t n_todo[2];
+    unsigned long long *queue;    // [2]
+    PoolDev pool;
+    unsigned long long base_off;  // byte offset of slot 0's base arena in the pool; slot s owns [base_off + s * slot_bytes, ...)
+    unsigned long long slot_bytes;
+    int log_b0;                   // base arena = 1 << log_b0 nodes (+ heap) and 2 << log_b0 hash entries
+    mgta_astar_side *sides;       // [2n]
+    char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
+    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = pool exhausted, 3 = bad seed, 4 = gate timeout
+    // shared term_nodes caches (search.cpp:182), one per direction.  window = 0: off (cold).  window = B >= 1: the path found by
+    // seed j (c_j expansions) is seen by exactly the seeds >= j + B + c_j / cost_rate (cost_rate = 0: no cost term; B = 1 then is
+    // the reference's sequential run).  The cost term lets later seeds start while a long search is still running: it cannot
+    // become visible to them any more, however soon it ends.
+    int window;
+    int cost_rate;
+    int gate;                     // 1 = seeds start in order behind the commit frontier (the normal shared-cache launch);
+                                  // 0 with window > 0 = a re-run of searches the pool could not hold: the caches are read with the
+                                  // same visibility rule but nothing waits
+    CacheEnt *cache[2];
+    uint64_t cache_mask[2];
+    uint32_t cache_probe_limit;   // an insert gives up after this many probes (a missed entry is always correct)
+    long long *run_seed;          // [slots] seed a search slot is working on (a lower bound while it is taking one from the queue), -1 = none
+    unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
+    unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last refresh by a waiting wave
+    uint32_t n_slots;
+    uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
+                                  // direction at a time, with the whole pool to itself)
+};
+
+__device__ __forceinline__ int to_fval(double x) {   // (int)x as x86-64 cvttsd2si does it (INT_MIN when out of range / NaN)
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+    return (int)x;
+}
+__device__ __forceinline__ int srank(int st) { return st == ST_M ? 3 : st == ST_D ? 2 : 1; }
+__device__ __forceinline__ uint64_t make_key(int64_t node_id, int state_no, int st) {
+    return ((uint64_t)node_id << 18) | ((uint64_t)(uint16_t)state_no << 2) | (uint64_t)(st + 1);
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t ent_prio(const HeapEnt &e) {   // AStarNode::operator< (a_star_node.h:34-82) as one integer: a < b <=> prio(a) < prio(b)
+    int st = (int)(e.key & 3) - 1;
+    return ((uint64_t)((uint32_t)e.fval ^ 0x80000000u) << 32) | ((uint64_t)(uint16_t)(0xFFFF - (uint16_t)((e.key >> 2) & 0xFFFF)) << 2) |
+           (uint64_t)srank(st);
+}
+
+// ---- agent-scope accesses: protocol words, caches and the pool's bookkeeping are written by other CUs (and XCDs) of the same
+// launch.  They are only ever touched by atomics performed at the coherence point, ordered by waiting for the returning atomic
+// before the next one is issued.  No acquire / release fences on polled words: on this part an agent-scope acquire invalidates,
+// and a release writes back, cache contents of the whole CU / XCD, and a gate that does that at polling rate slows every running
+// search by an order of magnitude (measured in round 1: 5.3 s -> 257 s).
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_fetch_add(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned int ld_agent(const unsigned int *p) {
+    return __hip_atomic_fetch_add(const_cast<unsigned int *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(long long *p, long long v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void st_agent(unsigned int *p, unsigned int v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- chunk pool ------------------------------------------------------------------------------------------------------------
+// Any subset of the lanes of a wave may call pool_alloc / pool_free, each for itself.  The callers of one wave take turns (one lane
+// at a time runs the whole lock / unlock sequence): two lanes of a wave must never compete for a lock, because a lane that has left
+// a spin loop waits at the reconvergence point for the lanes still in it -- with the lock in its hands (and the compiler is free to
+// move a critical section behind the loop that guards it).  A single spinning lane only ever waits for OTHER waves, which run on.
+__device__ __forceinline__ uint32_t pool_alloc_one(const PoolDev &P, int c) {
+    uint32_t res = kNoChunk;
+    if (ld_agent(&P.cnt[c]) != 0u) {
+        for (int spins = 0; spins < (1 << 20); ++spins) {
+            unsigned int expect = 0u;
+            if (__hip_atomic_compare_exchange_strong(&P.lock[c], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned int n = ld_agent(&P.cnt[c]);
+                if (n > 0u) {
+                    res = ld_agent(&P.stack[P.meta[c] + n - 1u]);
+                    st_agent(&P.cnt[c], n - 1u);
+                }
+                st_agent(&P.lock[c], 0u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);                              // (bounded: fall through to the bump pointer)
+        }
+        if (res != kNoChunk) __hip_atomic_fetch_add(&P.stat[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (res == kNoChunk) {
+        const unsigned long long size = 1ull << (c + kUnitLog);
+        unsigned long long old = ld_agent(P.bump);
+        while (old + size <= P.bytes) {
+            if (__hip_atomic_compare_exchange_strong(P.bump, &old, old + size, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                res = (uint32_t)(old >> kUnitLog);
+                break;
+            }
+        }
+        if (res == kNoChunk) __hip_atomic_fetch_add(&P.stat[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return res;
+}
+__device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
+    uint32_t res = kNoChunk;
+    const int lane = lane_id();
+    uint64_t turn = __ballot(true);                                   // the calling lanes
+    while (turn) {
+        const int l = __builtin_ctzll(turn);
+        turn &= turn - 1;
+        if (lane == l) res = pool_alloc_one(P, c);
+    }
+    // a chunk another CU may have used: drop whatever this CU's L1 still holds of it (once per chunk, not per poll)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return res;
+}
+// The caller has issued pool_release_fence() since its last store into the chunk.
+__device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit) {
+    const int lane = lane_id();
+    uint64_t turn = __ballot(true);
+    while (turn) {
+        const int l = __builtin_ctzll(turn);
+        turn &= turn - 1;
+        if (lane == l) {
+            for (int spins = 0; spins < (1 << 20); ++spins) {
+                unsigned int expect = 0u;
+                if (__hip_atomic_compare_exchange_strong(&P.lock[c], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    const unsigned int n = ld_agent(&P.cnt[c]);
+                    if (n < P.meta[kNumClasses + c]) {                 // (a full list leaks the chunk: only possible with toy chunk sizes)
+                        st_agent(&P.stack[P.meta[c] + n], unit);
+                        st_agent(&P.cnt[c], n + 1u);
+                    }
+                    st_agent(&P.lock[c], 0u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);                          // (bounded: the chunk is given up rather than the wave hung)
+            }
+        }
+    }
+}
+// Chunks travel between CUs of different XCDs, whose L2s are not coherent with each other for plain stores: write this XCD's
+// dirty lines back before a chunk is offered to the others (once per search that grew, never per expansion).
+__device__ __forceinline__ void pool_release_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- one search's arena ------------------------------------------------------------------------------------------------------
+struct Arena {
+    const uint32_t *seg;          // LDS: chunk (4 KB units) of every level of this search
+    char *pool;
+    int log_b0;
+    __device__ __forceinline__ void locate(uint32_t i, char *&base, uint32_t &size, uint32_t &off) const {
+        const uint32_t hi = i >> log_b0;
+        const int level = hi ? 32 - __builtin_clz(hi) : 0;
+        size = level ? (1u << (log_b0 + level - 1)) : (1u << log_b0);
+        off = level ? i - size : i;
+        base = pool + ((uint64_t)seg[level] << kUnitLog);
+    }
+    __device__ __forceinline__ ANode *node(uint32_t i) const {
+        char *b; uint32_t sz, off;
+        locate(i, b, sz, off);
+        return reinterpret_cast<ANode *>(b) + off;
+    }
+    __device__ __forceinline__ HeapEnt *heap(uint32_t i) const {      // the heap slots of a level follow its nodes
+        char *b; uint32_t sz, off;
+        locate(i, b, sz, off);
+        return reinterpret_cast<HeapEnt *>(b + (uint64_t)sz * sizeof(ANode)) + off;
+    }
+};
+__device__ __forceinline__ int chunk_class(int log_b0, int level) { return 6 + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
+__device__ __forceinline__ ANode load_node(const ANode *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    union { uint4 v[3]; ANode n; } u;
+    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2];
+    return u.n;
+}
+__device__ __forceinline__ void store_node(ANode *p, const ANode &n) {
+    union { uint4 v[3]; ANode n; } u;
+    u.n = n;
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = u.v[0]; q[1] = u.v[1]; q[2] = u.v[2];
+}
+__device__ __forceinline__ HeapEnt load_ent(const HeapEnt *p) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(p);
+    HeapEnt e;
+    e.key = (uint64_t)v.x | ((uint64_t)v.y << 32); e.fval = (int32_t)v.z; e.node = v.w;
+    return e;
+}
+__device__ __forceinline__ void store_ent(HeapEnt *p, const HeapEnt &e) {
+    *reinterpret_cast<uint4 *>(p) = make_uint4((uint32_t)e.key, (uint32_t)(e.key >> 32), (uint32_t)e.fval, e.node);
+}
+
+// ---- group (= one search) primitives: G consecutive lanes ---------------------------------------------------------------------
+template <int G> struct Grp {
+    static constexpr int kGroups = 64 / G;
+    static constexpr int kLog = G == 64 ? 6 : G == 32 ? 5 : 4;
+    static constexpr uint32_t kLdsHeap = (1u << kLog) * 4u - 1u;       // heap entries of a search kept in LDS: 63 / 127 / 255
+    static constexpr uint64_t kMask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    __device__ static __forceinline__ uint64_t ballot(bool p, int gbase) { return (__ballot(p) >> gbase) & kMask; }
+    template <class T> __device__ static __forceinline__ T bcast(T v, int src, int gbase) { return __shfl(v, gbase + src, 64); }
+};
+
+template <int G> struct Heap {
+    HeapEnt *lds;                 // this search's top Grp<G>::kLdsHeap entries
+    Arena ar;
+    int gl, gbase;
+    __device__ __forceinline__ HeapEnt get(uint64_t i) const { return i < Grp<G>::kLdsHeap ? lds[i] : load_ent(ar.heap((uint32_t)i)); }
+    __device__ __forceinline__ void set(uint64_t i, const HeapEnt &e) const {
+        if (i < Grp<G>::kLdsHeap) lds[i] = e; else store_ent(ar.heap((uint32_t)i), e);
+    }
+    // __push_heap(first, hole, 0, v) (bits/stl_heap.h): every lane of the group calls it with the same arguments
+    __device__ __forceinline__ void sift_up(uint64_t hole, const HeapEnt &v) const {
+        const int depth = 63 - __builtin_clzll(hole + 1);              // number of ancestors of `hole`
+        const uint64_t pv = ent_prio(v);
+        int a0 = 0;                                                    // ancestors a0+1 .. a0+G are looked at together
+        while (true) {
+            const int a = a0 + gl + 1;
+            HeapEnt e = v;
+            bool less = false;
+            if (a <= depth) {
+                e = get(((hole + 1) >> a) - 1);
+                less = ent_prio(e) < pv;
+            }
+            const uint64_t bal = Grp<G>::ballot(less, gbase);
+            int s = bal == Grp<G>::kMask ? G : __builtin_ctzll(~bal);  // ancestors of this batch that move down one level
+            if (gl < s) set(((hole + 1) >> (a - 1)) - 1, e);
+            if (s == G && a0 + G < depth) { a0 += G; continue; }
+            if (gl == 0) set(((hole + 1) >> (a0 + s)) - 1, v);
+            break;
+        }
+    }
+    // pop_heap + pop_back; n = current size (> 0); returns the former top.
+    // __adjust_heap walks down from the root moving the larger child up (the right one unless right < left).  log2(G) levels per
+    // memory round trip: lane l < G-1 holds one PAIR of siblings of the subtree under the hole (level t = floor(log2(l+1)) + 1,
+    // pair p = l + 1 - 2^(t-1)), decides locally which of the two its parent would pick, a chain of ballots tells which lanes lie on
+    // the path, and those lanes move their entries up at once.
+    __device__ __forceinline__ HeapEnt pop(uint32_t n) const {
+        const HeapEnt top = get(0);
+        if (n > 1) {
+            const HeapEnt v = get(n - 1);
+            const int64_t len = (int64_t)n - 1;
+            const int64_t half = (len - 1) / 2;                        // nodes below `half` have two children
+            int64_t hole = 0;
+            const int t = 32 - __builtin_clz((unsigned)gl + 1);        // 1 .. log2(G) for lanes 0 .. G-2
+            const int p = gl + 1 - (1 << (t - 1));
+            const int parent_lane = t > 1 ? (1 << (t - 2)) - 1 + (p >> 1) : 0;
+            const bool role = gl < G - 1;
+            while (hole < half) {
+                const int64_t P = ((hole + 1) << (t - 1)) - 1 + p;    // the node whose two children this lane holds
+                const bool has = role && P < half;
+                HeapEnt el, er;
+                el.key = 0; el.fval = 0; el.node = 0; er = el;
+                if (has) { el = get((uint64_t)(2 * P + 1)); er = get((uint64_t)(2 * P + 2)); }
+                const bool pick_left = ent_prio(er) < ent_prio(el);    // second = right child; if (right < left) second = left
+                const uint64_t pl = Grp<G>::ballot(pick_left, gbase);
+                uint64_t path = 0;
+#pragma unroll
+                for (int tt = 1; tt <= Grp<G>::kLog; ++tt) {
+                    const bool on = has && t == tt &&
+                                    (tt == 1 || (((path >> parent_lane) & 1ull) && (int)((pl >> parent_lane) & 1ull) == ((p & 1) ^ 1)));
+                    path |= Grp<G>::ballot(on, gbase);
+                }
+                HeapEnt ch;                                                       // the child the parent picks (field by field: no address select)
+                ch.key = pick_left ? el.key : er.key; ch.fval = pick_left ? el.fval : er.fval; ch.node = pick_left ? el.node : er.node;
+                if ((path >> gl) & 1ull) set((uint64_t)P, ch);                    // every node of the path moves up one level
+                const int deepest = 63 - __builtin_clzll(path);                   // path != 0: the hole has two children
+                hole = Grp<G>::bcast(pick_left ? 2 * P + 1 : 2 * P + 2, deepest, gbase);
+            }
+            if ((len & 1) == 0 && hole == (len - 2) / 2) {             // a last, single (left) child
+                const HeapEnt ce = get((uint64_t)(2 * hole + 1));
+                if (gl == 0) set((uint64_t)hole, ce);
+                hole = 2 * hole + 1;
+            }
+            sift_up((uint64_t)hole, v);
+        }
+        return top;
+    }
+};
+
+// closed set + open_hash: every lane of the group probes the same key (one request)
+__device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask, uint64_t key, bool &found, uint32_t &val) {
+    uint32_t i = (uint32_t)mix64(key) & hmask;
+    while (true) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(tab + i);
+        const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        if (k == 0) { found = false; val = kNone; return i; }
+        if (k == key) { found = true; val = v.z; return i; }
+        i = (i + 1) & hmask;
+    }
+}
+__device__ __forceinline__ void hash_put(HashEnt *tab, uint32_t i, uint64_t key, uint32_t val) {
+    *reinterpret_cast<uint4 *>(tab + i) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), val, 0u);
+}
+
+// child descriptor cached for `key` and visible to seed `seed`, or -1
+__device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
+    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    uint64_t i = mix64(key) & cmask;
+    for (uint32_t probes = 0; probes <= a.cache_probe_limit; ++probes) {
+        unsigned long long k = ld_agent(&tab[i].key);
+        if (k == 0) return -1;
+        if (k == key) {
+            unsigned long long v = ld_agent(&tab[i].val);
+            if (v == 0ull) return -1;
+            v = ~v;
+            return (int64_t)(v >> 16) <= seed ? (int)(v & 0xFFFF) : -1;
+        }
+        i = (i + 1) & cmask;
+    }
+    return -1;                                                         // (an insert never goes further than this either)
+}
+__device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t visible_from, int em_state) {
+    CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    uint64_t i = mix64(key) & cmask;
+    unsigned long long v = ((unsigned long long)visible_from << 16) | (unsigned long long)(em_state & 0xFFFF);
+    for (uint32_t probes = 0; probes <= a.cache_probe_limit; ++probes) {
+        unsigned long long k = ld_agent(&tab[i].key);
+        if (k == 0) {
+            unsigned long long expect = 0;
+            if (__hip_atomic_compare_exchange_strong(&tab[i].key, &expect, (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                k = key;
+            else
+                k = expect;
+        }
+        if (k == key) {
+            __hip_atomic_fetch_max(&tab[i].val, ~v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        i = (i + 1) & cmask;
+    }
+}
+
+// Highest seed that may start now: no unfinished search can still become visible to it (see AstarArgs::window).  Every lane of
+// the WAVE calls it and returns the same value; start_limit keeps the maximum ever computed (the bound only grows).  The table
+// reads are atomics performed at the coherence point, four in flight per lane.
+template <int G>
+__device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, int lane) {
+    constexpr uint32_t SPB = kAstarWaves * Grp<G>::kGroups;           // search slots per workgroup
+    const long long head = (long long)ld_agent(&a.queue[dir]);        // the queue first: every seed below it is in the table by now
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long bound = head + a.window - 1;
+    const uint32_t n_dir = a.n_slots / 2;                             // this direction's slots: workgroups 2b + dir
+    for (uint32_t t0 = 0; t0 < n_dir; t0 += 256) {
+        long long js[4];
+        unsigned long long pr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = t0 + u * 64 + (uint32_t)lane;
+            const uint32_t sl = (2 * (t / SPB) + (uint32_t)dir) * SPB + t % SPB;
+            js[u] = -1; pr[u] = 0;
+            if (t < n_dir) {
+                js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.cost_rate > 0) pr[u] = __hip_atomic_fetch_add(&a.run_progress[sl], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (js[u] >= 0) {
+                const long long b = js[u] + a.window - 1 + (a.cost_rate > 0 ? (long long)(pr[u] / (unsigned)a.cost_rate) : 0ll);
+                bound = b < bound ? b : bound;
+            }
+    }
+    bound = wave_min_ll(bound);
+    if (lane == 0 && bound > 0) __hip_atomic_fetch_max(&a.start_limit[dir], (unsigned long long)bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return bound;
+}
+
+__device__ __forceinline__ int base_of(char ch) {
+    return (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g' || ch == 'N' || ch == 'n') ? 2
+           : (ch == 'T' || ch == 't') ? 3 : -1;
+}
+
+template <int G, bool LDS>
+__global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
+    using GX = Grp<G>;
+    constexpr int GROUPS = GX::kGroups;
+    constexpr uint32_t SPB = kAstarWaves * GROUPS;
+    constexpr uint32_t LH = GX::kLdsHeap;
+    extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][level tables][HMM tables]
+    HeapEnt *const s_heap = reinterpret_cast<HeapEnt *>(s_mem);
+    uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * (LH + 1) * sizeof(HeapEnt));
+    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * ((LH + 1) * sizeof(HeapEnt) + kMaxLevels * sizeof(uint32_t)));
+
+    const int dir = blockIdx.x & 1;
+    HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
+    hv.tab = dir ? a.hm[1].tab : a.hm[0].tab; hv.M = dir ? a.hm[1].M : a.hm[0].M; hv.A = dir ? a.hm[1].A : a.hm[0].A;
+    hv.col_fwd = dir ? a.hm[1].col_fwd : a.hm[0].col_fwd; hv.col_enum = dir ? a.hm[1].col_enum : a.hm[0].col_enum;
+    const int M = hv.M, A = hv.A;
+    const double *tab = hv.tab;
+    if (LDS) {
+        const size_t nd = (size_t)(M + 1) * (A + 11);
+        for (size_t i = threadIdx.x; i < nd; i += kAstarThreads) s_tab[i] = hv.tab[i];
+        __syncthreads();
+        tab = s_tab;
+    }
+    const size_t M1 = (size_t)M + 1;
+    const double *msc = tab, *tsc = tab + M1 * A, *maxm = tsc + 7 * M1, *hc = maxm + M1;
+    const int lane = lane_id(), wv = wave_id();
+    const int gl = lane & (G - 1), gbase = lane & ~(G - 1), grp = lane / G;
+    const uint32_t lslot = (uint32_t)wv * GROUPS + (uint32_t)grp;     // search slot inside the workgroup
+    const uint32_t slot = blockIdx.x * SPB + lslot;
+    const GraphDev &g = a.g;
+    const bool forward = dir == 0;
+    const double NEG_INF = -__builtin_inf();
+    const uint64_t lt_mask = (1ull << gl) - 1ull;                     // lower lanes of the group
+    const int64_t n_todo = dir ? a.n_todo[1] : a.n_todo[0];
+    const int64_t *todo = dir ? a.todo[1] : a.todo[0];
+
+    // this slot's base arena: level 0 of the node pool + heap, then the base hash table
+    uint32_t *const seg = s_seg + (size_t)lslot * kMaxLevels;
+    const int log_b0 = a.log_b0;
+    const uint32_t B0 = 1u << log_b0;
+    const int base_hclass = 5 + log_b0 - kUnitLog;
+    char *const slot_base = a.pool.base + a.base_off + (uint64_t)slot * a.slot_bytes;
+    HashEnt *const base_hash = reinterpret_cast<HashEnt *>(slot_base + ((uint64_t)64 << log_b0));
+    if (gl == 0) seg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes) >> kUnitLog);
+    wave_lds_fence();
+    Heap<G> H;
+    H.lds = s_heap + (size_t)lslot * (LH + 1);
+    H.ar.seg = seg; H.ar.pool = a.pool.base; H.ar.log_b0 = log_b0;
+    H.gl = gl; H.gbase = gbase;
+    const Arena &AR = H.ar;
+
+    // ---- per-search state (uniform inside a group)
+    int st = S_IDLE;
+    bool need_scan = false;
+    unsigned long long spins = 0;
+    long long seed = -1;
+    int64_t sid = 0;
+    uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0;
+    int n_levels = 1;
+    HashEnt *hash = base_hash;
+    uint32_t hmask = 2 * B0 - 1;
+    int hclass = base_hclass;
+    int64_t n_closed = 0, n_expanded = 0, n_opened = 0;
+    int status = 1, partial = 0, ok = 0;
+    int32_t goal = -1, inter = 0, cur = 0;
+    double inter_val = 0;                                             // (real_score + exit_prob[length]) / ln 2 of node `inter`
+    bool first = true;
+    ANode curr;
+    curr.score = curr.real_score = curr.max_score = 0; curr.node_id = 0; curr.parent = -1; curr.fval = 0;
+    curr.state_no = curr.length = curr.negative_count = 0; curr.em_state = 0;
+
+    while (true) {
+        // ================= next search for the idle slots
+        if (st == S_IDLE && lslot >= a.active_slots) st = S_EXIT;
+        if (st == S_IDLE) {
+            long long qi = 0;
+            if (gl == 0) {
+                if (a.gate) {
+                    // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also
+                    // sees a slot that holds it (or its committed paths)
+                    st_agent(&a.run_progress[slot], 0ull);
+                    st_agent(&a.run_seed[slot], (long long)ld_agent(&a.queue[dir]));
+                    qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    qi = (long long)atomicAdd(&a.queue[dir], 1ull);
+                }
+            }
+            qi = GX::bcast(qi, 0, gbase);
+            if (qi >= n_todo) {
+                st = S_EXIT;
+                if (a.gate && gl == 0) st_agent(&a.run_seed[slot], -1ll);
+            } else {
+                seed = todo[qi];
+                sid = seed * 2 + dir;
+                if (a.gate) {
+                    if (gl == 0) st_agent(&a.run_seed[slot], (long long)seed);
+                    st = S_WAIT; need_scan = true; spins = 0;
+                } else {
+                    st = S_START;
+                }
+            }
+        }
+        if (__ballot(st != S_EXIT) == 0ull) break;
+
+        // ================= ordered-commit gate (shared-cache launches): wave-level, never blocks the searches that are running
+        // Seed i may start once no unfinished search j can still become visible to it: i < j + B + progress_j / cost_rate for every
+        // running j, and i < q + B for the next seed q of the queue.  The lowest running search always passes.  The limit moves when a
+        // search ends (its wave recomputes it) and, with a cost term, as the running searches progress: for that ONE waiting wave per
+        // direction and ~50 us re-reads the table (ticket = time of the last refresh); the others poll one word.
+        if (a.gate) {
+            if (__ballot(st == S_WAIT) != 0ull) {
+                bool scan = __ballot(st == S_WAIT && need_scan) != 0ull;
+                if (!scan) {
+                    long long lim = 0;
+                    if (lane == 0) lim = (long long)ld_agent(&a.start_limit[dir]);
+                    lim = __shfl(lim, 0, 64);
+                    if (st == S_WAIT && lim >= seed) st = S_START;
+                    if (__ballot(st == S_WAIT) != 0ull) {
+                        int refresh = 0;
+                        if (lane == 0) {
+                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+                            unsigned long long last = ld_agent(&a.start_limit[2 + dir]);
+                            if (now - last > 5000ull)
+                                refresh = __hip_atomic_compare_exchange_strong(&a.start_limit[2 + dir], &last, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        scan = __shfl(refresh, 0, 64) != 0;
+                    }
+                }
+                if (scan) {
+                    const long long b = start_bound<G>(a, dir, lane);
+                    if (st == S_WAIT && b >= seed) st = S_START;
+                    need_scan = false;
+                }
+                if (st == S_WAIT && ++spins > (1ull << 22)) {          // bounded wait: the host reports the seed
+                    if (gl == 0) { a.status[sid] = 4; st_agent(&a.run_seed[slot], -1ll); }
+                    st = S_EXIT;
+                }
+                if (__ballot(st == S_START || st == S_RUN) == 0ull) {  // nothing to do in this wave but wait
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+                }
+            }
+        }
+
+        // ================= start node (hmm_graph_search.h:132-189)
+        if (st == S_START) {
+            n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1;
+            hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            n_closed = 0; n_expanded = 0; n_opened = 0;
+            status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true;
+            for (uint32_t i = (uint32_t)gl; i <= hmask; i += G) hash_put(hash, i, 0ull, 0u);
+            const char *km = a.kmers + seed * a.klen;
+            const int n_aa = a.klen / 3;
+            const int sstate = forward ? a.start_state[seed] : (M - a.start_state[seed] - n_aa);   // :73
+            bool bad = sstate < 0 || sstate + n_aa > M || a.klen > kMaxKmer;
+            double sc = 0, rs = 0;
+            if (!bad) {
+                for (int i = 1; i <= n_aa; ++i) {                      // scoreStart / realScoreStart, :112-130
+                    const int ci = forward ? (i - 1) : (n_aa - i);     // the reverse search scores the reversed protein
+                    int c = 0;
+                    for (int t = 0; t < 3; ++t) {
+                        const int b = base_of(km[3 * ci + t]);
+                        if (b < 0) bad = true;
+                        c = c * 4 + (b < 0 ? 0 : b);
+                    }
+                    const int col = hv.col_fwd[c];
+                    if (col < 0) { bad = true; break; }
+                    const double m = msc[(size_t)(sstate + i) * A + col], t = tsc[(size_t)T_MM * M1 + sstate + i - 1];
+                    sc += m + t - maxm[sstate + i];
+                    rs += m + t;
+                }
+            }
+            st = S_RUN;
+            if (bad) { status = 3; st = S_DONE; }
+            else {
+                curr.parent = -1; curr.state_no = (int16_t)(sstate + n_aa); curr.em_state = (uint16_t)(ST_M << 9); curr.length = (int16_t)n_aa;
+                curr.fval = 0; curr.score = sc; curr.real_score = rs; curr.max_score = 0; curr.negative_count = 0;
+                curr.node_id = a.start_node[sid];
+                if (gl == 0) store_node(AR.node(0), curr);
+                n_nodes = 1;
+                inter_val = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
+                if (curr.state_no >= M) { ok = 1; goal = 0; st = S_DONE; }             // :193-197
+                else if (curr.node_id == -1) { ok = 0; n_opened = 1; st = S_DONE; }    // no children -> open.empty() -> false (:235-237)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+
+        // ================= one expansion
+        if (st == S_RUN) {
+            bool stop = false;
+            if (!first) {
+                // pop until a node that is not closed (hmm_graph_search.h:243-257)
+                bool have = false;
+                uint32_t hs = 0, hval = kNone;
+                uint64_t hkey = 0;
+                while (n_heap > 0) {
+                    const HeapEnt top = H.pop(n_heap);
+                    --n_heap;
+                    bool found;
+                    hs = hash_find(hash, hmask, top.key, found, hval);
+                    if (found && (hval >> 31)) continue;                               // closed
+                    cur = (int32_t)top.node;
+                    hkey = top.key;
+                    if (!found) ++n_keys;                                              // (children of the first expansion are not in open_hash)
+                    have = true;
+                    break;
+                }
+                if (!have) { partial = 1; ok = 1; goal = inter; stop = true; }        // open list ran dry (:339-341)
+                else {
+                    curr = load_node(AR.node((uint32_t)cur));
+                    const double cv = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
+                    const bool better = cv > inter_val;
+                    if (curr.state_no >= M) {                                          // goal (:259-270)
+                        if (better) inter = cur;
+                        ok = 1; goal = inter; stop = true;
+                    } else {
+                        if (gl == 0) hash_put(hash, hs, hkey, hval | 0x80000000u);     // closed.insert (:272)
+                        n_closed++;
+                        if (better) { inter = cur; inter_val = cv; }                   // :274-277
+                    }
+                }
+            }
+            // room for this expansion's children: the arena grows in place, the table is re-hashed when half full
+            if (!stop && n_nodes + kMaxNew > cap_nodes) {
+                uint32_t unit = 0;
+                if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && chunk_class(log_b0, n_levels) < kNumClasses) {
+                    if (gl == 0) unit = pool_alloc(a.pool, chunk_class(log_b0, n_levels));
+                    unit = GX::bcast(unit, 0, gbase);
+                    if (unit == kNoChunk) break;
+                    if (gl == 0) seg[n_levels] = unit;
+                    cap_nodes = B0 << n_levels;
+                    ++n_levels;
+                }
+                wave_lds_fence();
+                if (n_nodes + kMaxNew > cap_nodes) { status = 2; stop = true; }
+            }
+            while (!stop && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
+                uint32_t unit = kNoChunk;
+                if (hclass + 1 < kNumClasses && hmask < 0x7FFFFFFFu) {
+                    if (gl == 0) unit = pool_alloc(a.pool, hclass + 1);
+                    unit = GX::bcast(unit, 0, gbase);
+                }
+                if (unit == kNoChunk) { status = 2; stop = true; break; }
+                HashEnt *nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)unit << kUnitLog));
+                const uint32_t nmask = hmask * 2 + 1;
+                for (uint64_t i = (uint64_t)gl; i <= nmask; i += G) hash_put(nt, (uint32_t)i, 0ull, 0u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (uint64_t i0 = 0; i0 <= hmask; i0 += G) {                          // every lane moves one entry; slots are claimed at the L2
+                    const uint64_t i = i0 + gl;
+                    if (i <= hmask) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(hash + i);
+                        const unsigned long long k = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+                        if (k != 0ull) {
+                            uint32_t j = (uint32_t)mix64(k) & nmask;
+                            while (true) {
+                                unsigned long long expect = 0ull;
+                                if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&nt[j].key), &expect, k, __ATOMIC_RELAXED,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                    __hip_atomic_store(&nt[j].val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    break;
+                                }
+                                j = (j + 1) & nmask;
+                            }
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new table was filled behind this CU's L1
+                if (hclass > base_hclass) {
+                    pool_release_fence();
+                    if (gl == 0) pool_free(a.pool, hclass, (uint32_t)((reinterpret_cast<char *>(hash) - a.pool.base) >> kUnitLog));
+                }
+                if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hash = nt; hmask = nmask; ++hclass;
+            }
+
+            if (!stop) {
+                const int cst = curr.em_state >> 9;
+                const int next_state = curr.state_no + 1;
+                // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
+                int cached = -1;
+                if (a.window > 0) {
+                    if (gl == 0) cached = cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), seed);
+                    cached = GX::bcast(cached, 0, gbase);
+                }
+                const int cached_st = cached >= 0 ? (cached >> 9) : -1;
+
+                // ---- enumeration of the <= 64 codon paths (node_enumerator.h:98-128): lane (i, j) walks two edges and owns the <= 4
+                // third edges that continue from there
+                int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+                LineR Ls = g_load_line(g, (uint64_t)curr.node_id >> 6), Lt;
+                uint64_t lt_idx = 0;
+                const int od1 = g_outgoing_line(g, Ls, curr.node_id, p0, p1, p2, p3, Lt, lt_idx);
+                const int ci = (gl >> 2) & 3, cj = gl & 3;
+                bool valid = gl < 16 && ci < od1;
+                int od3 = 0, c12 = 0, low12 = 0;
+                if (valid) {
+                    const int64_t e1 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, ci);
+                    if ((uint64_t)(e1 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e1 >> 10));   // (e1 >> 4) >> 6: rare, a node's edges straddle two lines
+                    Ls = Lt;
+                    const int od2 = g_outgoing_line(g, Ls, e1 >> 4, p0, p1, p2, p3, Lt, lt_idx);
+                    valid = cj < od2;
+                    if (valid) {
+                        const int64_t e2 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, cj);
+                        if ((uint64_t)(e2 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e2 >> 10));
+                        Ls = Lt;
+                        od3 = g_outgoing_line(g, Ls, e2 >> 4, p0, p1, p2, p3, Lt, lt_idx);
+                        if (od3 < 0) od3 = 0;
+                        c12 = (((int)(e1 & 7) - 1) << 6) | (((int)(e2 & 7) - 1) << 3);
+                        low12 = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1);
+                    }
+                }
+                if (!valid) od3 = 0;
+                n_expanded++;
+                if (a.gate && a.cost_rate > 0 && (n_expanded & 63) == 0 && gl == 0)
+                    __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+                // ---- children (node_enumerator.h:131-244)
+                double mt, it, dt;
+                if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
+                else if (cst == ST_D) { mt = tsc[T_DM * M1 + curr.state_no]; it = NEG_INF; dt = tsc[T_DD * M1 + curr.state_no]; }
+                else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
+                const double max_match = maxm[next_state];
+                const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
+
+                // which of this lane's codons pass (stop codons :142-144; a cached child keeps only its own codon :146-148)
+                int use_bits = 0, cols = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                    if (k < od3) {
+                        const int codon = c12 | ((int)(e3 & 7) - 1);
+                        const int col = hv.col_enum[((codon >> 6) & 7) * 16 + ((codon >> 3) & 7) * 4 + (codon & 7)];
+                        bool use = col >= 0;
+                        if (use && cached >= 0) use = cached_st == ST_D ? ((e3 >> 4) == curr.node_id) : (codon == (cached & 511));
+                        if (use) { use_bits |= 1 << k; cols |= col << (8 * k); }
+                    }
+                }
+                const bool any_pass = GX::ballot(use_bits != 0, gbase) != 0ull;
+                // a cached match/insert child ends the enumeration at that child (:178-181,207-210)
+                const bool ins_ok = cst != ST_D && cached_st != ST_M;
+                const bool want_del = cst != ST_I && !((cached_st == ST_M || cached_st == ST_I) && any_pass);
+
+                // ---- admission (hmm_graph_search.h:288-311): prune test + open_hash lookup, all children in parallel
+                auto admissible = [&](int length, int negative_count, double real_score) {
+                    return a.prune > 0 ? ((length < 5 || negative_count <= a.prune) && real_score > 0.0) : true;
+                };
+                auto probe_open = [&](int64_t node_id, int state_no, int stt, int fval) -> bool {   // per-lane probe of this lane's own key
+                    const uint64_t key = make_key(node_id, state_no, stt);
+                    uint32_t ii = (uint32_t)mix64(key) & hmask;
+                    while (true) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(hash + ii);
+                        const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                        if (k == 0) return true;
+                        if (k == key) {
+                            const uint32_t oi = v.z & kNone;
+                            if (oi == kNone) return true;
+                            return AR.node(oi)->fval < fval;                           // got->second < next (:299-302); equal keys => only fval differs
+                        }
+                        ii = (ii + 1) & hmask;
+                    }
+                };
+                // node indices are handed out codon rank by codon rank (k), lane by lane, match before insert: the pool order is not
+                // observable, only the order of the commits below is
+                uint32_t nbase = n_nodes;
+                uint64_t MM = 0, MI = 0;                                               // admitted match / insert children: bit 16 k + lane
+                int fm0 = 0, fm1 = 0, fm2 = 0, fm3 = 0, fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (__ballot((use_bits >> k) & 1) == 0ull) continue;               // (uniform over the active lanes)
+                    const bool use = (use_bits >> k) & 1;
+                    const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                    const int codon = c12 | ((int)(e3 & 7) - 1);
+                    const int low = low12 & (int)((e3 >> 3) & 1);
+                    const int col = (cols >> (8 * k)) & 255;
+                    ANode cm, cin;                                                     // this codon's match / insert child
+                    cm.parent = cur; cin.parent = cur;
+                    cm.node_id = e3 >> 4; cin.node_id = e3 >> 4;
+                    cm.length = (int16_t)(curr.length + 1); cin.length = cm.length;
+                    cm.state_no = (int16_t)next_state; cin.state_no = curr.state_no;
+                    cm.em_state = (uint16_t)(codon | (ST_M << 9)); cin.em_state = (uint16_t)(codon | (ST_I << 9));
+                    const double pen = low ? a.low_cov_penalty : 0.0;                  // :150
+                    {
+                        const double e = mt + (use ? msc[(size_t)next_state * A + col] : 0.0);
+                        cm.real_score = curr.real_score + e - pen;
+                        if (cm.real_score >= curr.max_score) { cm.max_score = cm.real_score; cm.negative_count = 0; }
+                        else { cm.max_score = curr.max_score; cm.negative_count = (int16_t)(curr.negative_count + 1); }
+                        cm.score = curr.score + (e - pen - max_match);
+                        cm.fval = to_fval(10000 * (cm.score + 2.0 * h_m));             // :173
+                        const double ei = it + (next_state == M ? NEG_INF : 0.0);      // isc == 0 except at node M
+                        cin.real_score = curr.real_score + ei - pen;
+                        cin.max_score = curr.max_score;
+                        cin.negative_count = (int16_t)(curr.negative_count + 1);
+                        cin.score = curr.score + (ei - pen);
+                        cin.fval = to_fval(10000 * (cin.score + 2.0 * h_i));
+                    }
+                    bool open_m = use, open_i = use && ins_ok;
+                    if (!first) {                                                      // :212-233: the first expansion neither prunes nor looks up
+                        if (open_m) open_m = admissible(cm.length, cm.negative_count, cm.real_score) && probe_open(cm.node_id, cm.state_no, ST_M, cm.fval);
+                        if (open_i) open_i = admissible(cin.length, cin.negative_count, cin.real_score) && probe_open(cin.node_id, cin.state_no, ST_I, cin.fval);
+                    }
+                    const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
+                    const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
+                    if (open_m) store_node(AR.node(idx_m), cm);
+                    if (open_i) store_node(AR.node(idx_m + (open_m ? 1u : 0u)), cin);
+                    nbase += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
+                    MM |= (mm & 0xFFFFull) << (16 * k);
+                    MI |= (mi & 0xFFFFull) << (16 * k);
+                    if (k == 0) { fm0 = cm.fval; fi0 = cin.fval; } else if (k == 1) { fm1 = cm.fval; fi1 = cin.fval; }
+                    else if (k == 2) { fm2 = cm.fval; fi2 = cin.fval; } else { fm3 = cm.fval; fi3 = cin.fval; }
+                }
+                ANode cd;                                                              // delete child (:218-244), same in every lane
+                cd.parent = cur; cd.node_id = curr.node_id;
+                cd.state_no = (int16_t)next_state; cd.length = curr.length;
+                cd.real_score = curr.real_score + dt;
+                cd.max_score = curr.max_score;
+                cd.negative_count = (int16_t)(curr.negative_count + 1);
+                cd.score = curr.score + (dt - max_match);
+                cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
+                cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
+                bool del = want_del;
+                if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score) && probe_open(cd.node_id, cd.state_no, ST_D, cd.fval);
+                const uint32_t idx_d = nbase;
+                if (del && gl == 0) store_node(AR.node(idx_d), cd);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+                // ---- commit in the reference's order: open_hash[next] = next (:331) and open.push (:335), codon by codon
+                // (ascending lane, then k), match before insert, delete last
+                auto commit = [&](uint64_t key, int fval, uint32_t node) {
+                    HeapEnt he;
+                    he.key = key; he.fval = fval; he.node = node;
+                    if (!first) {
+                        bool found; uint32_t val;
+                        const uint32_t hs = hash_find(hash, hmask, key, found, val);
+                        if (gl == 0) hash_put(hash, hs, key, (found ? (val & 0x80000000u) : 0u) | node);
+                        if (!found) ++n_keys;
+                        n_opened++;
+                    }
+                    H.sift_up(n_heap, he);
+                    ++n_heap;
+                };
+                const uint64_t anyk = MM | MI;
+                uint32_t lanes_todo = (uint32_t)((anyk | (anyk >> 16) | (anyk >> 32) | (anyk >> 48)) & 0xFFFFull);
+                while (lanes_todo) {
+                    const int l = __builtin_ctz(lanes_todo);
+                    lanes_todo &= lanes_todo - 1;
+                    // this lane's children in k order; what they need from lane l: the third edges and the fvals
+                    const int64_t q0 = GX::bcast(p0, l, gbase), q1 = GX::bcast(p1, l, gbase), q2 = GX::bcast(p2, l, gbase), q3 = GX::bcast(p3, l, gbase);
+                    const uint32_t below = (1u << l) - 1u;
+                    uint32_t kbase = n_nodes;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t mmk = (uint32_t)(MM >> (16 * k)) & 0xFFFFu, mik = (uint32_t)(MI >> (16 * k)) & 0xFFFFu;
+                        const bool hm_ = (mmk >> l) & 1u, hi_ = (mik >> l) & 1u;
+                        if (hm_ || hi_) {
+                            const int64_t e3 = k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3;
+                            const uint32_t idx = kbase + (uint32_t)__popc(mmk & below) + (uint32_t)__popc(mik & below);
+                            if (hm_) commit(make_key(e3 >> 4, next_state, ST_M), GX::bcast(k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3, l, gbase), idx);
+                            if (hi_) commit(make_key(e3 >> 4, curr.state_no, ST_I), GX::bcast(k == 0 ? fi0 : k == 1 ? fi1 : k == 2 ? fi2 : fi3, l, gbase),
+                                            idx + (hm_ ? 1u : 0u));
+                        }
+                        kbase += (uint32_t)__popc(mmk) + (uint32_t)__popc(mik);
+                    }
+                }
+                if (del) commit(make_key(cd.node_id, cd.state_no, ST_D), cd.fval, idx_d);
+                n_nodes = nbase + (del ? 1u : 0u);
+                if (first) {
+                    first = false;
+                    n_opened = 1;
+                    if (n_heap == 0) { ok = 0; stop = true; }                          // :235-237
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (stop) st = S_DONE;
+        }
+
+        // ================= result: getHighestScoreNode + partialResultFromGoal (hmm_graph_search.h:83-110,345-356)
+        const bool finishing = st == S_DONE;
+        if (finishing) {
+            mgta_astar_side r;
+            r.ok = ok; r.partial = partial; r.n_closed = n_closed; r.n_expanded = n_expanded; r.n_opened = n_opened;
+            r.fval = 0; r.length = 0; r.state_no = -1; r.state = '-'; r.node_id = -1; r.real_score = 0; r.score = 0;
+            uint32_t len = 0;
+            char *dst = a.out_seq + (size_t)sid * a.out_cap;
+            if (status == 1 && ok && goal >= 0) {
+                int32_t best = goal;
+                ANode nd = load_node(AR.node((uint32_t)goal));
+                double best_rs = nd.real_score;
+                for (int32_t p = nd.parent; p >= 0;) {
+                    nd = load_node(AR.node((uint32_t)p));
+                    if (nd.real_score > best_rs) { best = p; best_rs = nd.real_score; }
+                    p = nd.parent;
+                }
+                const ANode gn = load_node(AR.node((uint32_t)best));
+                r.fval = gn.fval; r.length = gn.length; r.state_no = gn.state_no;
+                r.state = "mid"[gn.em_state >> 9]; r.node_id = gn.node_id; r.real_score = gn.real_score; r.score = gn.score;
+                // 3 characters per non-delete node from the goal back to the start, then reversed (:92-108);
+                // term_nodes.insert(parent -> child) along the same walk (:97-103)
+                nd = gn;
+                while (nd.parent >= 0) {
+                    if ((nd.em_state >> 9) != ST_D) {
+                        if (len + 3 > a.out_cap) { status = 2; break; }
+                        if (gl == 0)
+                            for (int t = 0; t < 3; ++t) dst[len + t] = "acgt-"[(nd.em_state >> (3 * t)) & 7];
+                        len += 3;
+                    }
+                    const ANode par = load_node(AR.node((uint32_t)nd.parent));
+                    if (a.window > 0 && gl == 0)
+                        cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
+                                     seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
+                    nd = par;
+                }
+                if (gl == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    for (uint32_t x = 0; x < len / 2; ++x) { char t = dst[x]; dst[x] = dst[len - 1 - x]; dst[len - 1 - x] = t; }
+                }
+            }
+            if (gl == 0) {
+                a.sides[sid] = r;
+                a.out_len[sid] = len;
+                a.status[sid] = status;
+            }
+            // everything above the base arena goes back to the pool
+            if (n_levels > 1 || hclass > base_hclass) {
+                pool_release_fence();
+                if (gl == 0) {
+                    for (int l = 1; l < n_levels; ++l) pool_free(a.pool, chunk_class(log_b0, l), seg[l]);
+                    if (hclass > base_hclass) pool_free(a.pool, hclass, (uint32_t)((reinterpret_cast<char *>(hash) - a.pool.base) >> kUnitLog));
+                }
+            }
+            n_levels = 1; cap_nodes = B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            if (a.gate && gl == 0) {     // the paths are in the cache (atomics, all performed): this search no longer holds anybody back
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&a.run_seed[slot], -1ll);
+            }
+            st = S_IDLE;
+        }
+        if (a.gate && __ballot(finishing) != 0ull) (void)start_bound<G>(a, dir, lane);   // whoever finishes a search moves the limit for the waiting ones
+    }
+}
+
+}  // namespace mgta

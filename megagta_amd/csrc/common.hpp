@@ -59,10 +59,8 @@ struct DevBuf {
 }  // namespace mgta
 
 namespace mgta {
-struct AstarArenas {           // grow-by-replacement A* work memory kept between mgta_astar_batch calls
-    DevBuf nodes, heap, hash, tag;
-    uint64_t slots = 0;
-    uint32_t cap_nodes = 0;
+struct AstarArenas {           // A* work memory kept between mgta_astar_batch calls: the chunk pool (base arenas of the search slots +
+    DevBuf pool, meta;         // the region the searches grow into) and the allocator's bookkeeping
 };
 }  // namespace mgta
 
@@ -73,6 +71,8 @@ struct mgta_ctx {
     uint64_t mem_limit = 0;       // 0 = auto
     int force_full_lsd = 0;
     int lsd_skip_left = 0;       // sorts left that go straight to LSD passes in LDS (the last look found mostly long runs)
+    int astar_log_b0 = 0;        // base arena of a search slot = 1 << astar_log_b0 nodes (0 = default 12); searches grow beyond it in place
+    uint64_t astar_pool_bytes = 0;   // device memory the searches may grow into (0 = auto)
     int search_cost_rate = 0;    // shared-cache searches: a path found with c expansions becomes visible c / rate seeds later (0 = no cost term)
     int force_lsd_tiles = 0;     // segment-local sort: LSD passes over every digit, no finish by comparison
     uint64_t live_bytes = 0, peak_bytes = 0;

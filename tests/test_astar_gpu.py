@@ -48,12 +48,26 @@ def _check_side(got, ref):
     assert got["n_closed"] == ref["closed"]
 
 
+@pytest.fixture(params=[(16, 0), (64, 0), (16, 7), (64, 7)], ids=["g16", "g64", "g16-grow", "g64-grow"])
+def search_mode(request, ctx):
+    """lanes per search (16: four searches per wavefront; 64: one) x base arena (0 = default 4096 nodes; 7 = 128 nodes: every search
+    of the goldens then outgrows its base arena and re-hashes several times)"""
+    group, log_b0 = request.param
+    os.environ["MGTA_ASTAR_GROUP"] = str(group)
+    ctx.set_search_arena(log_b0, 0)
+    yield request.param
+    os.environ.pop("MGTA_ASTAR_GROUP", None)
+    ctx.set_search_arena(0, 0)
+
+
 @pytest.mark.parametrize("fname,prune", [("astar_cold.txt.gz", 20), ("astar_cold_prune0.txt.gz", 0)])
-def test_cold_cache_vs_reference(toy, fname, prune):
+def test_cold_cache_vs_reference(toy, fname, prune, search_mode):
     from megagta_amd import api
     g, fw, rv, d = toy
     gold = H.parse_probe_astar(H.gz_lines(os.path.join(d, fname)))
     res, st = api.astar_search(g, fw, rv, [r["kmer"] for r in gold], [r["start_state"] for r in gold], prune, 0.5)
+    if search_mode[1]:
+        assert st["n_grown"] > 0 and st["n_rehash"] > 0 and st["n_retries"] == 0
     for r, ref in zip(res, gold):
         _check_side(r.right_side, ref["R"])
         _check_side(r.left_side, ref["L"])
@@ -98,7 +112,38 @@ def test_bad_seed_is_loud(toy):
         api.astar_search(g, fw, rv, ["A" * 45], [95], 20, 0.5)      # model position + 15 codons > M = 100
 
 
-def test_warm_sequential_equals_reference_search_1thread(toy):
+def test_pool_exhaustion_reruns_only_the_searches_it_hit(toy, ctx):
+    """a pool far too small for the searches in flight: the searches it cannot hold are run again (fewer at a time) and every result
+    still equals the reference's; a pool that cannot hold even one search is a loud error, never a wrong or missing contig"""
+    from megagta_amd import api
+    g, fw, rv, d = toy
+    gold = H.parse_probe_astar(H.gz_lines(os.path.join(d, "astar_cold_prune0.txt.gz")))
+    kmers, states = [r["kmer"] for r in gold], [r["start_state"] for r in gold]
+    seen_retry = False
+    try:
+        sizes = []
+        for kb in (16, 32, 64, 128, 256, 512, 1024, 4096, 16384, 65536):
+            ctx.set_search_arena(7, kb << 10)
+            try:
+                res, st = api.astar_search(g, fw, rv, kmers, states, 0, 0.5)
+            except api.MegaGtaError as e:
+                assert "do not fit" in str(e)
+                sizes.append((kb, "error"))
+                continue
+            sizes.append((kb, st["n_retries"]))
+            seen_retry |= st["n_retries"] > 0
+            for r, ref in zip(res, gold):
+                _check_side(r.right_side, ref["R"])
+                _check_side(r.left_side, ref["L"])
+                assert r.contig(ref["kmer"]) == ref["contig"]
+            if st["n_retries"] == 0:
+                break
+    finally:
+        ctx.set_search_arena(0, 0)
+    assert seen_retry, sizes
+
+
+def test_warm_sequential_equals_reference_search_1thread(toy, search_mode):
     """cache_mode 1: shared term_nodes caches with ordered commits == `megagta search ... 1` (per seed AND the FASTA file)"""
     from megagta_amd import api
     g, fw, rv, d = toy
