@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmegagta_hip.so")
+LIB_PATH = os.environ.get("MEGAGTA_HIP_LIB") or os.path.join(_HERE, "libmegagta_hip.so")   # (override: diagnostic builds)
 
 
 class MegaGtaError(RuntimeError):

@@ -47,7 +47,7 @@ void launch_astar(const mgta::AstarArgs &a, int blocks, size_t lds_bytes, bool u
     MGTA_HIP_CHECK(hipGetLastError());
 }
 template <int G> size_t lds_fixed() {
-    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * ((mgta::Grp<G>::kLdsHeap + 1) * sizeof(mgta::HeapEnt) + mgta::kMaxLevels * sizeof(uint32_t));
+    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::kLdsHeapSlots * sizeof(mgta::HeapEnt) + 2 * mgta::kMaxLevels * sizeof(uint32_t));
 }
 }  // namespace
 
@@ -177,6 +177,10 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         a.queue = d_queue.as<unsigned long long>();
         a.sides = d_sides.as<mgta_astar_side>(); a.out_seq = d_out.as<char>(); a.out_cap = out_cap; a.out_len = d_len.as<uint32_t>();
         a.status = d_status.as<int32_t>();
+        DevBuf d_prof;
+        d_prof.alloc(128);
+        MGTA_HIP_CHECK(hipMemsetAsync(d_prof.p, 0, 128, st));
+        a.prof = d_prof.as<unsigned long long>();
         const size_t lds_fix = G == 16 ? lds_fixed<16>() : lds_fixed<64>();
         const bool use_lds = lds_fix + tab_bytes + 1024 <= 160 * 1024;             // heap tops + level tables + HMM tables
         const size_t lds_bytes = lds_fix + (use_lds ? tab_bytes : 0);
@@ -210,7 +214,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         }
 
         const int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 12;
-        const uint64_t slot_bytes = 96ull << log_b0;                                // 64 B per node (+ heap slot) and 2 x 16 B of hash table
+        const uint64_t slot_bytes = 128ull << log_b0;                               // per node of the base arena: 64 B + 2 heap slots + 2 hash entries of 16 B
         AstarArenas &ar = ctx->astar;
         for (int attempt = 0; attempt < 3; ++attempt) {
             const int64_t work = (int64_t)std::max(todo[0].size(), todo[1].size());
@@ -218,6 +222,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             // persistent grid: one workgroup per CU and direction pair, fewer when there is little work; a pass that re-runs the
             // searches the pool could not hold runs fewer at a time
             int64_t blocks = std::min<int64_t>((int64_t)ctx->num_cus * (use_lds ? 1 : 2), 2 * ((work + spb - 1) / spb));
+            if (const char *e = getenv("MGTA_ASTAR_BLOCKS")) blocks = std::min<int64_t>(blocks, std::max(2, atoi(e)));   // (diagnostic)
             if (attempt == 1) blocks = std::max<int64_t>(2, blocks / 8);
             if (attempt == 2) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
@@ -306,6 +311,16 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 set_error("search %lld did not run (ordered-commit gate timed out)", (long long)s);
                 return MGTA_EHIP;
             }
+#ifdef MGTA_ASTAR_PROFILE
+        {
+            unsigned long long hp[12];
+            MGTA_HIP_CHECK(hipMemcpy(hp, d_prof.p, 96, hipMemcpyDeviceToHost));
+            const char *nm[12] = {"fetch", "gate", "start", "pop+closed", "grow", "cache+walk", "score+probe", "commit", "(run end)", "result+free", "", ""};
+            unsigned long long tot = 0;
+            for (int q = 0; q < 10; ++q) tot += hp[q];
+            for (int q = 0; q < 10; ++q) fprintf(stderr, "[astar-prof] %-12s %6.2f %%\n", nm[q], 100.0 * hp[q] / (tot ? tot : 1));
+        }
+#endif
         // results
         std::vector<mgta_astar_side> h_sides((size_t)n * 2);
         std::vector<uint32_t> h_len((size_t)n * 2);

@@ -24,7 +24,8 @@ constexpr int kAstarWaves = 8;                 // waves per workgroup (one workg
 constexpr int kAstarThreads = kAstarWaves * 64;
 constexpr uint32_t kNone = 0x7FFFFFFFu;
 constexpr int kMaxKmer = 160;
-constexpr int kMaxLevels = 32;                 // arena levels per search (level l >= 1 doubles the capacity)
+constexpr int kMaxLevels = 20;                 // levels of a growable array (level l >= 1 doubles the capacity)
+constexpr uint32_t kLdsHeapSlots = 72;         // heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels)
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
@@ -41,8 +42,9 @@ struct ANode {                    // AStarNode, a_star_node.h:9-33
     int32_t fval;
     int16_t state_no, length, negative_count;
     uint16_t em_state;            // nucl_emission (9 bits) | state << 9
+    uint32_t pad[4];              // one node = one aligned 64-byte sector: a node access is a single request
 };
-static_assert(sizeof(ANode) == 48, "node layout");
+static_assert(sizeof(ANode) == 64, "node layout");
 
 struct HeapEnt {                  // 16 bytes; the priority (fval, -state_no, state rank) is rebuilt from key + fval
     uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1)
@@ -100,7 +102,7 @@ struct AstarArgs {
     PoolDev pool;
     unsigned long long base_off;  // byte offset of slot 0's base arena in the pool; slot s owns [base_off + s * slot_bytes, ...)
     unsigned long long slot_bytes;
-    int log_b0;                   // base arena = 1 << log_b0 nodes (+ heap) and 2 << log_b0 hash entries
+    int log_b0;                   // base arena = 1 << log_b0 nodes, 2 << log_b0 heap slots and 2 << log_b0 hash entries
     mgta_astar_side *sides;       // [2n]
     char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
     int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = pool exhausted, 3 = bad seed, 4 = gate timeout
@@ -120,6 +122,7 @@ struct AstarArgs {
     unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
     unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last refresh by a waiting wave
     uint32_t n_slots;
+    unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
                                   // direction at a time, with the whole pool to itself)
 };
@@ -246,38 +249,32 @@ __device__ __forceinline__ void pool_release_fence() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---- one search's arena ------------------------------------------------------------------------------------------------------
-struct Arena {
-    const uint32_t *seg;          // LDS: chunk (4 KB units) of every level of this search
+// ---- growable arrays of one search ---------------------------------------------------------------------------------------------
+// Element i lives in level l = 0 for i < B0, else 1 + floor(log2(i / B0)); level l >= 1 covers [B0 << (l-1), B0 << l).  Every level
+// is one chunk of the pool (level 0: the slot's own base arena), so the array grows without moving anything.
+template <int ELEM_LOG>
+struct Grow {
+    const uint32_t *seg;          // LDS: chunk (4 KB units) of every level
     char *pool;
     int log_b0;
-    __device__ __forceinline__ void locate(uint32_t i, char *&base, uint32_t &size, uint32_t &off) const {
+    __device__ __forceinline__ char *at(uint32_t i) const {
         const uint32_t hi = i >> log_b0;
         const int level = hi ? 32 - __builtin_clz(hi) : 0;
-        size = level ? (1u << (log_b0 + level - 1)) : (1u << log_b0);
-        off = level ? i - size : i;
-        base = pool + ((uint64_t)seg[level] << kUnitLog);
+        const uint32_t off = level ? i - (1u << (log_b0 + level - 1)) : i;
+        return pool + ((uint64_t)seg[level] << kUnitLog) + ((uint64_t)off << ELEM_LOG);
     }
-    __device__ __forceinline__ ANode *node(uint32_t i) const {
-        char *b; uint32_t sz, off;
-        locate(i, b, sz, off);
-        return reinterpret_cast<ANode *>(b) + off;
-    }
-    __device__ __forceinline__ HeapEnt *heap(uint32_t i) const {      // the heap slots of a level follow its nodes
-        char *b; uint32_t sz, off;
-        locate(i, b, sz, off);
-        return reinterpret_cast<HeapEnt *>(b + (uint64_t)sz * sizeof(ANode)) + off;
-    }
+    __device__ __forceinline__ int chunk_class(int level) const { return ELEM_LOG + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
 };
-__device__ __forceinline__ int chunk_class(int log_b0, int level) { return 6 + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
+using NodeArr = Grow<6>;
+using HeapArr = Grow<4>;
 __device__ __forceinline__ ANode load_node(const ANode *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    union { uint4 v[3]; ANode n; } u;
+    union { uint4 v[4]; ANode n; } u;
     u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2];
     return u.n;
 }
 __device__ __forceinline__ void store_node(ANode *p, const ANode &n) {
-    union { uint4 v[3]; ANode n; } u;
+    union { uint4 v[4]; ANode n; } u;
     u.n = n;
     uint4 *q = reinterpret_cast<uint4 *>(p);
     q[0] = u.v[0]; q[1] = u.v[1]; q[2] = u.v[2];
@@ -296,19 +293,44 @@ __device__ __forceinline__ void store_ent(HeapEnt *p, const HeapEnt &e) {
 template <int G> struct Grp {
     static constexpr int kGroups = 64 / G;
     static constexpr int kLog = G == 64 ? 6 : G == 32 ? 5 : 4;
-    static constexpr uint32_t kLdsHeap = (1u << kLog) * 4u - 1u;       // heap entries of a search kept in LDS: 63 / 127 / 255
     static constexpr uint64_t kMask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
     __device__ static __forceinline__ uint64_t ballot(bool p, int gbase) { return (__ballot(p) >> gbase) & kMask; }
     template <class T> __device__ static __forceinline__ T bcast(T v, int src, int gbase) { return __shfl(v, gbase + src, 64); }
 };
 
+// The open list is libstdc++'s binary heap LOGICALLY (index i, children 2i+1 and 2i+2: the sift sequences below are __push_heap /
+// __adjust_heap word for word, so entries of equal priority leave in the reference's order), but entry i is STORED in blocks of
+// three tree levels: one 128-byte line holds a node, its two children and its four grandchildren (slots 1..7 of the block, slot 0
+// unused), blocks of one block level in tree order.  A walk down the tree then touches one line per three levels instead of one per
+// level, and the two lines below a block's leaf are adjacent.
+__device__ __forceinline__ uint32_t heap_slot(uint32_t i) {
+    const uint32_t j = i + 1;
+    const int l = 31 - __builtin_clz(j);
+    const int b = (l * 11) >> 5, r = l - 3 * b;                        // block level (l / 3) and level inside the block
+    const uint32_t lvl = 1u << (3 * b);
+    const uint32_t blk = (0x49249249u & (lvl - 1u)) + ((j >> r) - lvl);   // blocks of the levels above: (8^b - 1) / 7
+    return blk * 8u + ((1u << r) | (j & ((1u << r) - 1u)));
+}
+// slots a heap of n entries needs (the deepest block level is complete as soon as its second tree level has begun)
+__device__ __forceinline__ uint32_t heap_slots_needed(uint32_t n) {
+    const int l = 31 - __builtin_clz(n | 1u);
+    const int b = (l * 11) >> 5, r = l - 3 * b;
+    const uint32_t lvl = 1u << (3 * b);
+    const uint32_t blocks = (0x49249249u & (lvl - 1u)) + (r == 0 ? n - lvl + 1u : lvl);
+    return blocks * 8u;
+}
+
 template <int G> struct Heap {
-    HeapEnt *lds;                 // this search's top Grp<G>::kLdsHeap entries
-    Arena ar;
+    HeapEnt *lds;                 // this search's first kLdsHeapSlots slots
+    HeapArr ar;
     int gl, gbase;
-    __device__ __forceinline__ HeapEnt get(uint64_t i) const { return i < Grp<G>::kLdsHeap ? lds[i] : load_ent(ar.heap((uint32_t)i)); }
+    __device__ __forceinline__ HeapEnt get(uint64_t i) const {
+        const uint32_t s = heap_slot((uint32_t)i);
+        return s < kLdsHeapSlots ? lds[s] : load_ent(reinterpret_cast<const HeapEnt *>(ar.at(s)));
+    }
     __device__ __forceinline__ void set(uint64_t i, const HeapEnt &e) const {
-        if (i < Grp<G>::kLdsHeap) lds[i] = e; else store_ent(ar.heap((uint32_t)i), e);
+        const uint32_t s = heap_slot((uint32_t)i);
+        if (s < kLdsHeapSlots) lds[s] = e; else store_ent(reinterpret_cast<HeapEnt *>(ar.at(s)), e);
     }
     // __push_heap(first, hole, 0, v) (bits/stl_heap.h): every lane of the group calls it with the same arguments
     __device__ __forceinline__ void sift_up(uint64_t hole, const HeapEnt &v) const {
@@ -332,10 +354,11 @@ template <int G> struct Heap {
         }
     }
     // pop_heap + pop_back; n = current size (> 0); returns the former top.
-    // __adjust_heap walks down from the root moving the larger child up (the right one unless right < left).  log2(G) levels per
-    // memory round trip: lane l < G-1 holds one PAIR of siblings of the subtree under the hole (level t = floor(log2(l+1)) + 1,
-    // pair p = l + 1 - 2^(t-1)), decides locally which of the two its parent would pick, a chain of ballots tells which lanes lie on
-    // the path, and those lanes move their entries up at once.
+    // __adjust_heap walks down from the root moving the larger child up (the right one unless right < left).  Three levels per
+    // memory round trip (two below the root: the rounds then stay aligned with the blocks, and a round reads the two adjacent child
+    // blocks of the hole): lane l < 7 holds one PAIR of siblings of the subtree under the hole (level t = floor(log2(l+1)) + 1,
+    // pair p = l + 1 - 2^(t-1)), decides locally which of the two its parent would pick, a chain of ballots tells which lanes lie
+    // on the path, and those lanes move their entries up at once.
     __device__ __forceinline__ HeapEnt pop(uint32_t n) const {
         const HeapEnt top = get(0);
         if (n > 1) {
@@ -343,13 +366,13 @@ template <int G> struct Heap {
             const int64_t len = (int64_t)n - 1;
             const int64_t half = (len - 1) / 2;                        // nodes below `half` have two children
             int64_t hole = 0;
-            const int t = 32 - __builtin_clz((unsigned)gl + 1);        // 1 .. log2(G) for lanes 0 .. G-2
+            const int t = 32 - __builtin_clz((unsigned)gl + 1);        // 1, 2, 2, 3, 3, 3, 3 for lanes 0 .. 6
             const int p = gl + 1 - (1 << (t - 1));
             const int parent_lane = t > 1 ? (1 << (t - 2)) - 1 + (p >> 1) : 0;
-            const bool role = gl < G - 1;
+            int levels = 2;                                            // the root block holds two levels below the root
             while (hole < half) {
                 const int64_t P = ((hole + 1) << (t - 1)) - 1 + p;    // the node whose two children this lane holds
-                const bool has = role && P < half;
+                const bool has = t <= levels && P < half;
                 HeapEnt el, er;
                 el.key = 0; el.fval = 0; el.node = 0; er = el;
                 if (has) { el = get((uint64_t)(2 * P + 1)); er = get((uint64_t)(2 * P + 2)); }
@@ -357,7 +380,7 @@ template <int G> struct Heap {
                 const uint64_t pl = Grp<G>::ballot(pick_left, gbase);
                 uint64_t path = 0;
 #pragma unroll
-                for (int tt = 1; tt <= Grp<G>::kLog; ++tt) {
+                for (int tt = 1; tt <= 3; ++tt) {
                     const bool on = has && t == tt &&
                                     (tt == 1 || (((path >> parent_lane) & 1ull) && (int)((pl >> parent_lane) & 1ull) == ((p & 1) ^ 1)));
                     path |= Grp<G>::ballot(on, gbase);
@@ -367,6 +390,7 @@ template <int G> struct Heap {
                 if ((path >> gl) & 1ull) set((uint64_t)P, ch);                    // every node of the path moves up one level
                 const int deepest = 63 - __builtin_clzll(path);                   // path != 0: the hole has two children
                 hole = Grp<G>::bcast(pick_left ? 2 * P + 1 : 2 * P + 2, deepest, gbase);
+                levels = 3;
             }
             if ((len & 1) == 0 && hole == (len - 2) / 2) {             // a last, single (left) child
                 const HeapEnt ce = get((uint64_t)(2 * hole + 1));
@@ -475,16 +499,25 @@ __device__ __forceinline__ int base_of(char ch) {
            : (ch == 'T' || ch == 't') ? 3 : -1;
 }
 
+#ifdef MGTA_ASTAR_PROFILE   // diagnostic build only: per-phase cycle sums (s_memtime) of every wave
+#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; }
+#define PROF_FLUSH if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&a.prof[q_], pacc_[q_]);
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH
+#endif
+
 template <int G, bool LDS>
 __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     using GX = Grp<G>;
     constexpr int GROUPS = GX::kGroups;
     constexpr uint32_t SPB = kAstarWaves * GROUPS;
-    constexpr uint32_t LH = GX::kLdsHeap;
-    extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][level tables][HMM tables]
+    extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][level tables: nodes, heap][HMM tables]
     HeapEnt *const s_heap = reinterpret_cast<HeapEnt *>(s_mem);
-    uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * (LH + 1) * sizeof(HeapEnt));
-    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * ((LH + 1) * sizeof(HeapEnt) + kMaxLevels * sizeof(uint32_t)));
+    uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * kLdsHeapSlots * sizeof(HeapEnt));
+    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + 2 * kMaxLevels * sizeof(uint32_t)));
 
     const int dir = blockIdx.x & 1;
     HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
@@ -511,20 +544,25 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     const int64_t n_todo = dir ? a.n_todo[1] : a.n_todo[0];
     const int64_t *todo = dir ? a.todo[1] : a.todo[0];
 
-    // this slot's base arena: level 0 of the node pool + heap, then the base hash table
-    uint32_t *const seg = s_seg + (size_t)lslot * kMaxLevels;
+    // this slot's base arena: B0 nodes (64 B), 2 B0 heap slots (16 B), 2 B0 hash entries (16 B)
+    uint32_t *const seg = s_seg + (size_t)lslot * 2 * kMaxLevels, *const hseg = seg + kMaxLevels;
     const int log_b0 = a.log_b0;
     const uint32_t B0 = 1u << log_b0;
     const int base_hclass = 5 + log_b0 - kUnitLog;
     char *const slot_base = a.pool.base + a.base_off + (uint64_t)slot * a.slot_bytes;
-    HashEnt *const base_hash = reinterpret_cast<HashEnt *>(slot_base + ((uint64_t)64 << log_b0));
-    if (gl == 0) seg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes) >> kUnitLog);
+    HashEnt *const base_hash = reinterpret_cast<HashEnt *>(slot_base + ((uint64_t)96 << log_b0));
+    if (gl == 0) {
+        seg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes) >> kUnitLog);
+        hseg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes + ((uint64_t)64 << log_b0)) >> kUnitLog);
+    }
     wave_lds_fence();
     Heap<G> H;
-    H.lds = s_heap + (size_t)lslot * (LH + 1);
-    H.ar.seg = seg; H.ar.pool = a.pool.base; H.ar.log_b0 = log_b0;
+    H.lds = s_heap + (size_t)lslot * kLdsHeapSlots;
+    H.ar.seg = hseg; H.ar.pool = a.pool.base; H.ar.log_b0 = log_b0 + 1;
     H.gl = gl; H.gbase = gbase;
-    const Arena &AR = H.ar;
+    NodeArr AR;
+    AR.seg = seg; AR.pool = a.pool.base; AR.log_b0 = log_b0;
+    auto node_at = [&](uint32_t i) { return reinterpret_cast<ANode *>(AR.at(i)); };
 
     // ---- per-search state (uniform inside a group)
     int st = S_IDLE;
@@ -532,8 +570,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     unsigned long long spins = 0;
     long long seed = -1;
     int64_t sid = 0;
-    uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0;
-    int n_levels = 1;
+    uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0, cap_heap = 2 * B0;
+    int n_levels = 1, h_levels = 1;
     HashEnt *hash = base_hash;
     uint32_t hmask = 2 * B0 - 1;
     int hclass = base_hclass;
@@ -546,6 +584,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     curr.score = curr.real_score = curr.max_score = 0; curr.node_id = 0; curr.parent = -1; curr.fval = 0;
     curr.state_no = curr.length = curr.negative_count = 0; curr.em_state = 0;
 
+    PROF_DECL
     while (true) {
         // ================= next search for the idle slots
         if (st == S_IDLE && lslot >= a.active_slots) st = S_EXIT;
@@ -578,6 +617,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
         }
         if (__ballot(st != S_EXIT) == 0ull) break;
+        PROF(0)
 
         // ================= ordered-commit gate (shared-cache launches): wave-level, never blocks the searches that are running
         // Seed i may start once no unfinished search j can still become visible to it: i < j + B + progress_j / cost_rate for every
@@ -620,9 +660,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
         }
 
+        PROF(1)
         // ================= start node (hmm_graph_search.h:132-189)
         if (st == S_START) {
-            n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1;
+            n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1; cap_heap = 2 * B0; h_levels = 1;
             hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true;
@@ -654,7 +695,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 curr.parent = -1; curr.state_no = (int16_t)(sstate + n_aa); curr.em_state = (uint16_t)(ST_M << 9); curr.length = (int16_t)n_aa;
                 curr.fval = 0; curr.score = sc; curr.real_score = rs; curr.max_score = 0; curr.negative_count = 0;
                 curr.node_id = a.start_node[sid];
-                if (gl == 0) store_node(AR.node(0), curr);
+                if (gl == 0) store_node(node_at(0), curr);
                 n_nodes = 1;
                 inter_val = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
                 if (curr.state_no >= M) { ok = 1; goal = 0; st = S_DONE; }             // :193-197
@@ -663,6 +704,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
 
+        PROF(2)
         // ================= one expansion
         if (st == S_RUN) {
             bool stop = false;
@@ -685,7 +727,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 if (!have) { partial = 1; ok = 1; goal = inter; stop = true; }        // open list ran dry (:339-341)
                 else {
-                    curr = load_node(AR.node((uint32_t)cur));
+                    curr = load_node(node_at((uint32_t)cur));
                     const double cv = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
                     const bool better = cv > inter_val;
                     if (curr.state_no >= M) {                                          // goal (:259-270)
@@ -698,12 +740,13 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     }
                 }
             }
+            PROF(3)
             // room for this expansion's children: the arena grows in place, the table is re-hashed when half full
             if (!stop && n_nodes + kMaxNew > cap_nodes) {
                 uint32_t unit = 0;
                 if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && chunk_class(log_b0, n_levels) < kNumClasses) {
-                    if (gl == 0) unit = pool_alloc(a.pool, chunk_class(log_b0, n_levels));
+                while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && AR.chunk_class(n_levels) < kNumClasses) {
+                    if (gl == 0) unit = pool_alloc(a.pool, AR.chunk_class(n_levels));
                     unit = GX::bcast(unit, 0, gbase);
                     if (unit == kNoChunk) break;
                     if (gl == 0) seg[n_levels] = unit;
@@ -712,6 +755,20 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 wave_lds_fence();
                 if (n_nodes + kMaxNew > cap_nodes) { status = 2; stop = true; }
+            }
+            if (!stop && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {
+                uint32_t unit = 0;
+                const uint32_t need = heap_slots_needed(n_heap + kMaxNew);
+                while (need > cap_heap && h_levels < kMaxLevels && H.ar.chunk_class(h_levels) < kNumClasses) {
+                    if (gl == 0) unit = pool_alloc(a.pool, H.ar.chunk_class(h_levels));
+                    unit = GX::bcast(unit, 0, gbase);
+                    if (unit == kNoChunk) break;
+                    if (gl == 0) hseg[h_levels] = unit;
+                    cap_heap = (2 * B0) << h_levels;
+                    ++h_levels;
+                }
+                wave_lds_fence();
+                if (need > cap_heap) { status = 2; stop = true; }
             }
             while (!stop && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
                 uint32_t unit = kNoChunk;
@@ -753,6 +810,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 hash = nt; hmask = nmask; ++hclass;
             }
 
+            PROF(4)
             if (!stop) {
                 const int cst = curr.em_state >> 9;
                 const int next_state = curr.state_no + 1;
@@ -767,23 +825,14 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // ---- enumeration of the <= 64 codon paths (node_enumerator.h:98-128): lane (i, j) walks two edges and owns the <= 4
                 // third edges that continue from there
                 int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-                LineR Ls = g_load_line(g, (uint64_t)curr.node_id >> 6), Lt;
-                uint64_t lt_idx = 0;
-                const int od1 = g_outgoing_line(g, Ls, curr.node_id, p0, p1, p2, p3, Lt, lt_idx);
                 const int ci = (gl >> 2) & 3, cj = gl & 3;
-                bool valid = gl < 16 && ci < od1;
+                int64_t e1 = 0, e2 = 0;
+                bool valid = gl < 16 && ci < g_out_nth(g, curr.node_id, ci, e1);
                 int od3 = 0, c12 = 0, low12 = 0;
                 if (valid) {
-                    const int64_t e1 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, ci);
-                    if ((uint64_t)(e1 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e1 >> 10));   // (e1 >> 4) >> 6: rare, a node's edges straddle two lines
-                    Ls = Lt;
-                    const int od2 = g_outgoing_line(g, Ls, e1 >> 4, p0, p1, p2, p3, Lt, lt_idx);
-                    valid = cj < od2;
+                    valid = cj < g_out_nth(g, e1 >> 4, cj, e2);
                     if (valid) {
-                        const int64_t e2 = (int64_t)sel4((uint64_t)p0, (uint64_t)p1, (uint64_t)p2, (uint64_t)p3, cj);
-                        if ((uint64_t)(e2 >> 10) != lt_idx) Lt = g_load_line(g, (uint64_t)(e2 >> 10));
-                        Ls = Lt;
-                        od3 = g_outgoing_line(g, Ls, e2 >> 4, p0, p1, p2, p3, Lt, lt_idx);
+                        od3 = g_out_all(g, e2 >> 4, p0, p1, p2, p3);
                         if (od3 < 0) od3 = 0;
                         c12 = (((int)(e1 & 7) - 1) << 6) | (((int)(e2 & 7) - 1) << 3);
                         low12 = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1);
@@ -794,6 +843,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (a.gate && a.cost_rate > 0 && (n_expanded & 63) == 0 && gl == 0)
                     __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+                PROF(5)
                 // ---- children (node_enumerator.h:131-244)
                 double mt, it, dt;
                 if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
@@ -834,7 +884,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         if (k == key) {
                             const uint32_t oi = v.z & kNone;
                             if (oi == kNone) return true;
-                            return AR.node(oi)->fval < fval;                           // got->second < next (:299-302); equal keys => only fval differs
+                            return node_at(oi)->fval < fval;                           // got->second < next (:299-302); equal keys => only fval differs
                         }
                         ii = (ii + 1) & hmask;
                     }
@@ -880,8 +930,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     }
                     const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
                     const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
-                    if (open_m) store_node(AR.node(idx_m), cm);
-                    if (open_i) store_node(AR.node(idx_m + (open_m ? 1u : 0u)), cin);
+                    if (open_m) store_node(node_at(idx_m), cm);
+                    if (open_i) store_node(node_at(idx_m + (open_m ? 1u : 0u)), cin);
                     nbase += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
                     MM |= (mm & 0xFFFFull) << (16 * k);
                     MI |= (mi & 0xFFFFull) << (16 * k);
@@ -900,9 +950,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 bool del = want_del;
                 if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score) && probe_open(cd.node_id, cd.state_no, ST_D, cd.fval);
                 const uint32_t idx_d = nbase;
-                if (del && gl == 0) store_node(AR.node(idx_d), cd);
+                if (del && gl == 0) store_node(node_at(idx_d), cd);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
+                PROF(6)
                 // ---- commit in the reference's order: open_hash[next] = next (:331) and open.push (:335), codon by codon
                 // (ascending lane, then k), match before insert, delete last
                 auto commit = [&](uint64_t key, int fval, uint32_t node) {
@@ -950,8 +1001,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
+            PROF(7)
             if (stop) st = S_DONE;
         }
+        PROF(8)
 
         // ================= result: getHighestScoreNode + partialResultFromGoal (hmm_graph_search.h:83-110,345-356)
         const bool finishing = st == S_DONE;
@@ -963,14 +1016,14 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             char *dst = a.out_seq + (size_t)sid * a.out_cap;
             if (status == 1 && ok && goal >= 0) {
                 int32_t best = goal;
-                ANode nd = load_node(AR.node((uint32_t)goal));
+                ANode nd = load_node(node_at((uint32_t)goal));
                 double best_rs = nd.real_score;
                 for (int32_t p = nd.parent; p >= 0;) {
-                    nd = load_node(AR.node((uint32_t)p));
+                    nd = load_node(node_at((uint32_t)p));
                     if (nd.real_score > best_rs) { best = p; best_rs = nd.real_score; }
                     p = nd.parent;
                 }
-                const ANode gn = load_node(AR.node((uint32_t)best));
+                const ANode gn = load_node(node_at((uint32_t)best));
                 r.fval = gn.fval; r.length = gn.length; r.state_no = gn.state_no;
                 r.state = "mid"[gn.em_state >> 9]; r.node_id = gn.node_id; r.real_score = gn.real_score; r.score = gn.score;
                 // 3 characters per non-delete node from the goal back to the start, then reversed (:92-108);
@@ -983,7 +1036,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                             for (int t = 0; t < 3; ++t) dst[len + t] = "acgt-"[(nd.em_state >> (3 * t)) & 7];
                         len += 3;
                     }
-                    const ANode par = load_node(AR.node((uint32_t)nd.parent));
+                    const ANode par = load_node(node_at((uint32_t)nd.parent));
                     if (a.window > 0 && gl == 0)
                         cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
                                      seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
@@ -1000,14 +1053,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 a.status[sid] = status;
             }
             // everything above the base arena goes back to the pool
-            if (n_levels > 1 || hclass > base_hclass) {
+            if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
                 pool_release_fence();
                 if (gl == 0) {
-                    for (int l = 1; l < n_levels; ++l) pool_free(a.pool, chunk_class(log_b0, l), seg[l]);
+                    for (int l = 1; l < n_levels; ++l) pool_free(a.pool, AR.chunk_class(l), seg[l]);
+                    for (int l = 1; l < h_levels; ++l) pool_free(a.pool, H.ar.chunk_class(l), hseg[l]);
                     if (hclass > base_hclass) pool_free(a.pool, hclass, (uint32_t)((reinterpret_cast<char *>(hash) - a.pool.base) >> kUnitLog));
                 }
             }
-            n_levels = 1; cap_nodes = B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
             if (a.gate && gl == 0) {     // the paths are in the cache (atomics, all performed): this search no longer holds anybody back
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&a.run_seed[slot], -1ll);
@@ -1015,7 +1069,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             st = S_IDLE;
         }
         if (a.gate && __ballot(finishing) != 0ull) (void)start_bound<G>(a, dir, lane);   // whoever finishes a search moves the limit for the waiting ones
+        PROF(9)
     }
+    PROF_FLUSH
 }
 
 }  // namespace mgta

@@ -256,6 +256,110 @@ __device__ __forceinline__ int g_outgoing_line(const GraphDev &g, const LineR &L
     return od > 4 ? 4 : od;
 }
 
+// ---- OutgoingEdges without a loop: the edges of the node Forward(e) points to are the positions (y, x] where x is the node's `last`
+// edge and y the nearest lower edge with last | tip set; inside one line that is a mask, the valid ones are mask & ~invalid, and the
+// n-th edge in the reference's (descending) order is the n-th highest set bit.  Only a node whose edges straddle a line boundary
+// (about one in thirty) needs the words of the line before (vm_lo, fetched on demand).
+struct OutSet {
+    uint64_t vm_hi, vm_lo;        // valid out-edges in line li / in line li - 1
+    uint64_t li;
+    int od;                       // min(4, number of edges), -1 = `e` is not a valid edge
+};
+// Aout = line o.li (the edges' own line), written when od > 0
+__device__ __forceinline__ OutSet g_outset_line(const GraphDev &g, const LineR &Le, int64_t e, uint64_t &aw0, uint64_t &aw1, uint64_t &aw2,
+                                                uint64_t &aw3, uint64_t &am1) {
+    OutSet o;
+    o.vm_hi = 0; o.vm_lo = 0; o.li = 0; o.od = 0;
+    if (g_bit(Le.invalid, e)) { o.od = -1; return o; }
+    int a = l_W(Le, e);
+    if (a > 4) a -= 4;
+    int64_t cnt;                                                          // Rank(a, e) from the registers (rank_and_select.h:153)
+    if (e >= g.size - 1) cnt = a == 1 ? g.total_w[1] : a == 2 ? g.total_w[2] : a == 3 ? g.total_w[3] : g.total_w[4];
+    else {
+        const int j = (int)(e & 63), fw = j >> 4;
+        const int nb = (j & 15) + 1;
+        const uint64_t m = nb == 16 ? ~0ull : ((1ull << (4 * nb)) - 1);
+        cnt = (int64_t)sel4(Le.rw0, Le.rw1, Le.rw2, Le.rw3, a - 1);
+        const uint64_t e0 = nib_eq(Le.w0, a), e1 = nib_eq(Le.w1, a), e2 = nib_eq(Le.w2, a), e3 = nib_eq(Le.w3, a);
+        cnt += __popcll(fw > 0 ? e0 : (e0 & m));
+        if (fw >= 1) cnt += __popcll(fw > 1 ? e1 : (e1 & m));
+        if (fw >= 2) cnt += __popcll(fw > 2 ? e2 : (e2 & m));
+        if (fw >= 3) cnt += __popcll(e3 & m);
+    }
+    const int64_t rf = a == 1 ? g.rank_f[1] : a == 2 ? g.rank_f[2] : a == 3 ? g.rank_f[3] : g.rank_f[4];
+    const int64_t r = rf + cnt - 1;                                       // Forward: Select(rank_f[a] + count - 1), succinct_dbg.h:155-164
+    if (r >= g.total_last || r < 0) return o;
+    const uint64_t hh = (a <= 2) ? Le.h01 : Le.h23;
+    uint64_t li = (a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32);           // fwd_hint[a-1]
+    LineR A = g_load_line(g, li);
+    const uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
+        do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
+        A = g_load_line(g, li);
+    }
+    const int xj = select64(A.last, (int)(r - (int64_t)A.rank_last));
+    const uint64_t upto = xj == 63 ? ~0ull : ((2ull << xj) - 1ull);      // bits 0 .. xj
+    const uint64_t stop = (A.last | A.tip) & (upto >> 1);                 // last | tip strictly below xj
+    o.li = li;
+    if (stop) {
+        const int y = 63 - __builtin_clzll(stop);
+        o.vm_hi = upto & ~((2ull << y) - 1ull) & ~A.invalid;
+    } else {
+        o.vm_hi = upto & ~A.invalid;
+        if (li > 0) {                                                     // the node began in the line before
+            const GLine &P = g.lines[li - 1];
+            const uint64_t pstop = P.last | P.tip;
+            const uint64_t keep = pstop ? ~((2ull << (63 - __builtin_clzll(pstop))) - 1ull) : ~0ull;
+            o.vm_lo = keep & ~P.invalid;
+            if (pstop >> 63) o.vm_lo = 0;
+        }
+    }
+    const int n = __popcll(o.vm_hi) + __popcll(o.vm_lo);
+    o.od = n > 4 ? 4 : n;
+    // (field by field: a whole-struct copy is written to scratch memory even when nothing reads it back; only W and multi1 are needed)
+    aw0 = A.w0; aw1 = A.w1; aw2 = A.w2; aw3 = A.w3; am1 = A.multi1;
+    return o;
+}
+// n-th out-edge (n < od) packed id << 4 | multi1 << 3 | label; A = line o.li
+__device__ __forceinline__ int64_t g_outset_get(const GraphDev &g, const OutSet &o, uint64_t aw0, uint64_t aw1, uint64_t aw2, uint64_t aw3,
+                                                uint64_t am1, int n) {
+    const int nh = __popcll(o.vm_hi);
+    const bool hi = n < nh;
+    uint64_t m = hi ? o.vm_hi : o.vm_lo;
+    int skip = hi ? n : n - nh;
+    if (skip >= 1) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    if (skip >= 2) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    if (skip >= 3) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    const int pos = 63 - __builtin_clzll(m | 1ull);
+    int w, m1;
+    int64_t x;
+    if (hi) {
+        x = (int64_t)(o.li << 6) + pos;
+        w = (int)((sel4(aw0, aw1, aw2, aw3, (pos >> 4) & 3) >> ((pos & 15) * 4)) & 15); m1 = g_bit(am1, x);
+    } else {
+        x = (int64_t)((o.li - 1) << 6) + pos;
+        w = g_W(g, x); m1 = (int)g_multi1(g, x);
+    }
+    return (x << 4) | ((int64_t)m1 << 3) | (int64_t)(w > 4 ? w - 4 : w);
+}
+// OutgoingEdges(e)[n] and the out-degree; the lines never leave the function (a 120-byte struct that flows from call to call ends
+// up in scratch memory)
+__device__ __forceinline__ int g_out_nth(const GraphDev &g, int64_t e, int n, int64_t &edge) {
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, m1 = 0;
+    const OutSet o = g_outset_line(g, g_load_line(g, (uint64_t)e >> 6), e, w0, w1, w2, w3, m1);
+    if (n < o.od) edge = g_outset_get(g, o, w0, w1, w2, w3, m1, n);
+    return o.od;
+}
+__device__ __forceinline__ int g_out_all(const GraphDev &g, int64_t e, int64_t &o0, int64_t &o1, int64_t &o2, int64_t &o3) {
+    uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, m1 = 0;
+    const OutSet o = g_outset_line(g, g_load_line(g, (uint64_t)e >> 6), e, w0, w1, w2, w3, m1);
+    if (o.od > 0) o0 = g_outset_get(g, o, w0, w1, w2, w3, m1, 0);
+    if (o.od > 1) o1 = g_outset_get(g, o, w0, w1, w2, w3, m1, 1);
+    if (o.od > 2) o2 = g_outset_get(g, o, w0, w1, w2, w3, m1, 2);
+    if (o.od > 3) o3 = g_outset_get(g, o, w0, w1, w2, w3, m1, 3);
+    return o.od;
+}
+
 __device__ __forceinline__ int g_tip_char(const GraphDev &g, int64_t tip_rank, int j) {
     const uint32_t *t = g.tip_labels + (size_t)g.words_per_tip * tip_rank;
     return (t[j >> 4] >> (15 - (j & 15)) * 2) & 3;

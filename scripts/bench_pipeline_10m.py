@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import torch  # noqa: F401
 from megagta_amd import api, findstart, synth, hmm as hmmlib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-window = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+configs = [tuple(int(y) for y in (x + ":16:0").split(":")[:3]) for x in (sys.argv[2] if len(sys.argv) > 2 else "4096").split(",")]   # window[:lanes per search[:cost rate]]
 mg = synth.make_metagenome(n, 150, (("rplB", 277),), seed=1)
 td = tempfile.mkdtemp()
 synth.write_gene_models(mg.genes, td)
@@ -26,8 +26,12 @@ t3 = time.time()
 seeds = [(l.split("\t")[3], int(l.split("\t")[7])) for l in lines]
 fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))
 rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "rev_enone.hmm")))
-res, st = api.astar_search(g, fw, rv, [x[0] for x in seeds], [x[1] - 1 for x in seeds], 20, 0.5, cache_mode=window)
-t4 = time.time()
-print(json.dumps({"reads": n, "build_ms": round(s["ms_total"], 1), "build+graph_s": round(t1 - t0, 3), "findstart_kernel_ms": round(ms_fs, 1), "hits": int(hits.size),
+for window, group, rate in configs:
+  os.environ["MGTA_ASTAR_GROUP"] = str(group)
+  t3 = time.time()
+  res, st = api.astar_search(g, fw, rv, [x[0] for x in seeds], [x[1] - 1 for x in seeds], 20, 0.5, cache_mode=window, cost_rate=rate)
+  t4 = time.time()
+  print(json.dumps({"reads": n, "build_ms": round(s["ms_total"], 1), "build+graph_s": round(t1 - t0, 3), "findstart_kernel_ms": round(ms_fs, 1), "hits": int(hits.size),
                   "seeds": len(seeds), "seed_lines_host_s": round(t3 - t2, 2), "search_kernel_s": round(st["ms_kernel"] / 1e3, 2), "search_wall_s": round(t4 - t3, 2),
-                  "expansions": st["n_expansions"], "window": window, "distinct_contigs": len({r.contig(x[0]) for r, x in zip(res, seeds)})}))
+                  "expansions": st["n_expansions"], "window": window, "group": group, "cost_rate": rate, "grown": st["n_grown"], "pool_used_GB": round(st["pool_used"] / 1e9, 1),
+                  "distinct_contigs": len({r.contig(x[0]) for r, x in zip(res, seeds)})}), flush=True)
