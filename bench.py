@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — MegaGTA hot path on MI355X: SdBG build (Gk-mer/s) [+ A* expansions/s once built].
+"""bench.py — MegaGTA hot path on MI355X: SdBG build (Gk-mer/s) + A* expansions/s + reads->contigs wall.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--k 45]
 
-A "step" = one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: packed reads -> SdBG edge stream (count, key generation, radix sort, edge emission) on every
-rank's share of the 65536 prefix buckets; for N > 1 the record shards are all-gathered over RCCL so
-every rank ends with the whole graph.  Work is fixed as N grows => "strong".
-N = 1 workload = BASELINE.json configs[1]: rplB, 10 M x 150 bp reads, CLI k = 45 (graph k = 44).
+N = 1 workload = BASELINE.json configs[2], the configuration the metric is quoted on: rplB + nirK, 100 M x 150 bp synthetic reads,
+CLI k = 45 (graph k = 44); `--reads 10000000` is configs[1].  The reads are generated and packed ON the device (seeded; every rank
+draws the same set) and are resident in HBM before the timed region starts.
 
-One JSON line on rank 0: metric/value/unit per BASELINE.json, `roofline` for the dominant kernel
-(radix scatter; algorithmic bytes / HIP-event duration measured inside the library on its own
-stream) and `cpu_baseline` = the reference binary (oracle/_ref/megagta buildgraph, kind "reference")
-or the oracle port, timed on this box's host cores on a bounded sample of the same reads.
+A "step" = one pass of the hot path over that input: packed reads -> SdBG edge stream (count, key generation, radix sort, edge
+emission) on every rank's share of the 65536 prefix buckets; for N > 1 the record shards are all-gathered over RCCL, device to device,
+so every rank ends with the whole stream.  Work is fixed as N grows => "strong".
+
+One JSON line on rank 0: metric / value / unit per BASELINE.json;
+  `roofline`     the dominant kernel of the build (algorithmic bytes / HIP-event duration measured inside the library on its own stream);
+  `search`       the A* leg on the graph of that build (graph + HMMs replicated; seeds shard by gene, then round-robin; one all-gather
+                 of contigs): expansions/s, achieved bytes/s against the measured random-line ceiling;
+  `e2e`          reads.fa -> contigs through the driver (`megagta.py -k 30,36,45`, rplB + nirK) on a bounded sample, next to the
+                 reference binary on the same files;
+  `cpu_baseline` the reference `buildgraph` (kind "reference") or the oracle port on this box's host cores, bounded sample.
 """
 from __future__ import annotations
 
@@ -31,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s, ~6.3 TB/s achievable)
+REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
+DRIVER = os.path.join(ROOT, "megagta_amd", "megagta.py")
 
 
 def b_build(k: int, L: int, edges_per_kmer: float) -> float:
@@ -46,21 +53,24 @@ def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int) -> dict:
     sample = reads[:n]
     n_kmers = n * (reads.shape[1] - k)
     cores = os.cpu_count() or 1
-    ref = os.path.join(ROOT, "oracle", "_ref", "megagta")
     tmp = tempfile.mkdtemp(prefix="mgta_cpu_")
     try:
-        if os.path.exists(ref):
+        if os.path.exists(REF):
             synth.write_lib_bin(sample, os.path.join(tmp, "reads.lib"))
-            threads = max(2, min(cores, 64))
-            cmd = [ref, "buildgraph", "-k", str(k), "-m", "1", "--host_mem", str(32 << 30), "--mem_flag", "1", "--gpu_mem", "0",
-                   "--output_prefix", os.path.join(tmp, "g"), "--num_cpu_threads", str(threads), "--num_output_threads", "1",
-                   "--read_lib_file", os.path.join(tmp, "reads.lib")]
-            t = time.time()
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            dt = time.time() - t
+            best = None
+            for threads in sorted({max(2, min(cores, 16)), max(2, min(cores, 64))}):     # the reference does not scale to every core: keep the best
+                cmd = [REF, "buildgraph", "-k", str(k), "-m", "1", "--host_mem", str(32 << 30), "--mem_flag", "1", "--gpu_mem", "0",
+                       "--output_prefix", os.path.join(tmp, f"g{threads}"), "--num_cpu_threads", str(threads), "--num_output_threads", "1",
+                       "--read_lib_file", os.path.join(tmp, "reads.lib")]
+                t = time.time()
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                dt = time.time() - t
+                if best is None or dt < best[0]:
+                    best = (dt, threads)
+            dt, threads = best
             return {"value": n_kmers / dt / 1e9, "unit": "Gk-mer/s", "cores": threads, "kind": "reference",
                     "sample": f"first {n} reads x {reads.shape[1]} bp of the same set, graph k={k}, `megagta buildgraph` "
-                              f"(reads.lib.bin -> .sdbg files, {dt:.2f} s wall incl. file I/O)"}
+                              f"(reads.lib.bin -> .sdbg files, {dt:.2f} s wall incl. file I/O; best of 16 / 64 threads)"}
         from oracle import oracle as O
         packed, start = synth.pack_reads_for_build(sample)
         threads = min(cores, 32)
@@ -73,15 +83,99 @@ def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int) -> dict:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def write_fasta_fast(reads: np.ndarray, path: str) -> None:
+    """>r0000000\\nACGT...\\n per read, assembled as one byte matrix"""
+    n, L = reads.shape
+    width = 8
+    rec = np.empty((n, 1 + 1 + width + 1 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord(">")
+    rec[:, 1] = ord("r")
+    ids = np.arange(n, dtype=np.int64)
+    for d in range(width):
+        rec[:, 2 + width - 1 - d] = (ids % 10 + ord("0")).astype(np.uint8)
+        ids //= 10
+    rec[:, 2 + width] = ord("\n")
+    rec[:, 3 + width:3 + width + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[reads]
+    rec[:, -1] = ord("\n")
+    rec.tofile(path)
+
+
+def e2e_leg(reads: np.ndarray, genes, n_ours: int, n_ref: int, klist: str = "30,36,45") -> dict:
+    """reads.fa -> contigs/<gene>/{nucl,prot}_merged.fasta through megagta.py (one run per sample), wall seconds; the reference binary
+    behind the same driver on the smaller sample (its thread count swept, best kept) and ours on that sample too for an equal-work ratio"""
+    from megagta_amd import synth
+    cores = os.cpu_count() or 1
+    tmp = tempfile.mkdtemp(prefix="mgta_e2e_")
+    out = {"k_list": klist, "genes": [g.name for g in genes]}
+    try:
+        gl = synth.write_gene_models(genes, os.path.join(tmp, "models"))
+
+        def run(n, tag, extra):
+            fa = os.path.join(tmp, f"reads_{n}.fa")
+            if not os.path.exists(fa):
+                write_fasta_fast(reads[:n], fa)
+            od = os.path.join(tmp, "out_" + tag)
+            t = time.time()
+            r = subprocess.run([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            dt = time.time() - t
+            if r.returncode != 0:
+                raise RuntimeError(f"megagta.py ({tag}) failed: {r.stderr[-800:]}")
+            n_contigs = {g.name: sum(1 for l in open(os.path.join(od, "contigs", g.name, "nucl_merged.fasta")) if l.startswith(">")) for g in genes}
+            shutil.rmtree(od, ignore_errors=True)
+            return dt, n_contigs
+
+        n_ours = min(n_ours, reads.shape[0])
+        dt, nc = run(n_ours, "ours", ["-t", str(min(cores, 16))])
+        out["ours"] = {"reads": n_ours, "seconds": dt, "reads_per_s": n_ours / dt, "contigs": nc}
+        if n_ref > 0 and os.path.exists(REF):
+            n_ref = min(n_ref, reads.shape[0])
+            best = None
+            for threads in sorted({min(cores, 8), min(cores, 32), cores}):
+                dtr, ncr = run(n_ref, f"ref_t{threads}", ["--bin", REF, "-t", str(threads)])
+                if best is None or dtr < best[0]:
+                    best = (dtr, threads, ncr)
+            dto, nco = run(n_ref, "ours_small", ["-t", str(min(cores, 16))])
+            out["reference"] = {"reads": n_ref, "seconds": best[0], "threads": best[1], "reads_per_s": n_ref / best[0], "contigs": best[2],
+                                "note": "the reference binary behind the same driver on the same files; best of 8 / 32 / all threads"}
+            out["ours_same_sample"] = {"reads": n_ref, "seconds": dto, "contigs": nco}
+            out["speedup_same_sample"] = best[0] / dto
+            out["speedup_reads_per_s"] = (n_ours / dt) / (n_ref / best[0])
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def random_line_ceiling(torch, n_lines: int = 1 << 26, probes: int = 1 << 26) -> float:
+    """GB/s of independent random 128-byte line reads over a table far larger than the caches (8 GB): the rate the A* leg's
+    graph / arena accesses are priced against ("achieved random-sector rate vs a measured ceiling")"""
+    tab = torch.empty((n_lines, 32), dtype=torch.int32, device="cuda")
+    tab.random_(0, 100)
+    idx = torch.randint(0, n_lines, (probes,), device="cuda")
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(3):
+        t = time.time()
+        s = tab[idx].sum()
+        torch.cuda.synchronize()
+        best = max(best, probes * 128 / (time.time() - t) / 1e9)
+    del tab, idx, s
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--reads", type=int, default=100_000_000)
     ap.add_argument("--k", type=int, default=45, help="CLI k (graph k = k-1, megagta.py:815-816)")
+    ap.add_argument("--genes", default="rplB:277,nirK:360")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--seeds", type=int, default=8000, help="seed k-mers of the A* leg (0 = skip the search leg)")
+    ap.add_argument("--seeds", type=int, default=8000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
+    ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
+    ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="sample the reference binary is timed on in that leg (0 = skip)")
+    ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,32 +184,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from megagta_amd import api, synth
+    from megagta_amd import dist as mdist
     k = args.k - 1
     L = 150
-    # identical synthetic read set on every rank (seeded); generated + packed in chunks on the host
+    gene_specs = tuple((g.split(":")[0], int(g.split(":")[1])) for g in args.genes.split(","))
+    # identical synthetic read set on every rank (seeded), generated and packed on the device
     t0 = time.time()
-    mg = synth.make_metagenome(args.reads, L, (("rplB", 277),), seed=1)
-    packed, start = synth.pack_reads_for_build(mg.reads)
+    host_sample = max(args.cpu_sample if not args.no_cpu_baseline else 0, args.e2e_reads, args.e2e_ref_reads, 1) if rank == 0 and world == 1 else 1
+    mg = synth.make_metagenome_device(args.reads, L, gene_specs, seed=1, device=f"cuda:{local_rank}", host_sample=host_sample)
     t_gen = time.time() - t0
 
     ctx = api.Context(local_rank)
-    rd = ctx.upload_reads(packed, start)            # inputs resident in HBM before the timed region
-    from megagta_amd import dist as mdist
+    rd = ctx.adopt_reads(mg.packed.data_ptr(), mg.n_words, mg.start.data_ptr(), mg.n_reads, keepalive=(mg.packed, mg.start))
     b0, b1 = mdist.bucket_share(rank, world)
 
     def step():
         g = ctx.build_sdbg(rd, k, collect=False, bucket_range=(b0, b1))
         if world > 1:
             # the path's one exchange: every rank receives every shard of the edge stream (RCCL all-gather),
-            # device to device: the shard never visits the host
+            # device to device: the shard never visits the host.  The library writes the shard on its own stream: torch's stream is
+            # drained first (the block it hands out may still be read by the previous step's collectives)
+            torch.cuda.current_stream().synchronize()
             shard = api.export_records_to_torch(ctx)
             n = torch.tensor([shard.numel()], device="cuda", dtype=torch.int64)
             ns = [torch.zeros_like(n) for _ in range(world)]
@@ -147,47 +244,60 @@ def main():
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
         dt = float(td.item())
 
-    # ---- A* leg: graph + HMMs replicated, seeds dealt round-robin, one all-gather of contigs
+    # ---- A* leg: graph + HMMs replicated (every rank builds the whole graph from its resident reads: the stream of all passes stays on
+    # the device), seeds shard by gene, then round-robin; one all-gather of contigs
     search = None
     findstart_leg = None
     denovo_leg = None
     if args.seeds > 0:
-        import tempfile
         from megagta_amd import hmm as hmmlib
-        if world > 1:
-            g = ctx.build_sdbg(rd, k, collect=True, bucket_range=(b0, b1))
-            graph = api.Graph(ctx, mdist.all_gather_edge_stream(g))
-        else:
-            ctx.build_sdbg(rd, k, collect=False)
-            graph = api.Graph(ctx, None, k)                 # row f-4: the stream stays on the device between build and search
+        from megagta_amd import findstart as fsm
+        ctx.keep_stream(True)
+        tg = time.time()
+        gst = ctx.build_sdbg(rd, k, collect=False).stats
+        graph = api.Graph(ctx, None, k)                 # row f-4: the stream never leaves the device between build and search
+        t_graph = time.time() - tg
+        ctx.keep_stream(False)
+        ctx.release_scratch()                           # the build's key buffers make room for the searches' pool
         td = tempfile.mkdtemp(prefix="mgta_bench_")
         synth.write_gene_models(mg.genes, td)
-        fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "for_enone.hmm")))
-        rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(td, "rplB", "rev_enone.hmm")))
-        # seed finder (row f-2) on the reads already resident for the build: kernel time of one gene's scan
-        from megagta_amd import findstart as fsm
-        fwords, _ = fsm.reference_words(os.path.join(td, "rplB", "ref_aligned.faa"), args.k // 3)
-        fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
-        fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
-        findstart_leg = {"ms_kernel": fms, "windows_per_s": args.reads * (L - args.k + 1) * 2 / (fms * 1e-3), "hits": int(fhits.size),
-                         "reference_words": len(fwords), "note": "mgta_findstart, both strands, k=%d, one gene" % args.k}
+        hm, seeds = [], []
+        fs_ms, fs_hits = 0.0, 0
+        for gi, gene in enumerate(mg.genes):
+            d = os.path.join(td, gene.name)
+            hm.append((api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "for_enone.hmm"))), api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "rev_enone.hmm")))))
+            seeds.append(synth.synthetic_seeds(gene, args.k, args.seeds, seed=4 + gi))
+            # seed finder (row f-2) on the reads already resident for the build: kernel time of one scan per gene
+            fwords, _ = fsm.reference_words(os.path.join(d, "ref_aligned.faa"), args.k // 3)
+            fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
+            fs_ms += fms
+            fs_hits += int(fhits.size)
+        findstart_leg = {"ms_kernel": fs_ms, "windows_per_s": len(mg.genes) * args.reads * (L - args.k + 1) * 2 / (fs_ms * 1e-3), "hits": fs_hits,
+                         "note": "mgta_findstart, both strands, k=%d, one scan per gene (%d genes)" % (args.k, len(mg.genes))}
         shutil.rmtree(td, ignore_errors=True)
-        seeds = synth.synthetic_seeds(mg.genes[0], args.k, args.seeds, seed=4)
-        mine = mdist.seed_share(len(seeds), rank, world)
-        kmers, states = [seeds[i][0] for i in mine], [seeds[i][1] - 1 for i in mine]
+        share = mdist.gene_seed_share([len(s) for s in seeds], rank, world)
 
         def sstep():
-            res, st = api.astar_search(graph, fw, rv, kmers, states, 20, 0.5)
-            if world > 1:
-                mdist.all_gather_contigs(len(seeds), mine, [r.contig(km) for r, km in zip(res, kmers)])
-            return st
+            tot = {"n_expansions": 0, "ms_kernel": 0.0, "n_retries": 0, "n_grown": 0, "pool_used": 0}
+            for gi in range(len(mg.genes)):
+                mine = share[gi]
+                kmers, states = [seeds[gi][i][0] for i in mine], [seeds[gi][i][1] - 1 for i in mine]
+                res, st = api.astar_search(graph, hm[gi][0], hm[gi][1], kmers, states, 20, 0.5) if len(mine) else ([], None)
+                if st:
+                    for key in ("n_expansions", "ms_kernel", "n_retries", "n_grown"):
+                        tot[key] += st[key]
+                    tot["pool_used"] = max(tot["pool_used"], st["pool_used"])
+                if world > 1:
+                    mdist.all_gather_contigs(len(seeds[gi]), mine, [r.contig(km) for r, km in zip(res, kmers)])
+            return tot
 
         sstep()
         fence()
         t = time.time()
-        sst = [sstep() for _ in range(max(1, args.steps // 2))]
+        n_s = max(1, args.steps // 2)
+        sst = [sstep() for _ in range(n_s)]
         fence()
-        sdt = (time.time() - t) / len(sst)
+        sdt = (time.time() - t) / n_s
         nexp = torch.tensor([float(sst[-1]["n_expansions"]), sdt], dtype=torch.float64, device="cuda")
         if world > 1:
             ne = nexp[:1].clone()
@@ -195,25 +305,37 @@ def main():
             tm = nexp[1:].clone()
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             nexp = torch.cat([ne, tm])
-        search = {"value": float(nexp[0]) / float(nexp[1]), "unit": "HMM-scored node expansions/s", "n_seeds": len(seeds),
+        rate = float(nexp[0]) / float(nexp[1])
+        search = {"value": rate, "unit": "HMM-scored node expansions/s", "n_seeds": sum(len(s) for s in seeds), "genes": [g.name for g in mg.genes],
+                  "graph_edges": int(graph.size), "graph_build_and_load_s": t_graph, "graph_passes": gst["n_passes"],
                   "expansions_per_step": float(nexp[0]), "ms_per_step": float(nexp[1]) * 1e3, "cache_mode": "cold (every seed independent)",
-                  "bytes_per_expansion_algorithmic": 510, "achieved_GBps": float(nexp[0]) * 510 / float(nexp[1]) / 1e9,
-                  "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"]}
-        if world == 1:
+                  "lanes_per_search": 16, "searches_in_flight_per_gpu": 8192,
+                  "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"], "searches_grown_in_place": sst[-1]["n_grown"],
+                  "pool_used_GB": sst[-1]["pool_used"] / 1e9}
+        if rank == 0:
+            # roofline of the leg: algorithmic bytes per expansion (170 B x (1 + d1 + d1 d2), 510 B unbranched) over time, against
+            # the rate this device sustains on independent random 128-byte line reads
+            ceiling = random_line_ceiling(torch)
+            search["roofline"] = {"bound": "hbm-latency (random 128-byte lines)", "bytes_per_expansion_algorithmic": 510,
+                                  "achieved": rate * 510 / 1e9, "peak": ceiling, "unit": "GB/s", "frac": rate * 510 / 1e9 / ceiling,
+                                  "peak_note": "measured in this run: 2^26 independent random 128-byte line reads over an 8 GB table",
+                                  "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and (args.reads <= 20_000_000 or args.denovo):
             # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits)
             _, dst = graph.denovo(150, False, k + 2)
             denovo_leg = {"edges": int(graph.size), "ms_tips": dst["ms_tips"], "ms_bubbles": dst["ms_bubbles"], "ms_unitigs": dst["ms_unitigs"],
                           "tips": dst["n_tips"], "bubbles": dst["n_bubbles"], "bubble_rounds": dst["n_bubble_rounds"], "contigs": dst["n_contigs"],
                           "edges_per_s": graph.size / max(1e-9, (dst["ms_tips"] + dst["ms_bubbles"] + dst["ms_unitigs"]) * 1e-3),
                           "note": "mgta_denovo --max_tip_len 150 on the build leg's graph (one-thread-reference result, computed on the device)"}
+        graph.free()
 
     if rank == 0:
         s = stats[-1]
         n_kmers = s["n_kmers"]                       # every rank scans all reads: whole-job k-mers per step
         ms_step = dt / args.steps * 1e3
         value = n_kmers / (ms_step * 1e-3) / 1e9
-        # the two big kernels of the build: radix_scatter (P launches: the most significant bytes) and local_sort (one launch:
-        # every remaining digit in LDS).  Each launch reads and writes every key of this rank once = 16W bytes per
+        # the two big kernels of the build: radix_scatter (P launches per pass: the most significant bytes) and local_sort (one launch per
+        # pass: every remaining digit in LDS).  Each launch reads and writes every key of the pass once = 16W bytes per
         # (k+1)-mer occurrence.  Durations: HIP events recorded by the library on its own stream.
         W = s["words_per_key"]
         items_per_launch = s["n_items"] / max(1, s["n_passes"])
@@ -228,14 +350,17 @@ def main():
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
-            traffic = json.load(open(tp)).get(dom_name + "_bytes_per_launch")
+            tj = json.load(open(tp))
+            if tj.get("reads") == args.reads:
+                traffic = tj.get(dom_name + "_bytes_per_launch")
         edges_per_kmer = s["n_edges"] / max(1, n_kmers) * world
+        gene_txt = " + ".join(g[0] for g in gene_specs)
         out = {
-            "metric": "HMM-scored node expansions/sec + SdBG-build Gk-mer/s, k=45, 100Mx150bp",
+            "metric": f"HMM-scored node expansions/sec + SdBG-build Gk-mer/s, k={args.k}, {args.reads // 1_000_000}Mx{L}bp",
             "value": value, "unit": "Gk-mer/s (SdBG build)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"rplB, {args.reads} x {L}bp synthetic reads, CLI k={args.k} (graph k={k}), -c 1, "
+            "config": {"workload": f"{gene_txt}, {args.reads} x {L}bp synthetic reads, CLI k={args.k} (graph k={k}), -c 1, "
                                    f"{'bucket-range sharded, all-gather of record shards' if world > 1 else '1x MI355X'}",
                        "reads": args.reads, "read_len": L, "graph_k": k, "n_kmers": n_kmers, "n_items": s["n_items"],
                        "n_edges_rank0": s["n_edges"], "passes": s["n_passes"]},
@@ -244,21 +369,36 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "other_kernels": {"radix_scatter_kernel": {"avg_launch_ms": ms_scatter, "launches_per_step": launches / args.steps,
                                                                     "achieved": alg_bytes / (ms_scatter * 1e-3) / 1e9 if ms_scatter > 0 else 0.0},
-                                           "local_sort_kernel": {"avg_launch_ms": ms_local, "launches_per_step": 1,
+                                           "local_sort_kernel": {"avg_launch_ms": ms_local, "launches_per_step": s["n_passes"],
                                                                  "achieved": alg_bytes / (ms_local * 1e-3) / 1e9 if ms_local > 0 else 0.0}}},
             "whole_build": {"algorithmic_bytes_per_kmer": b_build(k, L, edges_per_kmer),
                             "achieved_GBps": n_kmers * b_build(k, L, edges_per_kmer) / (ms_step * 1e-3) / 1e9,
+                            "frac_of_hbm_peak": n_kmers * b_build(k, L, edges_per_kmer) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "phase_ms": {p: s[p] for p in ("ms_count", "ms_gen", "ms_sort", "ms_emit", "ms_total")},
-                            "oversized_segments": s["n_big_segments"]},
-            "host_prep_s": t_gen,
+                            "oversized_segments": s["n_big_segments"],
+                            "pcie_inclusive_note": "inputs resident; uploading the packed reads (0.25 B/base + 8 B/read at ~55 GB/s) and returning "
+                                                   "2 B/edge would add ~%.0f ms per build" % ((args.reads * (L * 0.25 + 8) + s["n_edges"] * 2) / 55e9 * 1e3)},
+            "input_generation_s": t_gen,
         }
         if search is not None:
             out["search"] = search
             out["findstart"] = findstart_leg
             if denovo_leg is not None:
                 out["denovo"] = denovo_leg
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(mg.reads, k, args.cpu_sample)
+        if world == 1:
+            # free the device before the child processes of the e2e leg ask for it
+            rd.free()
+            rd._keep = None
+            ctx.release_scratch()
+            mg.packed = mg.start = None
+            torch.cuda.empty_cache()
+            if args.e2e_reads > 0:
+                try:
+                    out["e2e"] = e2e_leg(mg.sample_reads, mg.genes, args.e2e_reads, args.e2e_ref_reads)
+                except Exception as e:                                   # the bench line must not die with a leg
+                    out["e2e"] = {"error": str(e)[-600:]}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(mg.sample_reads, k, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -84,6 +84,8 @@ SYMBOLS = {
     "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_ctx_set_search_cost_rate": (C.c_int, [C.c_void_p, C.c_int]),
     "mgta_ctx_set_search_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
+    "mgta_ctx_keep_stream": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgta_ctx_release_scratch": (C.c_int, [C.c_void_p]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgta_host_free": (None, [C.c_void_p]),
     "mgta_sdbg_load": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

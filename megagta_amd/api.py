@@ -71,6 +71,14 @@ class Context:
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 
+    def keep_stream(self, on: bool = True):
+        """whole-range builds leave their whole edge stream on the device, also when they take several memory-bound passes"""
+        check(self._L.mgta_ctx_keep_stream(self.h, int(on)), "mgta_ctx_keep_stream")
+
+    def release_scratch(self):
+        """free the work memory kept between calls (build pool, search pool)"""
+        check(self._L.mgta_ctx_release_scratch(self.h), "mgta_ctx_release_scratch")
+
     def set_search_arena(self, log2_base_nodes: int = 0, pool_bytes: int = 0):
         """work memory of the A* searches: base arena of 1 << log2_base_nodes nodes per search slot (0 = default), pool the searches
         grow into (0 = auto).  Small values exercise the in-place growth on small inputs."""

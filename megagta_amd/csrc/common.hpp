@@ -88,6 +88,13 @@ struct mgta_ctx {
     const void *last_first = nullptr;
     uint64_t last_n_tips = 0;
     int last_k = 0, last_words_per_tip = 0;
+    // mgta_ctx_keep_stream: a build of several memory-bound passes also leaves its WHOLE edge stream on the device (records and tip
+    // labels of every pass appended here, records per bucket on the host), so that mgta_sdbg_load_resident works at any size
+    int keep_stream = 0;
+    bool acc_valid = false;
+    mgta::DevBuf acc_rec, acc_tips;
+    uint64_t acc_n_rec = 0, acc_n_tips = 0;
+    std::vector<int64_t> acc_items;
 };
 
 namespace mgta {

@@ -61,6 +61,24 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
     return MGTA_OK;
 }
 
+int mgta_ctx_keep_stream(mgta_ctx *ctx, int on) {
+    if (!ctx) return MGTA_EINVAL;
+    ctx->keep_stream = on ? 1 : 0;
+    if (!on) { ctx->acc_rec.release(); ctx->acc_tips.release(); ctx->acc_valid = false; }
+    return MGTA_OK;
+}
+
+int mgta_ctx_release_scratch(mgta_ctx *ctx) {
+    if (!ctx) return MGTA_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    const bool in_pool = ctx->last_rec && !ctx->acc_valid;      // the last pass's stream lives in the pool: it goes with it
+    ctx->pool.clear();
+    ctx->astar.pool.release(); ctx->astar.meta.release();
+    if (in_pool) { ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0; }
+    return MGTA_OK;
+}
+
 int mgta_ctx_set_mem_limit(mgta_ctx *ctx, uint64_t bytes) {
     if (!ctx) return MGTA_EINVAL;
     ctx->mem_limit = bytes;

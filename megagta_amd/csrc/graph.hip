@@ -213,6 +213,10 @@ int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
     }
     try {
         MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        if (ctx->acc_valid)      // a multi-pass build that kept its whole stream (mgta_ctx_keep_stream): records per bucket are on the host
+            return load_graph(ctx, ctx->last_k, static_cast<const uint16_t *>(ctx->last_rec), (int64_t)ctx->last_n_rec, ctx->acc_items.data(),
+                              static_cast<const uint32_t *>(ctx->last_tips), (int64_t)ctx->last_n_tips * ctx->last_words_per_tip,
+                              ctx->last_words_per_tip, true, out);
         // records before every bucket (-1 = empty bucket) -> records per bucket
         std::vector<int64_t> first((size_t)MGTA_NUM_BUCKETS * 3), items(MGTA_NUM_BUCKETS);
         if (ctx->last_n_rec) {

@@ -1816,6 +1816,13 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     uint64_t avail = (uint64_t)free_b + pool_bytes(ctx);
     uint64_t budget = ctx->mem_limit ? std::min<uint64_t>(ctx->mem_limit, avail) : (uint64_t)(avail * 0.9);
 
+    // whole-stream hand-off of a multi-pass build (mgta_ctx_keep_stream)
+    const bool acc = ctx->keep_stream && bucket_begin == 0 && bucket_end == (uint32_t)MGTA_NUM_BUCKETS;
+    ctx->acc_valid = false;
+    ctx->acc_n_rec = 0; ctx->acc_n_tips = 0;
+    if (acc) ctx->acc_items.assign(MGTA_NUM_BUCKETS, 0);
+    std::vector<int64_t> acc_first;
+
     Timer t_all(stream), t_ph(stream);
     std::vector<std::pair<hipEvent_t, hipEvent_t>> scatter_ev;
     uint32_t *d_block_count = pool_get<uint32_t>(ctx, S_BLOCK_COUNT, std::max<uint64_t>(1, n_blocks) * 4);
@@ -1905,6 +1912,11 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12) + 4096;
         uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
+        if (acc) {     // room for the stream the passes leave behind: ~0.6 edges of 2 bytes per (k+1)-mer, tips, slack
+            const uint64_t est = (uint64_t)S.n_kmers * 3 / 2 + (64ull << 20);
+            const uint64_t have = ctx->acc_rec.bytes + ctx->acc_tips.bytes;
+            other += est > have ? est - have : 0;
+        }
         const uint64_t avail = budget - std::min<uint64_t>(budget, other);
         if (need + need / 8 > avail && width > 1) {                   // narrower bucket ranges (CX1's lv1 loop, cx1.h:494)
             const double ratio = (double)(need + need / 8) / (double)std::max<uint64_t>(avail, 1) * 1.03;
@@ -2011,6 +2023,36 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             S.ms_emit += t_ph.stop();
             ctx->last_rec = d_out_rec; ctx->last_n_rec = n_edges; ctx->last_bucket_lo = b_lo; ctx->last_bucket_hi = b_hi;
             ctx->last_tips = d_out_tips; ctx->last_n_tips = n_tips; ctx->last_first = d_first; ctx->last_k = k; ctx->last_words_per_tip = words_per_tip;
+            if (acc) {
+                // append this pass to the whole-stream buffers (device to device); capacity from the share of the buckets done so far
+                auto ensure = [&](DevBuf &buf, uint64_t used, uint64_t add) {
+                    if (used + add <= buf.bytes) return;
+                    const double done = (double)(b_hi) / (double)MGTA_NUM_BUCKETS;
+                    uint64_t want = (uint64_t)((double)(used + add) / std::max(done, 1e-3) * 1.1) + (1u << 20);
+                    want = std::max<uint64_t>(want, used + add);
+                    DevBuf bigger;
+                    bigger.alloc(want, &ctx->live_bytes, &ctx->peak_bytes);
+                    if (used) MGTA_HIP_CHECK(hipMemcpyAsync(bigger.p, buf.p, used, hipMemcpyDeviceToDevice, stream));
+                    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                    buf = std::move(bigger);
+                };
+                ensure(ctx->acc_rec, ctx->acc_n_rec * 2, n_edges * 2);
+                ensure(ctx->acc_tips, ctx->acc_n_tips * words_per_tip * 4, n_tips * words_per_tip * 4);
+                if (n_edges) MGTA_HIP_CHECK(hipMemcpyAsync(ctx->acc_rec.as<char>() + ctx->acc_n_rec * 2, d_out_rec, n_edges * 2, hipMemcpyDeviceToDevice, stream));
+                if (n_tips) MGTA_HIP_CHECK(hipMemcpyAsync(ctx->acc_tips.as<char>() + ctx->acc_n_tips * words_per_tip * 4, d_out_tips,
+                                                          n_tips * words_per_tip * 4, hipMemcpyDeviceToDevice, stream));
+                acc_first.resize((size_t)nb * 3);
+                MGTA_HIP_CHECK(hipMemcpyAsync(acc_first.data(), d_first, (size_t)nb * 3 * 8, hipMemcpyDeviceToHost, stream));
+                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                int64_t nxt = (int64_t)n_edges;
+                for (int64_t b = (int64_t)nb - 1; b >= 0; --b) {
+                    int64_t f = acc_first[(size_t)b * 3];
+                    if (f < 0) f = nxt;
+                    ctx->acc_items[(size_t)b_lo + (size_t)b] = nxt - f;
+                    nxt = f;
+                }
+                ctx->acc_n_rec += n_edges; ctx->acc_n_tips += n_tips;
+            }
             // ---- device -> host
             if (sink) {
                 t_ph.start();
@@ -2043,6 +2085,12 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             if (rc != 0) { set_error("edge sink returned %d", rc); return MGTA_ESINK; }
         }
         b_lo = b_hi;
+    }
+    if (acc) {
+        ctx->last_rec = ctx->acc_rec.p; ctx->last_n_rec = ctx->acc_n_rec; ctx->last_bucket_lo = 0; ctx->last_bucket_hi = (uint32_t)MGTA_NUM_BUCKETS;
+        ctx->last_tips = ctx->acc_tips.p; ctx->last_n_tips = ctx->acc_n_tips; ctx->last_first = nullptr; ctx->last_k = k;
+        ctx->last_words_per_tip = words_per_tip;
+        ctx->acc_valid = true;
     }
     S.ms_total = t_all.stop();
     for (auto &ev : scatter_ev) {

@@ -61,14 +61,50 @@ def seed_share(n_seeds: int, rank: int, world: int) -> np.ndarray:
     return np.arange(rank, n_seeds, world, dtype=np.int64)
 
 
+def gene_seed_share(seeds_per_gene: list[int], rank: int, world: int) -> list[np.ndarray]:
+    """Seeds shard by GENE first, then round-robin inside a gene (BASELINE.json north_star): with at least as many
+    ranks as genes every gene gets a group of ranks (sizes proportional to its seeds, at least one each) and its seeds are dealt
+    round-robin inside the group, so a rank stages ONE gene's HMM tables; with fewer ranks than genes whole genes are dealt round-robin
+    over the ranks.  Returns, per gene, the seed indices this rank runs (ascending; empty for genes it does not take)."""
+    n_genes = len(seeds_per_gene)
+    out = [np.zeros(0, dtype=np.int64) for _ in range(n_genes)]
+    if n_genes == 0:
+        return out
+    if world < n_genes:
+        for g in range(rank, n_genes, world):
+            out[g] = np.arange(seeds_per_gene[g], dtype=np.int64)
+        return out
+    total = max(1, sum(seeds_per_gene))
+    size = [1] * n_genes                                             # ranks per gene: one each, the rest by share of the seeds
+    for _ in range(world - n_genes):
+        g = max(range(n_genes), key=lambda x: seeds_per_gene[x] / total / size[x])
+        size[g] += 1
+    first = 0
+    for g in range(n_genes):
+        if first <= rank < first + size[g]:
+            out[g] = np.arange(rank - first, seeds_per_gene[g], size[g], dtype=np.int64)
+        first += size[g]
+    return out
+
+
 def all_gather_contigs(n_seeds: int, mine: np.ndarray, contigs: list[str], group=None) -> list[str]:
-    """mine[i] = global seed index of contigs[i]; returns all contigs in seed order on every rank"""
-    blob = "\n".join(contigs).encode()
-    idx = _all_gather_var(np.asarray(mine, dtype=np.int64), group)
-    blobs = _all_gather_var(np.frombuffer(blob, dtype=np.uint8), group)
+    """mine[i] = global seed index of contigs[i]; returns all contigs in seed order on every rank.  The path's one exchange: ONE
+    all-gather of a length-prefixed byte buffer per rank ([n][seed index, length]*n[bytes]), padded to the longest (a second, 8-byte
+    all-gather tells the sizes)."""
+    mine = np.asarray(mine, dtype=np.int64)
+    enc = [c.encode() for c in contigs]
+    head = np.empty(1 + 2 * mine.size, dtype=np.int64)
+    head[0] = mine.size
+    head[1::2] = mine
+    head[2::2] = [len(b) for b in enc]
+    blob = np.concatenate([head.view(np.uint8), np.frombuffer(b"".join(enc), dtype=np.uint8)])
     out = [""] * n_seeds
-    for ids, b in zip(idx, blobs):
-        parts = b.tobytes().decode().split("\n") if ids.size else []
-        for i, s in zip(ids.tolist(), parts):
-            out[i] = s
+    for b in _all_gather_var(blob, group):
+        n = int(b[:8].view(np.int64)[0])
+        h = b[8:8 + 16 * n].view(np.int64)
+        pos = 8 + 16 * n
+        for j in range(n):
+            ln = int(h[2 * j + 1])
+            out[int(h[2 * j])] = b[pos:pos + ln].tobytes().decode()
+            pos += ln
     return out

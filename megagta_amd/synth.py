@@ -267,3 +267,92 @@ def write_seeds(path: str, seeds: list[tuple[str, int]]) -> None:
     with open(path, "w") as f:
         for kmer, pos in seeds:
             f.write(f"dump_gene_name\tdump_seq_name\tdump\t{kmer}\ttrue\t1\tx\t{pos}\n")
+
+
+# ----------------------------------------------------------------------------------------------
+# The same kind of read set generated and packed ON THE DEVICE (bench.py: 100 M reads in seconds instead of minutes of numpy).
+# torch is only used here, as the random generator + gather + bit packing of the synthetic input; nothing on the product path.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class DeviceMetagenome:
+    packed: "object"               # torch int32 [n_words + 16]: reads REVERSED and concatenated, 2 bits per base (pack_reads_for_build)
+    start: "object"                # torch int64 [n_reads + 1]
+    n_words: int
+    n_reads: int
+    read_len: int
+    genes: list[Gene]              # variants of the first `keep_variants` genomes only (seeds for the search leg)
+    sample_reads: np.ndarray       # the first `host_sample` reads on the host (uint8 codes), for the CPU baseline
+
+
+def make_metagenome_device(n_reads: int, read_len: int = 150, gene_specs=(("rplB", 277),), seed: int = 1, genome_len: int = 20000,
+                           aa_sub: float = 0.10, err: float = 0.005, reads_per_genome: int = 2000, device: str = "cuda",
+                           host_sample: int = 1_000_000, keep_variants: int = 4096, chunk: int = 4_000_000) -> DeviceMetagenome:
+    """G = n_reads / reads_per_genome random genomes, one diverged copy of every gene in each, uniform reads, random strand,
+    substitution errors: the model of make_metagenome, drawn by the device's generator (so the reads differ from the
+    numpy version's; every rank of a multi-GPU run draws the same ones from the same seed)."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    n_genomes = max(1, n_reads // reads_per_genome)
+    L = read_len
+    genomes = torch.randint(0, 4, (n_genomes, genome_len), dtype=torch.uint8, device=device, generator=gen)
+    # codon lists per amino acid (padded to 6) for the random synonymous codons
+    ctab = np.zeros((20, 6), dtype=np.int64)
+    ccnt = np.zeros(20, dtype=np.int64)
+    for ai, a in enumerate(AA_ORDER):
+        cs = codons_for(a)
+        ctab[ai, :len(cs)] = cs
+        ccnt[ai] = len(cs)
+    ctab_d, ccnt_d = torch.from_numpy(ctab).to(device), torch.from_numpy(ccnt).to(device)
+    genes: list[Gene] = []
+    slot = genome_len // (len(gene_specs) + 1)
+    ar_g = torch.arange(n_genomes, device=device)
+    for gi, (name, M) in enumerate(gene_specs):
+        cons_idx = rng.integers(0, 20, size=M)
+        gene = Gene(name=name, M=M, consensus="".join(AA_ORDER[i] for i in cons_idx))
+        prot = torch.from_numpy(cons_idx).to(device).unsqueeze(0).repeat(n_genomes, 1)                     # [G, M]
+        sub = torch.rand((n_genomes, M), device=device, generator=gen) < aa_sub
+        prot = torch.where(sub, torch.randint(0, 20, (n_genomes, M), device=device, generator=gen), prot)
+        pick = (torch.rand((n_genomes, M), device=device, generator=gen) * ccnt_d[prot]).long().clamp_(max=5)
+        codon = ctab_d[prot, torch.minimum(pick, ccnt_d[prot] - 1)]                                         # [G, M] 0..63
+        nt = torch.stack([codon >> 4, (codon >> 2) & 3, codon & 3], dim=2).reshape(n_genomes, 3 * M).to(torch.uint8)
+        pos = gi * slot + torch.randint(0, max(1, slot - 3 * M), (n_genomes,), device=device, generator=gen)
+        cols = pos.unsqueeze(1) + torch.arange(3 * M, device=device).unsqueeze(0)
+        genomes[ar_g.unsqueeze(1), cols] = nt
+        gene.variants = [v for v in nt[:keep_variants].cpu().numpy()]
+        genes.append(gene)
+    flat = genomes.reshape(-1)
+    n_bases = n_reads * L
+    n_words = (n_bases + 15) // 16
+    packed = torch.zeros(n_words + 16, dtype=torch.int32, device=device)
+    shifts = (30 - 2 * torch.arange(16, device=device, dtype=torch.int32))
+    ar_l = torch.arange(L, device=device)
+    sample = []
+    chunk -= chunk % 8                                               # 8 reads of 150 bases = 75 words: chunks end on word boundaries
+    assert (8 * L) % 16 == 0
+    for s in range(0, n_reads, chunk):
+        e = min(n_reads, s + chunk)
+        m = e - s
+        g_i = torch.randint(0, n_genomes, (m,), device=device, generator=gen)
+        p = torch.randint(0, genome_len - L + 1, (m,), device=device, generator=gen)
+        r = flat[(g_i * genome_len + p).unsqueeze(1) + ar_l.unsqueeze(0)]                                   # [m, L] uint8
+        strand = torch.rand((m,), device=device, generator=gen) < 0.5
+        r = torch.where(strand.unsqueeze(1), 3 - r.flip(1), r)
+        errs = torch.rand((m, L), device=device, generator=gen) < err
+        r = torch.where(errs, (r + torch.randint(1, 4, (m, L), device=device, generator=gen, dtype=torch.uint8)) & 3, r)
+        if len(sample) * chunk < host_sample:
+            sample.append(r[: max(0, host_sample - len(sample) * chunk)].cpu().numpy())
+        rr = r.flip(1).reshape(-1)                                   # reversed, not complemented (cx1_read2sdbg_s1.cpp:97,117)
+        pad = (-rr.numel()) % 16
+        if pad:
+            rr = torch.cat([rr, torch.zeros(pad, dtype=torch.uint8, device=device)])
+        w = (rr.view(-1, 16).to(torch.int32) << shifts).sum(dim=1, dtype=torch.int32)
+        w0 = s * L // 16
+        packed[w0:w0 + w.numel()] = w
+        del r, rr, w, errs, g_i, p, strand
+    start = torch.arange(n_reads + 1, device=device, dtype=torch.int64) * L
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+    return DeviceMetagenome(packed=packed, start=start, n_words=n_words, n_reads=n_reads, read_len=L, genes=genes,
+                            sample_reads=np.concatenate(sample) if sample else np.zeros((0, L), np.uint8))

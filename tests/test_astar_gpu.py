@@ -191,6 +191,33 @@ def test_windowed_warm_vs_oracle(ctx, oracle, window, rate):
                         assert got["real_score"] == ref.real_score and got["fval"] == ref.fval
 
 
+def test_window_mode_grows_in_place_instead_of_failing(ctx):
+    """the CLI's default mode (ordered-commit window) with base arenas of 128 nodes: every search outgrows its arena many times over
+    (round 1 returned MGTA_EOVERFLOW from this mode when a search passed 2^18 nodes); results == the same run with roomy arenas"""
+    from megagta_amd import api
+    import tempfile
+    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_gene_models(mg.genes, td)
+        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
+        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
+        g = api.Graph(ctx, stream)
+        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+        want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)          # prune 0: the largest searches
+        try:
+            ctx.set_search_arena(7, 0)
+            got, st = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)
+        finally:
+            ctx.set_search_arena(0, 0)
+        assert st["n_grown"] > 300 and st["n_rehash"] > 1000 and st["n_retries"] == 0 and st0["n_retries"] == 0
+        assert st["n_expansions"] == st0["n_expansions"]
+        for a, b, km in zip(got, want, kmers):
+            assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
+
+
 @pytest.mark.parametrize("M,k1,prune,pen,seed", [(60, 30, 20, 0.5, 1), (90, 36, 0, 0.5, 2), (150, 45, 20, 0.0, 3), (75, 45, 5, 2.0, 4),
                                                    (200, 36, 20, 0.5, 5), (48, 30, 3, 0.25, 6)])
 def test_fuzz_genes_k_and_search_options_vs_oracle(ctx, oracle, tmp_path, M, k1, prune, pen, seed):

@@ -56,6 +56,22 @@ def test_two_rank_gather(golden_dir, oracle):
     assert ret[0][2] > 0 and ret[1][2] > 0          # both ranks really owned part of the stream
 
 
+def test_gene_first_seed_share():
+    """genes -> ranks first, then round-robin inside a gene: every seed exactly once, a rank holds one gene when there are enough ranks"""
+    from megagta_amd import dist as mdist
+    for world in (1, 2, 3, 4, 8):
+        for per_gene in ([100, 140], [5, 5000], [7], [10, 20, 30, 40, 50], [0, 9]):
+            got = [mdist.gene_seed_share(per_gene, r, world) for r in range(world)]
+            for g, n in enumerate(per_gene):
+                allidx = np.sort(np.concatenate([got[r][g] for r in range(world)]))
+                assert allidx.tolist() == list(range(n)), (world, per_gene, g)
+            if world >= len(per_gene):
+                assert all(sum(1 for g in range(len(per_gene)) if got[r][g].size) <= 1 for r in range(world))
+    # 8 ranks, two genes with 1 : 1.4 seeds: 3 + 5 ranks
+    got = [mdist.gene_seed_share([1000, 1400], r, 8) for r in range(8)]
+    assert [int(got[r][0].size > 0) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
+
+
 def test_bucket_share_covers_everything():
     from megagta_amd import dist as mdist
     for world in (1, 2, 3, 4, 8):

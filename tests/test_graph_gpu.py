@@ -116,6 +116,38 @@ def test_graph_from_device_resident_stream(ctx, golden_dir, case, k):
         api.Graph(ctx, None, k)
 
 
+def test_graph_from_resident_stream_of_a_multi_pass_build(ctx, golden_dir):
+    """row f-4 at any size: with mgta_ctx_keep_stream a build that memory forces into several bucket-range passes still leaves its whole
+    edge stream on the device (each pass appended); the graph built from it answers like the host-loaded one on every edge"""
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    stream = ctx.build_sdbg(rd, 44)
+    g_host = api.Graph(ctx, stream)
+    try:
+        ctx.set_mem_limit(48 << 20)                        # the 1.7 M sort items need ~5 passes of this size
+        st = ctx.build_sdbg(rd, 44, collect=False).stats
+        assert st["n_passes"] >= 3
+        with pytest.raises(api.MegaGtaError):              # without the switch only the last pass is on the device
+            api.Graph(ctx, None, 44)
+        ctx.keep_stream(True)
+        st = ctx.build_sdbg(rd, 44, collect=False).stats
+        assert st["n_passes"] >= 3 and st["n_edges"] == stream.records.size
+        g_dev = api.Graph(ctx, None, 44)
+    finally:
+        ctx.set_mem_limit(0)
+        ctx.keep_stream(False)
+    assert g_dev.size == g_host.size
+    ids = np.arange(g_host.size)
+    d0, o0 = g_host.outgoing(ids)
+    d1, o1 = g_dev.outgoing(ids)
+    assert np.array_equal(d0, d1) and np.array_equal(o0, o1)
+    _, qs = H.parse_probe_graph(H.gz_lines(os.path.join(golden_dir, "toy", "graph_k44.txt.gz")))
+    deg, out = g_dev.outgoing([q["e"] for q in qs])
+    for q, d, o in zip(qs, deg.tolist(), out.tolist()):
+        assert d == q["od"] and o[:max(d, 0)] == q["out"]
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_fuzz_navigation_vs_oracle(ctx, oracle, seed):
     """random small graphs (any k, tips, $ edges, hot k-mers): OutgoingEdges of every edge and IndexBinarySearchEdge of present and absent
