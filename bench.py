@@ -127,12 +127,14 @@ def e2e_leg(reads: np.ndarray, genes, n_ours: int, n_ref: int, klist: str = "30,
 
         n_ours = min(n_ours, reads.shape[0])
         dt, nc = run(n_ours, "ours", ["-t", str(min(cores, 16))])
+        note(f"e2e ours: {n_ours} reads in {dt:.1f} s")
         out["ours"] = {"reads": n_ours, "seconds": dt, "reads_per_s": n_ours / dt, "contigs": nc}
         if n_ref > 0 and os.path.exists(REF):
             n_ref = min(n_ref, reads.shape[0])
             best = None
             for threads in sorted({min(cores, 8), min(cores, 32), cores}):
                 dtr, ncr = run(n_ref, f"ref_t{threads}", ["--bin", REF, "-t", str(threads)])
+                note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
                 if best is None or dtr < best[0]:
                     best = (dtr, threads, ncr)
             dto, nco = run(n_ref, "ours_small", ["-t", str(min(cores, 16))])
@@ -161,6 +163,15 @@ def random_line_ceiling(torch, n_lines: int = 1 << 26, probes: int = 1 << 26) ->
         best = max(best, probes * 128 / (time.time() - t) / 1e9)
     del tab, idx, s
     return best
+
+
+_T0 = time.time()
+
+
+def note(msg: str) -> None:
+    """progress on stderr (the JSON line on stdout stays the only stdout output)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -201,6 +212,7 @@ def main():
     host_sample = max(args.cpu_sample if not args.no_cpu_baseline else 0, args.e2e_reads, args.e2e_ref_reads, 1) if rank == 0 and world == 1 else 1
     mg = synth.make_metagenome_device(args.reads, L, gene_specs, seed=1, device=f"cuda:{local_rank}", host_sample=host_sample)
     t_gen = time.time() - t0
+    note(f"{args.reads} reads generated and packed on the device in {t_gen:.1f} s")
 
     ctx = api.Context(local_rank)
     rd = ctx.adopt_reads(mg.packed.data_ptr(), mg.n_words, mg.start.data_ptr(), mg.n_reads, keepalive=(mg.packed, mg.start))
@@ -233,12 +245,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    note("warm-up done")
     t = time.time()
     stats = []
     for _ in range(args.steps):
         stats.append(step())
     fence()
     dt = time.time() - t
+    note(f"{args.steps} build steps: {dt / args.steps * 1e3:.1f} ms each, {stats[-1]['n_passes']} pass(es)")
     if world > 1:
         td = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
@@ -257,6 +271,7 @@ def main():
         gst = ctx.build_sdbg(rd, k, collect=False).stats
         graph = api.Graph(ctx, None, k)                 # row f-4: the stream never leaves the device between build and search
         t_graph = time.time() - tg
+        note(f"graph of {graph.size} edges resident ({t_graph:.1f} s incl. the build)")
         ctx.keep_stream(False)
         ctx.release_scratch()                           # the build's key buffers make room for the searches' pool
         td = tempfile.mkdtemp(prefix="mgta_bench_")
@@ -275,6 +290,7 @@ def main():
         findstart_leg = {"ms_kernel": fs_ms, "windows_per_s": len(mg.genes) * args.reads * (L - args.k + 1) * 2 / (fs_ms * 1e-3), "hits": fs_hits,
                          "note": "mgta_findstart, both strands, k=%d, one scan per gene (%d genes)" % (args.k, len(mg.genes))}
         shutil.rmtree(td, ignore_errors=True)
+        note(f"seed scans: {fs_ms:.1f} ms, {fs_hits} hits; {sum(len(x) for x in seeds)} synthetic seeds")
         share = mdist.gene_seed_share([len(s) for s in seeds], rank, world)
 
         def sstep():
@@ -291,13 +307,15 @@ def main():
                     mdist.all_gather_contigs(len(seeds[gi]), mine, [r.contig(km) for r, km in zip(res, kmers)])
             return tot
 
-        sstep()
+        w0 = sstep()
         fence()
+        note(f"search warm-up: {w0['n_expansions']} expansions, {w0['ms_kernel']:.0f} ms on the device")
         t = time.time()
         n_s = max(1, args.steps // 2)
         sst = [sstep() for _ in range(n_s)]
         fence()
         sdt = (time.time() - t) / n_s
+        note(f"search: {sdt:.2f} s per step")
         nexp = torch.tensor([float(sst[-1]["n_expansions"]), sdt], dtype=torch.float64, device="cuda")
         if world > 1:
             ne = nexp[:1].clone()
@@ -316,6 +334,7 @@ def main():
             # roofline of the leg: algorithmic bytes per expansion (170 B x (1 + d1 + d1 d2), 510 B unbranched) over time, against
             # the rate this device sustains on independent random 128-byte line reads
             ceiling = random_line_ceiling(torch)
+            note(f"random-line ceiling {ceiling:.0f} GB/s")
             search["roofline"] = {"bound": "hbm-latency (random 128-byte lines)", "bytes_per_expansion_algorithmic": 510,
                                   "achieved": rate * 510 / 1e9, "peak": ceiling, "unit": "GB/s", "frac": rate * 510 / 1e9 / ceiling,
                                   "peak_note": "measured in this run: 2^26 independent random 128-byte line reads over an 8 GB table",
@@ -394,10 +413,13 @@ def main():
             torch.cuda.empty_cache()
             if args.e2e_reads > 0:
                 try:
+                    note("e2e leg ...")
                     out["e2e"] = e2e_leg(mg.sample_reads, mg.genes, args.e2e_reads, args.e2e_ref_reads)
+                    note("e2e leg done")
                 except Exception as e:                                   # the bench line must not die with a leg
                     out["e2e"] = {"error": str(e)[-600:]}
             if not args.no_cpu_baseline:
+                note("cpu baseline ...")
                 out["cpu_baseline"] = cpu_baseline(mg.sample_reads, k, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:

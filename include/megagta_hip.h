@@ -147,6 +147,7 @@ int mgta_sdbg_load(mgta_ctx *, int k, const uint16_t *recs, int64_t size, const 
 int mgta_sdbg_load_resident(mgta_ctx *, mgta_sdbg **out);
 void mgta_sdbg_free(mgta_sdbg *);
 int64_t mgta_sdbg_size(const mgta_sdbg *);
+int mgta_sdbg_k(const mgta_sdbg *);                 /* the graph's k (node length), -1 for NULL */
 /* batched navigation (test hook + building block of the search): for each edge id the valid
  * outgoing edges in the reference's order (descending id) [succinct_dbg.cpp:78-97];
  * outdeg[i] = -1 for an invalid edge.  out4 = n x 4 int64 (unused slots -1). Host pointers. */

@@ -245,6 +245,7 @@ void mgta_sdbg_free(mgta_sdbg *g) {
     ctx_release(c);
 }
 int64_t mgta_sdbg_size(const mgta_sdbg *g) { return g ? g->dev.size : -1; }
+int mgta_sdbg_k(const mgta_sdbg *g) { return g ? g->dev.k : -1; }
 
 int mgta_sdbg_outgoing(mgta_sdbg *g, const int64_t *edges, int64_t n, int64_t *out4, int8_t *outdeg) {
     if (!g || n < 0 || (n > 0 && (!edges || !out4 || !outdeg))) { set_error("mgta_sdbg_outgoing: bad argument"); return MGTA_EINVAL; }

@@ -23,6 +23,11 @@ struct PackedReads {
     void append(const uint8_t *codes, size_t n, bool reverse);
     void append_packed(const uint32_t *w, size_t n, bool reverse);   // n bases as the .bin files hold them (base j of a word at bits 30-2j)
     void finish();
+    // a loaded library kept between the steps of one process: mark() before sequences are appended for one step (assist contigs),
+    // rewind() afterwards (finish() only flushes the last partial word, which rewind() takes back)
+    struct Mark { size_t n_words, n_start; uint64_t acc, n_bases; int acc_bits, max_len; };
+    Mark mark() const { return Mark{words.size(), start.size(), acc_, n_bases_, acc_bits_, max_len}; }
+    void rewind(const Mark &m) { words.resize(m.n_words); start.resize(m.n_start); acc_ = m.acc; n_bases_ = m.n_bases; acc_bits_ = m.acc_bits; max_len = m.max_len; }
   private:
     uint64_t acc_ = 0;
     int acc_bits_ = 0;

@@ -9,8 +9,10 @@
 //               [--need_mercy] [--assist_seq FASTA]                       build_graph.cpp:38-48
 //   search      <sdbg_prefix> <gene_list> <starting_kmers_prefix> <output_prefix> <prune_len>
 //               <low_cov_penalty> [num_threads]                            search.cpp:72-90
+#include <fcntl.h>
 #include <getopt.h>
 #include <sys/resource.h>
+#include <unistd.h>
 #include <sys/time.h>
 
 #include <cstdio>
@@ -29,6 +31,71 @@ static double now_s() {
     struct timeval tv;
     gettimeofday(&tv, nullptr);
     return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+// ------------------------------------------------------------------------------------------------
+// `megagta serve`: one process for all the steps of a driver run.  The sub-commands are the same functions; what a worker keeps
+// between them is what a one-shot process pays for again at every step: the device context with its work memory (mapping device
+// memory costs ~27 ms/GB), the read library (reads.lib.bin unpacked once), and the graph of the last `buildgraph`, which stays on
+// the device for the `denovo` / `search` that follows instead of travelling through PREFIX.sdbg.* (succinct_dbg.cpp:595-723; the
+// files are still written: they are the run's artefacts and what `--continue` resumes from).
+struct Session {
+    bool active = false;
+    mgta_ctx *ctx = nullptr;
+    std::string lib_key;          // path of the .bin the library was read from
+    PackedReads lib;              // reversed, NOT finished (sequences of one step are appended behind it and taken off again)
+    bool lib_loaded = false;
+    mgta_sdbg *graph = nullptr;   // graph of the last buildgraph, not used yet
+    std::string graph_prefix;
+};
+static Session g_sess;
+
+static mgta_ctx *ctx_get() {
+    if (g_sess.active && g_sess.ctx) return g_sess.ctx;
+    mgta_ctx *ctx = mgta_ctx_create(0);
+    if (!ctx) die("%s", mgta_last_error());
+    if (g_sess.active) g_sess.ctx = ctx;
+    return ctx;
+}
+static void ctx_put(mgta_ctx *ctx) {
+    if (!g_sess.active) mgta_ctx_destroy(ctx);
+}
+// the library of `bin_path` (reads.lib.bin), reversed; `mk` = its end (rewind to it when the step is over)
+static PackedReads &lib_get(const std::string &bin_path, const std::string &lib_prefix, PackedReads &local, PackedReads::Mark &mk) {
+    PackedReads &pr = g_sess.active ? g_sess.lib : local;
+    if (!(g_sess.active && g_sess.lib_loaded && g_sess.lib_key == bin_path)) {
+        if (g_sess.active) { g_sess.lib = PackedReads(); g_sess.lib_loaded = false; }
+        if (!lib_prefix.empty()) load_read_lib(lib_prefix, /*reverse=*/true, pr);       // cx1_read2sdbg_s1.cpp:97,117
+        else load_read_bin(bin_path, /*reverse=*/true, pr);
+        if (g_sess.active) { g_sess.lib_loaded = true; g_sess.lib_key = bin_path; }
+    }
+    mk = pr.mark();
+    return pr;
+}
+static void lib_put(PackedReads &pr, const PackedReads::Mark &mk) {
+    if (g_sess.active) pr.rewind(mk);
+}
+static void graph_drop() {
+    if (g_sess.graph) { mgta_sdbg_free(g_sess.graph); g_sess.graph = nullptr; g_sess.graph_prefix.clear(); }
+}
+// the graph PREFIX names: the one the last buildgraph of this process left on the device, else read from the files
+static mgta_sdbg *graph_get(mgta_ctx *ctx, const std::string &prefix, int *k_out, size_t *n_edges) {
+    if (g_sess.active && g_sess.graph && g_sess.graph_prefix == prefix) {
+        mgta_sdbg *g = g_sess.graph;
+        g_sess.graph = nullptr; g_sess.graph_prefix.clear();
+        *k_out = mgta_sdbg_k(g); *n_edges = (size_t)mgta_sdbg_size(g);
+        logf("graph %s: still on the device", prefix.c_str());
+        return g;
+    }
+    graph_drop();
+    EdgeStream s;
+    read_sdbg(prefix, s);
+    mgta_sdbg *g = nullptr;
+    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
+                       s.words_per_tip, &g) != MGTA_OK)
+        die("mgta_sdbg_load: %s", mgta_last_error());
+    *k_out = s.k; *n_edges = s.recs.size();
+    return g;
 }
 
 struct RssLine {   // AutoMaxRssRecorder, utils.h:99-128
@@ -101,15 +168,18 @@ static int main_buildgraph(int argc, char **argv) {
     if (min_count < 1) min_count = 1;
 
     double t0 = now_s();
-    PackedReads pr;
-    load_read_lib(lib_file, /*reverse=*/true, pr);                       // cx1_read2sdbg_s1.cpp:97,117
+    PackedReads local;
+    PackedReads::Mark mk;
+    PackedReads &pr = lib_get(lib_file + ".bin", lib_file, local, mk);
+    pr.n_short = mk.n_start ? mk.n_start - 1 : 0;                        // the library's reads; assist sequences follow
     if (!assist.empty()) load_assist_fasta(assist, /*reverse=*/true, pr); // :121-134
     pr.finish();
     logf("%zu reads, %d max read length, %llu total bases (load %.3f s)", pr.start.size() - 1, pr.max_len,
          (unsigned long long)pr.start.back(), now_s() - t0);
 
-    mgta_ctx *ctx = mgta_ctx_create(0);
-    if (!ctx) die("%s", mgta_last_error());
+    mgta_ctx *ctx = ctx_get();
+    graph_drop();
+    if (g_sess.active) mgta_ctx_keep_stream(ctx, 1);
     // --gpu_mem: device budget in bytes.  Unset, a one-shot process takes 64 GB at most: device memory is mapped at ~27 ms/GB
     // (measured: 194 GB cost 5.3 s before the first kernel ran), which outweighs the few extra bucket-range passes of a tighter budget
     // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  A resident caller (bench, multi-k API) keeps the pool.
@@ -120,6 +190,12 @@ static int main_buildgraph(int argc, char **argv) {
     int rc = mgta_sdbg_build(ctx, pr.words.data(), pr.words.size(), pr.start.data(), pr.start.size() - 1, pr.n_short, k, min_count,
                              min_count > 1 ? need_mercy : 0, sink_collect, &s, &st);
     if (rc != MGTA_OK) die("mgta_sdbg_build: %s", mgta_last_error());
+    lib_put(pr, mk);
+    if (g_sess.active) {                                                 // the graph stays on the device for the step that uses it
+        if (mgta_sdbg_load_resident(ctx, &g_sess.graph) != MGTA_OK) die("mgta_sdbg_load_resident: %s", mgta_last_error());
+        g_sess.graph_prefix = out_prefix;
+        mgta_ctx_keep_stream(ctx, 0);
+    }
     if (min_count > 1) {                                                 // PREFIX.counting (s1_post_proc, cx1_read2sdbg_s1.cpp:923-930)
         std::vector<int64_t> hist(65536);
         if (mgta_sdbg_last_counting(ctx, hist.data()) != MGTA_OK) die("%s", mgta_last_error());
@@ -129,7 +205,7 @@ static int main_buildgraph(int argc, char **argv) {
         for (int i = 1; i <= 65535; ++i) { acc += hist[i]; fprintf(cf, "%d %lld\n", i, acc); }
         fclose(cf);
     }
-    mgta_ctx_destroy(ctx);
+    ctx_put(ctx);
     logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
          (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);
     double t1 = now_s();
@@ -185,17 +261,13 @@ static int main_search(int argc, char **argv) {
     if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
     double t0 = now_s();
     logf("Loading SdBG...");
-    EdgeStream s;
-    read_sdbg(argv[1], s);
-    mgta_ctx *ctx = mgta_ctx_create(0);
-    if (!ctx) die("%s", mgta_last_error());
+    mgta_ctx *ctx = ctx_get();
     if (mgta_ctx_set_search_cost_rate(ctx, cost_rate) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
-    mgta_sdbg *g = nullptr;
-    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
-                       s.words_per_tip, &g) != MGTA_OK)
-        die("mgta_sdbg_load: %s", mgta_last_error());
+    int gk = 0;
+    size_t n_edges = 0;
+    mgta_sdbg *g = graph_get(ctx, argv[1], &gk, &n_edges);
     logf("Done! Time elapsed: %.4lf", now_s() - t0);
-    const size_t klen = (size_t)s.k + 1;
+    const size_t klen = (size_t)gk + 1;
     for (const GeneEntry &gene : read_gene_list(argv[2])) {
         double tg = now_s();
         logf("START %s", gene.name.c_str());
@@ -228,7 +300,7 @@ static int main_search(int argc, char **argv) {
         logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device)", gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total);
     }
     mgta_sdbg_free(g);
-    mgta_ctx_destroy(ctx);
+    ctx_put(ctx);
     return 0;
 }
 
@@ -340,15 +412,15 @@ static int main_findstart(int argc, char **argv) {
     RssLine rss;
     const RefWords ref = load_reference_words(argv[1], k / 3);
     logf("reference kmer set size: %lld\n", (long long)ref.model_pos.size());
-    PackedReads pr;
-    load_read_bin(argv[2], /*reverse=*/true, pr);                       // stored as buildgraph wants them: the scan handles both orders
+    PackedReads local;
+    PackedReads::Mark mk;
+    PackedReads &pr = lib_get(argv[2], "", local, mk);                   // stored as buildgraph wants them: the scan handles both orders
     const uint64_t n_lib = pr.start.empty() ? 0 : pr.start.size() - 1;
     if (argc > 5) load_fastx(argv[5], true, pr);
     pr.finish();
     const uint64_t n_reads = pr.start.size() - 1;
     logf("Processing %llu reads, %llu contigs\n", (unsigned long long)n_lib, (unsigned long long)(n_reads - n_lib));
-    mgta_ctx *ctx = mgta_ctx_create(0);
-    if (!ctx) die("%s", mgta_last_error());
+    mgta_ctx *ctx = ctx_get();
     mgta_reads *rd = nullptr;
     if (mgta_reads_upload(ctx, pr.words.data(), pr.words.size(), pr.start.data(), n_reads, &rd) != MGTA_OK) die("%s", mgta_last_error());
     std::vector<mgta_seed_hit> hits(1 << 16);
@@ -379,7 +451,8 @@ static int main_findstart(int argc, char **argv) {
         printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", kv.first.c_str(), 1, ref.prot[(size_t)kv.second].c_str(),
                ref.model_pos[(size_t)kv.second]);
     mgta_reads_free(rd);
-    mgta_ctx_destroy(ctx);
+    lib_put(pr, mk);
+    ctx_put(ctx);
     return 0;
 }
 
@@ -412,15 +485,11 @@ static int main_denovo(int argc, char **argv) {
         return 1;
     }
     double t0 = now_s();
-    EdgeStream s;
-    read_sdbg(sdbg_name.c_str(), s);
-    mgta_ctx *ctx = mgta_ctx_create(0);
-    if (!ctx) die("%s", mgta_last_error());
-    mgta_sdbg *g = nullptr;
-    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
-                       s.words_per_tip, &g) != MGTA_OK)
-        die("mgta_sdbg_load: %s", mgta_last_error());
-    logf("Number of Edges: %lld; K value: %d (load %.3f s)", (long long)s.recs.size(), s.k, now_s() - t0);
+    mgta_ctx *ctx = ctx_get();
+    int gk = 0;
+    size_t n_edges = 0;
+    mgta_sdbg *g = graph_get(ctx, sdbg_name, &gk, &n_edges);
+    logf("Number of Edges: %lld; K value: %d (load %.3f s)", (long long)n_edges, gk, now_s() - t0);
     char *fasta = nullptr;
     uint64_t len = 0;
     mgta_denovo_stats st;
@@ -438,11 +507,74 @@ static int main_denovo(int argc, char **argv) {
     fclose(f);
     mgta_host_free(fasta);
     mgta_sdbg_free(g);
-    mgta_ctx_destroy(ctx);
+    ctx_put(ctx);
+    return 0;
+}
+
+static int dispatch(int argc, char **argv);
+
+// megagta serve: requests on stdin, one per line: the sub-command's argv, tab separated; a field "<PATH" / ">PATH" redirects the
+// step's stdin / stdout (filterbylen, translate, findstart).  Reply "DONE <exit code>" on the descriptor stdout had at start.  A step
+// that dies takes the worker with it: the driver then reports the step as failed, as it does for a one-shot process.
+static int main_serve() {
+    g_sess.active = true;
+    FILE *req = fdopen(dup(0), "r"), *rep = fdopen(dup(1), "w");
+    if (!req || !rep) die("serve: cannot duplicate the standard descriptors");
+    const int null_in = open("/dev/null", O_RDONLY);
+    dup2(null_in, 0);                                                     // steps never read the request channel
+    char *line = nullptr;
+    size_t cap = 0;
+    ssize_t n;
+    while ((n = getline(&line, &cap, req)) > 0) {
+        while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) line[--n] = 0;
+        if (n == 0) continue;
+        std::vector<std::string> f;
+        for (char *p = line, *e; ; p = e + 1) {
+            e = strchr(p, '\t');
+            f.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+            if (!e) break;
+        }
+        if (f[0] == "quit") break;
+        std::string in_path, out_path;
+        std::vector<char *> av;
+        for (std::string &x : f) {
+            if (!x.empty() && x[0] == '<') in_path = x.substr(1);
+            else if (!x.empty() && x[0] == '>') out_path = x.substr(1);
+            else av.push_back(const_cast<char *>(x.c_str()));
+        }
+        av.push_back(nullptr);
+        int save_in = -1, save_out = -1, rc = 1;
+        fflush(stdout);
+        if (!in_path.empty()) {
+            int fd = open(in_path.c_str(), O_RDONLY);
+            if (fd < 0) { fprintf(stderr, "serve: cannot open %s\n", in_path.c_str()); goto reply; }
+            save_in = dup(0); dup2(fd, 0); close(fd);
+            clearerr(stdin);
+        }
+        if (!out_path.empty()) {
+            int fd = open(out_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) { fprintf(stderr, "serve: cannot write %s\n", out_path.c_str()); goto reply; }
+            save_out = dup(1); dup2(fd, 1); close(fd);
+        }
+        rc = dispatch((int)av.size() - 1, av.data());
+    reply:
+        fflush(stdout);
+        if (save_out >= 0) { dup2(save_out, 1); close(save_out); }
+        if (save_in >= 0) { dup2(save_in, 0); close(save_in); clearerr(stdin); }
+        fprintf(rep, "DONE %d\n", rc);
+        fflush(rep);
+    }
+    graph_drop();
+    if (g_sess.ctx) mgta_ctx_destroy(g_sess.ctx);
     return 0;
 }
 
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "serve") return main_serve();
+    return dispatch(argc, argv);
+}
+
+static int dispatch(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stderr, "Usage: %s <sub_program> [sub options]\n    sub-programs on the MI355X hot path:\n        buildgraph    build succinct de Bruijn graph\n"
                         "        denovo        tips, bubbles, contigs of an intermediate k\n        search        HMM-guided search of gene contigs\n        findstart     find starting kmers of the search\n        dumpversion   dump version\n", argv[0]);

@@ -8,8 +8,10 @@ Drop-in surface kept (reference src/megagta.py): options `-r/-1/-2/--12 -g -k -c
 (:815-816), one child process per step with stderr relayed into the log, first non-zero exit aborts.
 
 Every sub-command runs from THIS package's `bin/megagta` (C++ host + libmegagta_hip.so): `buildgraph`, `denovo`, `findstart`, `search`
-on the device, `buildlib`, `filterbylen`, `translate` on the host.  `--ref-bin` / $MEGAGTA_REF_BIN (the stock MegaGTA executable) is
-kept for steps a future reference version may add; nothing needs it today.
+on the device, `buildlib`, `filterbylen`, `translate` on the host.  By default the steps are requests to ONE worker process (`megagta
+serve`): same sub-commands, same files and checkpoints, but the device context, the unpacked read library and the graph of the last
+`buildgraph` stay where they are between steps.  `--one-process-per-step` (or a `--bin` without `serve`, e.g. the stock MegaGTA
+executable) runs one child process per step like the reference driver.
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ import multiprocessing
 import os
 import subprocess
 import sys
+import threading
 import time
 from datetime import datetime
 
@@ -28,7 +31,9 @@ USAGE = """Usage:
     -k/--k-list 30,36,45   -c/--min-count 1   -p/--prune-len 20   -l/--low-cov-penalty 0.5
     -m/--memory 0.9        -t/--num-cpu-threads N   --min-contig-len 450   --max-tip-len 150
     --no-mercy  --mem-flag 1  --gpu-mem BYTES  --keep-tmp-files  --continue  --verbose
-    --ref-bin PATH   stock `megagta` binary for the steps outside the accelerated path"""
+    --bin PATH       the multi-call `megagta` executable (default: this package's bin/megagta)
+    --one-process-per-step   start every step as its own process, as the reference driver does (default: one worker process,
+                     `megagta serve`, runs all steps and keeps the device context, the read library and the last graph between them)"""
 
 
 class Usage(Exception):
@@ -57,7 +62,7 @@ class Opt:
         self.gene_list = ""
         self.gene_info = {}
         self.bin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "megagta")
-        self.ref_bin = os.environ.get("MEGAGTA_REF_BIN", "")
+        self.one_process_per_step = False
 
 
 opt = Opt()
@@ -65,7 +70,7 @@ cp = 0
 
 LONG = ["help", "read=", "12=", "out-dir=", "memory=", "gpu-mem=", "min-contig-len=", "num-cpu-threads=", "kmin-1pass", "k-list=",
         "min-count=", "max-tip-len=", "no-mercy", "keep-tmp-files", "mem-flag=", "version", "verbose", "continue", "gene-list=",
-        "prune-len=", "low-cov-penalty=", "ref-bin=", "bin="]
+        "prune-len=", "low-cov-penalty=", "bin=", "one-process-per-step"]
 
 
 def parse_opt(argv):
@@ -108,8 +113,8 @@ def parse_opt(argv):
         elif o in ("-g", "--gene-list"): opt.gene_list = v
         elif o in ("-p", "--prune-len"): opt.prune_len = int(v)
         elif o in ("-l", "--low-cov-penalty"): opt.low_cov_penalty = float(v)
-        elif o == "--ref-bin": opt.ref_bin = v
         elif o == "--bin": opt.bin = v
+        elif o == "--one-process-per-step": opt.one_process_per_step = True
         else:
             raise Usage("Invalid option " + o)
     opt.temp_dir = opt.out_dir + "tmp/"
@@ -120,12 +125,22 @@ def parse_opt(argv):
 
 
 def prepare_continue():
-    """re-read opts.txt and the last finished checkpoint (reference :321-351)"""
-    opt.continue_mode = True
+    """re-read opts.txt and the last finished checkpoint (reference :321-351): every option but -o comes from opts.txt, parsed into a
+    fresh option set (options given next to --continue are ignored, as the reference says it does); without an opts.txt the run goes on
+    in normal mode"""
+    global opt
     if not os.path.exists(opt.out_dir + "opts.txt"):
-        raise Usage("Cannot find " + opt.out_dir + "opts.txt, nothing to continue")
+        print("Cannot find " + opt.out_dir + "opts.txt", file=sys.stderr)
+        print("Please check whether the output directory is correctly set by \"-o\"", file=sys.stderr)
+        print("Now switching to normal mode.", file=sys.stderr)
+        return
+    print("Continue mode activated. Ignore all options other than -o/--out-dir.", file=sys.stderr)
     with open(opt.out_dir + "opts.txt") as f:
         argv = [l.rstrip("\n") for l in f if l.strip()]
+    out_dir = opt.out_dir
+    opt = Opt()
+    opt.out_dir = out_dir
+    opt.continue_mode = True
     parse_opt(argv)
     opt.last_cp = -1
     if os.path.exists(opt.temp_dir + "cp.txt"):
@@ -134,6 +149,7 @@ def prepare_continue():
                 a = line.split()
                 if len(a) == 2 and a[1] == "done":
                     opt.last_cp = int(a[0])
+    print("Continue from check point " + str(opt.last_cp), file=sys.stderr)
 
 
 def detect_available_mem():
@@ -204,29 +220,86 @@ def should_run():
     return (not opt.continue_mode) or cp > opt.last_cp
 
 
-def run_step(cmd, what, stdin=None, stdout=None):
-    """one child process per step, stderr relayed line by line into the log (reference :563-576)"""
+class Worker:
+    """`megagta serve`: requests = one tab-separated argv per line (+ "<path" / ">path" redirections), reply "DONE <rc>"."""
+
+    def __init__(self, binary):
+        self.p = subprocess.Popen([binary, "serve"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        self.t = threading.Thread(target=self._relay, daemon=True)
+        self.t.start()
+
+    def _relay(self):
+        for line in self.p.stderr:
+            logging.debug(line.decode(errors="replace").rstrip())
+
+    def request(self, fields):
+        try:
+            self.p.stdin.write(("\t".join(fields) + "\n").encode())
+            self.p.stdin.flush()
+            reply = self.p.stdout.readline().decode().split()
+        except (BrokenPipeError, OSError):
+            reply = []
+        if len(reply) == 2 and reply[0] == "DONE":
+            return int(reply[1])
+        ret = self.p.wait()                      # the worker died in the step (a fatal error prints its reason and exits)
+        return ret if ret != 0 else 1
+
+    def close(self):
+        try:
+            self.p.stdin.write(b"quit\n")
+            self.p.stdin.flush()
+            self.p.stdin.close()
+        except (BrokenPipeError, OSError):
+            pass
+        self.p.wait()
+        self.t.join(timeout=5)
+
+
+worker = None
+
+
+def start_worker():
+    """one worker for all steps when the executable has `serve` (ours has; the stock MegaGTA binary has not)"""
+    global worker
+    if opt.one_process_per_step:
+        return
+    try:
+        w = Worker(opt.bin)
+    except OSError:
+        return
+    if w.request(["dumpversion", ">" + os.devnull]) == 0:
+        worker = w
+    else:
+        logging.debug("%s has no `serve`: one process per step" % opt.bin)
+
+
+def run_step(cmd, what, stdin_path=None, stdout_path=None):
+    """one step: a request to the worker, or one child process (reference :563-576); stderr is relayed line by line into the log"""
     logging.info("--- [%s] %s ---" % (datetime.now().strftime("%c"), what))
     logging.debug("cmd: " + " ".join(cmd))
-    try:
-        p = subprocess.Popen(cmd, stdin=stdin, stdout=stdout, stderr=subprocess.PIPE)
-    except OSError:
-        logging.error("Error: sub-program %s not found" % cmd[0])
-        sys.exit(1)
-    for line in p.stderr:
-        logging.debug(line.decode(errors="replace").rstrip())
-    ret = p.wait()
+    if worker is not None:
+        fields = cmd[1:] + (["<" + stdin_path] if stdin_path else []) + ([">" + stdout_path] if stdout_path else [])
+        ret = worker.request(fields)
+    else:
+        fin = open(stdin_path, "rb") if stdin_path else None
+        fout = open(stdout_path, "wb") if stdout_path else None
+        try:
+            p = subprocess.Popen(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+        except OSError:
+            logging.error("Error: sub-program %s not found" % cmd[0])
+            sys.exit(1)
+        for line in p.stderr:
+            logging.debug(line.decode(errors="replace").rstrip())
+        ret = p.wait()
+        for f in (fin, fout):
+            if f:
+                f.close()
     if ret != 0:
         logging.error("Error occurs when running \"%s\", please refer to %s for detail" % (what, log_file()))
         logging.error("[Exit code %d]" % ret)
+        if worker is not None:
+            worker.close()
         sys.exit(ret)
-
-
-def need_ref(step):
-    if not opt.ref_bin or not os.path.exists(opt.ref_bin):
-        logging.error("step '%s' is outside the accelerated path: give the stock megagta binary with --ref-bin / $MEGAGTA_REF_BIN" % step)
-        sys.exit(1)
-    return opt.ref_bin
 
 
 def build_lib():
@@ -271,7 +344,7 @@ def assemble(k):
         nxt = opt.k_list[opt.k_list.index(k) + 1]
         run_step([opt.bin, "denovo", "-s", graph_prefix(k), "-o", graph_prefix(k), "-t", str(opt.num_cpu_threads),
                   "--min_standalone", "400", "--max_tip_len", str(opt.max_tip_len), "--min_contig", str(nxt + 1)],
-                 "De novo assembling contigs from SdBG for k = %d" % k, stdout=subprocess.PIPE)
+                 "De novo assembling contigs from SdBG for k = %d" % k, stdout_path=os.devnull)
     write_cp()
 
 
@@ -281,30 +354,31 @@ def find_seed(k, gene):
         i = opt.k_list.index(k)
         if i > 0:
             par.append(contig_file(opt.k_list[i - 1]))
-        with open(graph_prefix(k) + "_" + gene + "_starting_kmers.txt", "w") as out:
-            run_step([opt.bin, "findstart"] + par, "Finding starting kmers for %s k = %d" % (gene, k), stdout=out)
+        run_step([opt.bin, "findstart"] + par, "Finding starting kmers for %s k = %d" % (gene, k),
+                 stdout_path=graph_prefix(k) + "_" + gene + "_starting_kmers.txt")
     write_cp()
 
 
 def search_contigs(k):
-    run_it = should_run()
-    if run_it:
+    """search, then per gene filterbylen + translate.  Checkpoints as the reference writes them (:680-760): the two filters of every
+    gene have their own, written INSIDE the search step, the search's own comes last -- a finished run continues identically under
+    either driver"""
+    if should_run():
         run_step([opt.bin, "search", graph_prefix(k), opt.gene_list, graph_prefix(k), graph_prefix(k), str(opt.prune_len),
                   str(opt.low_cov_penalty), str(min(12, opt.num_cpu_threads))], "Searching contigs for k = %d" % k)
+        os.makedirs(opt.out_dir + "contigs", exist_ok=True)
+        for gene in opt.gene_info:
+            d = opt.out_dir + "contigs/" + gene
+            os.makedirs(d, exist_ok=True)
+            if should_run():
+                run_step([opt.bin, "filterbylen", str(opt.min_contig_len)], "Filtering contigs with minimum length = %d" % opt.min_contig_len,
+                         stdin_path=graph_prefix(k) + "_raw_contigs_" + gene + ".fasta", stdout_path=d + "/nucl_merged.fasta")
+            write_cp()
+            if should_run():
+                run_step([opt.bin, "translate", d + "/nucl_merged.fasta"], "Translating nucl contigs to aa contigs",
+                         stdout_path=d + "/prot_merged.fasta")
+            write_cp()
     write_cp()
-    os.makedirs(opt.out_dir + "contigs", exist_ok=True)
-    for gene in opt.gene_info:
-        d = opt.out_dir + "contigs/" + gene
-        os.makedirs(d, exist_ok=True)
-        if should_run():
-            with open(graph_prefix(k) + "_raw_contigs_" + gene + ".fasta") as fin, open(d + "/nucl_merged.fasta", "w") as fout:
-                run_step([opt.bin, "filterbylen", str(opt.min_contig_len)],
-                         "Filtering contigs with minimum length = %d" % opt.min_contig_len, stdin=fin, stdout=fout)
-        write_cp()
-        if should_run():
-            with open(d + "/prot_merged.fasta", "w") as fout:
-                run_step([opt.bin, "translate", d + "/nucl_merged.fasta"], "Translating nucl contigs to aa contigs", stdout=fout)
-        write_cp()
 
 
 def main(argv=None):
@@ -326,6 +400,7 @@ def main(argv=None):
         if not opt.continue_mode:
             with open(opt.out_dir + "opts.txt", "w") as f:
                 f.write("\n".join(argv[1:]) + "\n")
+        start_worker()
         build_lib()
         parse_gene_list()
         opt.k_list = [k - 1 for k in opt.k_list]                      # graph k = CLI k - 1
@@ -337,6 +412,8 @@ def main(argv=None):
                 for gene in opt.gene_info:
                     find_seed(k, gene)
                 search_contigs(k)
+        if worker is not None:
+            worker.close()
         logging.info("--- [%s] ALL DONE. Time elapsed: %f seconds ---" % (datetime.now().strftime("%c"), time.time() - t0))
         return 0
     except Usage as e:

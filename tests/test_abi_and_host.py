@@ -138,3 +138,49 @@ def test_host_sdbg_reader_and_writer(tmp_path, oracle, golden_dir):
     assert r.returncode == 0, r.stderr
     assert api.read_sdbg(str(tmp_path / "out")).md5() == s.md5()
     assert oracle.Stream.read(str(tmp_path / "out")).edges().md5() == s.md5()
+
+
+def test_driver_continue_mode_follows_the_reference(tmp_path, monkeypatch, capsys):
+    """--continue (reference megagta.py:321-351): every option but -o comes from opts.txt, parsed into a FRESH option set (reads given
+    next to --continue are not appended a second time); without an opts.txt the driver says so and carries on in normal mode"""
+    import importlib
+    from megagta_amd import megagta as drv
+    drv = importlib.reload(drv)
+    out = tmp_path / "run"
+    (out / "tmp").mkdir(parents=True)
+    (out / "opts.txt").write_text("-r\nreads.fa\n-g\ngenes.txt\n-k\n30,45\n-o\n" + str(out) + "\n")
+    (out / "tmp" / "cp.txt").write_text("0\tdone\n1\tdone\n2\tdone\n")
+    drv.parse_opt(["-r", "other.fa", "--continue", "-o", str(out)])
+    assert drv.opt.continue_mode and drv.opt.last_cp == 2
+    assert drv.opt.se == ["reads.fa"] and drv.opt.k_list == [30, 45] and drv.opt.gene_list == "genes.txt"
+    drv = importlib.reload(drv)
+    empty = tmp_path / "nothing"
+    empty.mkdir()
+    drv.parse_opt(["-r", "x.fa", "--continue", "-o", str(empty)])
+    assert not drv.opt.continue_mode and drv.opt.se == ["x.fa"] and "switching to normal mode" in capsys.readouterr().err
+
+
+def test_driver_checkpoint_order_of_the_last_step(tmp_path, monkeypatch):
+    """search_contigs writes the checkpoints of filterbylen / translate of every gene INSIDE the search step and the search's own last
+    (reference megagta.py:680-760), so that either driver can continue the other's run"""
+    import importlib
+    from megagta_amd import megagta as drv
+    drv = importlib.reload(drv)
+    calls = []
+    monkeypatch.setattr(drv, "run_step", lambda cmd, what, stdin_path=None, stdout_path=None: calls.append(cmd[1]))
+    drv.opt.out_dir = str(tmp_path) + "/"
+    drv.opt.temp_dir = drv.opt.out_dir + "tmp/"
+    os.makedirs(drv.opt.temp_dir)
+    drv.opt.gene_info = {"rplB": ("f", "r", "a"), "nirK": ("f", "r", "a")}
+    drv.search_contigs(44)
+    assert calls == ["search", "filterbylen", "translate", "filterbylen", "translate"]
+    assert open(drv.opt.temp_dir + "cp.txt").read() == "".join(f"{i}\tdone\n" for i in range(5))
+    # continuing a run whose search checkpoint is there: nothing runs, ONE checkpoint is passed (the nested ones are skipped with it)
+    drv = importlib.reload(drv)
+    monkeypatch.setattr(drv, "run_step", lambda *a, **k: calls.append("again"))
+    drv.opt.out_dir = str(tmp_path) + "/"
+    drv.opt.temp_dir = drv.opt.out_dir + "tmp/"
+    drv.opt.gene_info = {"rplB": ("f", "r", "a"), "nirK": ("f", "r", "a")}
+    drv.opt.continue_mode, drv.opt.last_cp = True, 4
+    drv.search_contigs(44)
+    assert "again" not in calls and drv.cp == 1

@@ -38,7 +38,7 @@ def test_single_k_pipeline_matches_reference_artifacts(toy_inputs, oracle, golde
     out = d / "out1"
     # a single-k run needs no reference binary at all: buildlib, buildgraph, findstart, search, filterbylen, translate are ours
     r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "45", "-o", str(out),
-                        "-t", "4", "--min-contig-len", "150"], capture_output=True, text=True, env={**os.environ, "MEGAGTA_REF_BIN": ""})
+                        "-t", "4", "--min-contig-len", "150"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
     toy = os.path.join(golden_dir, "toy")
     # graph files written by OUR buildgraph decode (with the oracle's reader = the reference format) to the reference's stream
@@ -255,3 +255,32 @@ def test_config3_two_genes_multi_k_stagewise_and_contig_multiset(two_gene_inputs
     # the filtered outputs exist for both genes
     for gene in genes:
         assert (out / "contigs" / gene / "nucl_merged.fasta").stat().st_size > 0 and (out / "contigs" / gene / "prot_merged.fasta").stat().st_size > 0
+
+
+def test_worker_process_and_one_process_per_step_write_identical_artefacts(toy_inputs):
+    """the driver's default (ONE `megagta serve` worker: context, read library and the last graph stay resident between the steps) and
+    `--one-process-per-step` (the reference driver's way: every step reads its inputs from the files) produce the same files, byte for
+    byte: graphs, contigs of the intermediate k, seeds, raw and filtered contigs, checkpoints"""
+    assert os.path.exists(BIN), "megagta_amd/bin/megagta missing: run __graft_entry__.build()"
+    d = toy_inputs
+    outs = []
+    for tag, extra in (("w", []), ("p", ["--one-process-per-step"])):
+        out = d / f"out_mode_{tag}"
+        r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(d / "gene_list.txt"), "-k", "30,36,45", "-o", str(out),
+                            "-t", "4", "--min-contig-len", "150", "--verbose"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(out)
+        log = (out / "log").read_text()
+        assert ("still on the device" in log) == (tag == "w")          # the hand-off really happened (and only in the worker)
+    files = ["k29/29.sdbg.0", "k29/29.sdbg_info", "k29/29.contigs.fa", "k35/35.sdbg.0", "k35/35.contigs.fa", "k35/35.contigs.fa.info",
+             "k44/44.sdbg.0", "k44/44.sdbg_info", "k44/44_rplB_starting_kmers.txt", "k44/44_raw_contigs_rplB.fasta",
+             "contigs/rplB/nucl_merged.fasta", "contigs/rplB/prot_merged.fasta", "tmp/cp.txt", "tmp/reads.lib.bin"]
+    for f in files:
+        a, b = (outs[0] / f).read_bytes(), (outs[1] / f).read_bytes()
+        assert a == b and len(a) > 0, f
+    # a failing step in the worker is reported like a failing child process
+    bad = d / "gene_list_bad.txt"
+    bad.write_text("rplB /nonexistent/for.hmm /nonexistent/rev.hmm " + (d / "gene_list.txt").read_text().split()[3] + "\n")
+    r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(bad), "-k", "45", "-o", str(d / "out_bad"), "-t", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Error occurs when running" in r.stderr
