@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--k", type=int, default=45, help="CLI k (graph k = k-1, megagta.py:815-816)")
     ap.add_argument("--genes", default="rplB:277,nirK:360")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--seeds", type=int, default=8000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
+    ap.add_argument("--seeds", type=int, default=20000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
     ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="sample the reference binary is timed on in that leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
@@ -311,7 +311,7 @@ def main():
         fence()
         note(f"search warm-up: {w0['n_expansions']} expansions, {w0['ms_kernel']:.0f} ms on the device")
         t = time.time()
-        n_s = max(1, args.steps // 2)
+        n_s = 1 if args.reads > 20_000_000 else max(1, args.steps // 2)      # (a step of the search leg takes ~25 s at 100 M reads)
         sst = [sstep() for _ in range(n_s)]
         fence()
         sdt = (time.time() - t) / n_s

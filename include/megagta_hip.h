@@ -222,7 +222,7 @@ typedef struct mgta_astar_stats {
     int64_t n_seeds, n_expansions, n_opened, n_retries;   /* n_retries: searches run again because the pool was exhausted (normally 0) */
     double ms_total, ms_kernel;
     int64_t n_grown, n_rehash, n_recycled;                /* searches that outgrew their base arena, hash tables re-built, chunks re-used */
-    uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / high-water mark of its bump pointer */
+    uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / most of it in use at once */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */

@@ -216,20 +216,21 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         const int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 12;
         const uint64_t slot_bytes = 128ull << log_b0;                               // per node of the base arena: 64 B + 2 heap slots + 2 hash entries of 16 B
         AstarArenas &ar = ctx->astar;
-        for (int attempt = 0; attempt < 3; ++attempt) {
+        for (int attempt = 0; attempt < 4; ++attempt) {
             const int64_t work = (int64_t)std::max(todo[0].size(), todo[1].size());
             if (work == 0) break;
             // persistent grid: one workgroup per CU and direction pair, fewer when there is little work; a pass that re-runs the
             // searches the pool could not hold runs fewer at a time
             int64_t blocks = std::min<int64_t>((int64_t)ctx->num_cus * (use_lds ? 1 : 2), 2 * ((work + spb - 1) / spb));
             if (const char *e = getenv("MGTA_ASTAR_BLOCKS")) blocks = std::min<int64_t>(blocks, std::max(2, atoi(e)));   // (diagnostic)
-            if (attempt == 1) blocks = std::max<int64_t>(2, blocks / 8);
-            if (attempt == 2) blocks = 2;
+            if (attempt == 2) blocks = std::max<int64_t>(2, blocks / 8);
+            if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
-            // pool = the slots' base arenas + what the searches grow into: 8 MB per search in flight unless the caller said otherwise,
-            // everything that is free for the re-run passes
-            uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes : std::max<uint64_t>(256ull << 20, std::min<uint64_t>(slots, (uint64_t)work * 2) * (8ull << 20));
+            // pool = the slots' base arenas + what the searches grow into: 24 MB per search in flight unless the caller said otherwise
+            // (searches of 10^5 expansions hold 50-100 MB; no new search starts while 70 % of it is in use), everything that is free for
+            // the re-run passes
+            uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes : std::max<uint64_t>(256ull << 20, std::min<uint64_t>(slots, (uint64_t)work * 2) * (24ull << 20));
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
             if (attempt > 0 && !ctx->astar_pool_bytes) dyn = avail;
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
@@ -247,25 +248,26 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 meta[c] = (uint32_t)stack_words; meta[kNumClasses + c] = (uint32_t)fit;
                 stack_words += fit;
             }
-            const size_t meta_words = 2 + 2 * kNumClasses /*lock, cnt*/ + 8 /*stat (u64 x 4)*/ + 2 * kNumClasses /*meta*/;
+            const size_t meta_words = 2 + 2 * kNumClasses /*lock, cnt*/ + 12 /*stat (u64 x 6)*/ + 2 * kNumClasses /*meta*/;
             if (ar.meta.bytes < (meta_words + stack_words) * 4 + 64) ar.meta.alloc((meta_words + stack_words) * 4 + 64, &ctx->live_bytes, &ctx->peak_bytes);
             {
-                // layout (32-bit words): [bump u64][stat u64 x 4][lock NC][cnt NC][meta 2 NC][stacks]
+                // layout (32-bit words): [bump u64][stat u64 x 6][lock NC][cnt NC][meta 2 NC][stacks]
                 uint32_t *w = ar.meta.as<uint32_t>();
-                MGTA_HIP_CHECK(hipMemsetAsync(w, 0, (10 + 2 * kNumClasses) * 4, st));
-                MGTA_HIP_CHECK(hipMemcpyAsync(w + 10 + 2 * kNumClasses, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+                MGTA_HIP_CHECK(hipMemsetAsync(w, 0, (14 + 2 * kNumClasses) * 4, st));
+                MGTA_HIP_CHECK(hipMemcpyAsync(w + 14 + 2 * kNumClasses, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
                 const unsigned long long bump0 = slots * slot_bytes;
                 MGTA_HIP_CHECK(hipMemcpyAsync(w, &bump0, 8, hipMemcpyHostToDevice, st));
                 a.pool.base = ar.pool.as<char>(); a.pool.bytes = pool_bytes;
                 a.pool.bump = reinterpret_cast<unsigned long long *>(w);
                 a.pool.stat = reinterpret_cast<unsigned long long *>(w + 2);
-                a.pool.lock = w + 10; a.pool.cnt = w + 10 + kNumClasses;
-                a.pool.meta = w + 10 + 2 * kNumClasses;
-                a.pool.stack = w + 10 + 4 * kNumClasses;
+                a.pool.lock = w + 14; a.pool.cnt = w + 14 + kNumClasses;
+                a.pool.meta = w + 14 + 2 * kNumClasses;
+                a.pool.stack = w + 14 + 4 * kNumClasses;
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
+            a.pool.soft_limit = dyn / 10 * 7;
             a.gate = cache_mode > 0 && attempt == 0;
-            a.active_slots = attempt == 2 ? 1u : (uint32_t)spb;
+            a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_seed.p, 0xFF, slots * 8, st));
@@ -283,8 +285,8 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            unsigned long long h_pool[5];                                           // bump, stat[0..3]
-            MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 40, hipMemcpyDeviceToHost, st));
+            unsigned long long h_pool[7];                                           // bump, stat[0..5]
+            MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 56, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
             MGTA_HIP_CHECK(hipGetLastError());
             float ms = 0;
@@ -292,7 +294,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             ST.ms_kernel += ms;
             ST.n_recycled += (int64_t)h_pool[1]; ST.n_rehash += (int64_t)h_pool[3]; ST.n_grown += (int64_t)h_pool[4];
             ST.pool_bytes = pool_bytes;
-            ST.pool_used = std::max<uint64_t>(ST.pool_used, h_pool[0]);
+            ST.pool_used = std::max<uint64_t>(ST.pool_used, slots * slot_bytes + h_pool[6]);   // base arenas + most ever handed out at once
             for (int d = 0; d < 2; ++d) {
                 std::vector<int64_t> again;
                 for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);

@@ -81,7 +81,9 @@ struct PoolDev {
     unsigned int *lock, *cnt;     // [kNumClasses] spin lock and number of free chunks per class
     unsigned int *stack;          // free chunks (4 KB units) of class c at stack[meta[c] .. meta[c] + meta[kNumClasses + c])
     const unsigned int *meta;
-    unsigned long long *stat;     // [0] chunks served by the free lists, [1] failed allocations, [2] re-hashes, [3] searches that grew
+    unsigned long long *stat;     // [0] chunks served by the free lists, [1] failed allocations, [2] re-hashes, [3] searches that grew,
+                                  // [4] bytes handed out and not yet returned, [5] its high-water mark (sampled when a search starts)
+    unsigned long long soft_limit;   // no new search starts while more than this is in use: the ones that run keep room to grow
 };
 
 struct AstarArgs {
@@ -216,11 +218,13 @@ __device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
     }
     // a chunk another CU may have used: drop whatever this CU's L1 still holds of it (once per chunk, not per poll)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (res != kNoChunk) __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bytes in use
     return res;
 }
 // The caller has issued pool_release_fence() since its last store into the chunk.
 __device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit) {
     const int lane = lane_id();
+    __hip_atomic_fetch_sub(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t turn = __ballot(true);
     while (turn) {
         const int l = __builtin_ctzll(turn);
@@ -588,7 +592,17 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     while (true) {
         // ================= next search for the idle slots
         if (st == S_IDLE && lslot >= a.active_slots) st = S_EXIT;
-        if (st == S_IDLE) {
+        bool admit = true;
+        if (st == S_IDLE) {       // admission: searches in flight are bounded by the memory they hold, not only by the number of slots
+            unsigned long long used = 0;
+            if (gl == 0) {
+                used = ld_agent(&a.pool.stat[4]);
+                if (used > ld_agent(&a.pool.stat[5])) __hip_atomic_fetch_max(&a.pool.stat[5], used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            used = GX::bcast(used, 0, gbase);
+            admit = used <= a.pool.soft_limit;
+        }
+        if (st == S_IDLE && admit) {
             long long qi = 0;
             if (gl == 0) {
                 if (a.gate) {
@@ -617,6 +631,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
         }
         if (__ballot(st != S_EXIT) == 0ull) break;
+        if (__ballot(st != S_EXIT && st != S_IDLE) == 0ull) {               // every slot of this wave waits for memory
+#pragma unroll
+            for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+        }
         PROF(0)
 
         // ================= ordered-commit gate (shared-cache launches): wave-level, never blocks the searches that are running

@@ -537,6 +537,8 @@ static int main_serve() {
         if (f[0] == "quit") break;
         std::string in_path, out_path;
         std::vector<char *> av;
+        static char prog[] = "megagta";
+        av.push_back(prog);
         for (std::string &x : f) {
             if (!x.empty() && x[0] == '<') in_path = x.substr(1);
             else if (!x.empty() && x[0] == '>') out_path = x.substr(1);
