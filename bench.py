@@ -100,20 +100,27 @@ def write_fasta_fast(reads: np.ndarray, path: str) -> None:
     rec.tofile(path)
 
 
-def e2e_leg(reads: np.ndarray, genes, n_ours: int, n_ref: int, klist: str = "30,36,45") -> dict:
-    """reads.fa -> contigs/<gene>/{nucl,prot}_merged.fasta through megagta.py (one run per sample), wall seconds; the reference binary
-    behind the same driver on the smaller sample (its thread count swept, best kept) and ours on that sample too for an equal-work ratio"""
+def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,36,45") -> dict:
+    """reads.fa -> contigs/<gene>/{nucl,prot}_merged.fasta through megagta.py, wall seconds.  Two read sets of their own (the same
+    model as the build leg's, 15x coverage each: a prefix of the 100 M reads would be a 0.3x sample of 50 000 genomes with next to
+    nothing to assemble): `n_ours` reads for our driver run, and `n_ref` reads on which the reference binary runs behind the same driver
+    (thread count swept, best kept) and ours runs too, for an equal-work ratio."""
     from megagta_amd import synth
     cores = os.cpu_count() or 1
     tmp = tempfile.mkdtemp(prefix="mgta_e2e_")
-    out = {"k_list": klist, "genes": [g.name for g in genes]}
+    out = {"k_list": klist, "genes": [g[0] for g in gene_specs]}
     try:
-        gl = synth.write_gene_models(genes, os.path.join(tmp, "models"))
+        sets = {}
 
         def run(n, tag, extra):
-            fa = os.path.join(tmp, f"reads_{n}.fa")
-            if not os.path.exists(fa):
-                write_fasta_fast(reads[:n], fa)
+            if n not in sets:
+                mg = synth.make_metagenome_device(n, 150, gene_specs, seed=1000 + n % 997, device=device, host_sample=n)
+                d = os.path.join(tmp, f"set_{n}")
+                gl_ = synth.write_gene_models(mg.genes, os.path.join(d, "models"))
+                write_fasta_fast(mg.sample_reads, os.path.join(d, "reads.fa"))
+                sets[n] = (os.path.join(d, "reads.fa"), gl_, [g.name for g in mg.genes])
+                del mg
+            fa, gl, names = sets[n]
             od = os.path.join(tmp, "out_" + tag)
             t = time.time()
             r = subprocess.run([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
@@ -121,25 +128,24 @@ def e2e_leg(reads: np.ndarray, genes, n_ours: int, n_ref: int, klist: str = "30,
             dt = time.time() - t
             if r.returncode != 0:
                 raise RuntimeError(f"megagta.py ({tag}) failed: {r.stderr[-800:]}")
-            n_contigs = {g.name: sum(1 for l in open(os.path.join(od, "contigs", g.name, "nucl_merged.fasta")) if l.startswith(">")) for g in genes}
+            n_contigs = {g: sum(1 for l in open(os.path.join(od, "contigs", g, "nucl_merged.fasta")) if l.startswith(">")) for g in names}
             shutil.rmtree(od, ignore_errors=True)
             return dt, n_contigs
 
-        n_ours = min(n_ours, reads.shape[0])
         dt, nc = run(n_ours, "ours", ["-t", str(min(cores, 16))])
         note(f"e2e ours: {n_ours} reads in {dt:.1f} s")
         out["ours"] = {"reads": n_ours, "seconds": dt, "reads_per_s": n_ours / dt, "contigs": nc}
         if n_ref > 0 and os.path.exists(REF):
-            n_ref = min(n_ref, reads.shape[0])
             best = None
-            for threads in sorted({min(cores, 8), min(cores, 32), cores}):
+            for threads in sorted({min(cores, 32), cores}):
                 dtr, ncr = run(n_ref, f"ref_t{threads}", ["--bin", REF, "-t", str(threads)])
                 note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
                 if best is None or dtr < best[0]:
                     best = (dtr, threads, ncr)
             dto, nco = run(n_ref, "ours_small", ["-t", str(min(cores, 16))])
             out["reference"] = {"reads": n_ref, "seconds": best[0], "threads": best[1], "reads_per_s": n_ref / best[0], "contigs": best[2],
-                                "note": "the reference binary behind the same driver on the same files; best of 8 / 32 / all threads"}
+                                "note": "the reference binary behind the same driver on the same files; best of 32 / all threads "
+                                        "(8 threads were slower in every run kept under profiles/)"}
             out["ours_same_sample"] = {"reads": n_ref, "seconds": dto, "contigs": nco}
             out["speedup_same_sample"] = best[0] / dto
             out["speedup_reads_per_s"] = (n_ours / dt) / (n_ref / best[0])
@@ -209,7 +215,7 @@ def main():
     gene_specs = tuple((g.split(":")[0], int(g.split(":")[1])) for g in args.genes.split(","))
     # identical synthetic read set on every rank (seeded), generated and packed on the device
     t0 = time.time()
-    host_sample = max(args.cpu_sample if not args.no_cpu_baseline else 0, args.e2e_reads, args.e2e_ref_reads, 1) if rank == 0 and world == 1 else 1
+    host_sample = max(args.cpu_sample if not args.no_cpu_baseline else 0, 1) if rank == 0 and world == 1 else 1
     mg = synth.make_metagenome_device(args.reads, L, gene_specs, seed=1, device=f"cuda:{local_rank}", host_sample=host_sample)
     t_gen = time.time() - t0
     note(f"{args.reads} reads generated and packed on the device in {t_gen:.1f} s")
@@ -414,7 +420,7 @@ def main():
             if args.e2e_reads > 0:
                 try:
                     note("e2e leg ...")
-                    out["e2e"] = e2e_leg(mg.sample_reads, mg.genes, args.e2e_reads, args.e2e_ref_reads)
+                    out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}")
                     note("e2e leg done")
                 except Exception as e:                                   # the bench line must not die with a leg
                     out["e2e"] = {"error": str(e)[-600:]}

@@ -363,8 +363,7 @@ template <int G> struct Heap {
     // blocks of the hole): lane l < 7 holds one PAIR of siblings of the subtree under the hole (level t = floor(log2(l+1)) + 1,
     // pair p = l + 1 - 2^(t-1)), decides locally which of the two its parent would pick, a chain of ballots tells which lanes lie
     // on the path, and those lanes move their entries up at once.
-    __device__ __forceinline__ HeapEnt pop(uint32_t n) const {
-        const HeapEnt top = get(0);
+    __device__ __forceinline__ void remove_top(uint32_t n) const {      // (the caller has read the top: get(0))
         if (n > 1) {
             const HeapEnt v = get(n - 1);
             const int64_t len = (int64_t)n - 1;
@@ -403,9 +402,21 @@ template <int G> struct Heap {
             }
             sift_up((uint64_t)hole, v);
         }
-        return top;
     }
 };
+// start fetching a line the search is going to need a few microseconds from now (the popped node's hash slot, its pool entry, its
+// graph line) while the heap is being repaired: by the time it is used it comes from L2 instead of HBM.  gfx950 has no prefetch
+// instruction: a one-byte load whose result nobody reads.  The compiler does not know the asm is a load, so the register is kept
+// reserved until touch_done(), which waits for the load (a result arriving later would overwrite whatever the register holds then).
+__device__ __forceinline__ uint32_t touch(const void *p) {
+    uint32_t t;
+    asm volatile("global_load_ubyte %0, %1, off" : "=v"(t) : "v"(p) : "memory");
+    return t;
+}
+__device__ __forceinline__ void touch_done(uint32_t a, uint32_t b, uint32_t c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(a), "v"(b), "v"(c));
+}
 
 // closed set + open_hash: every lane of the group probes the same key (one request)
 __device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask, uint64_t key, bool &found, uint32_t &val) {
@@ -428,10 +439,10 @@ __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_
     const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
     uint64_t i = mix64(key) & cmask;
     for (uint32_t probes = 0; probes <= a.cache_probe_limit; ++probes) {
-        unsigned long long k = ld_agent(&tab[i].key);
+        const unsigned long long k = ld_agent(&tab[i].key);
+        unsigned long long v = ld_agent(&tab[i].val);                  // (both in flight together: one round trip per probe)
         if (k == 0) return -1;
         if (k == key) {
-            unsigned long long v = ld_agent(&tab[i].val);
             if (v == 0ull) return -1;
             v = ~v;
             return (int64_t)(v >> 16) <= seed ? (int)(v & 0xFFFF) : -1;
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     // ---- per-search state (uniform inside a group)
     int st = S_IDLE;
     bool need_scan = false;
-    unsigned long long spins = 0;
+    uint32_t spins = 0;
     long long seed = -1;
     int64_t sid = 0;
     uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0, cap_heap = 2 * B0;
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     HashEnt *hash = base_hash;
     uint32_t hmask = 2 * B0 - 1;
     int hclass = base_hclass;
-    int64_t n_closed = 0, n_expanded = 0, n_opened = 0;
+    uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     int32_t goal = -1, inter = 0, cur = 0;
     double inter_val = 0;                                             // (real_score + exit_prob[length]) / ln 2 of node `inter`
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (st == S_WAIT && b >= seed) st = S_START;
                     need_scan = false;
                 }
-                if (st == S_WAIT && ++spins > (1ull << 22)) {          // bounded wait: the host reports the seed
+                if (st == S_WAIT && ++spins > (1u << 22)) {          // bounded wait: the host reports the seed
                     if (gl == 0) { a.status[sid] = 4; st_agent(&a.run_seed[slot], -1ll); }
                     st = S_EXIT;
                 }
@@ -732,7 +743,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 uint32_t hs = 0, hval = kNone;
                 uint64_t hkey = 0;
                 while (n_heap > 0) {
-                    const HeapEnt top = H.pop(n_heap);
+                    const HeapEnt top = H.get(0);
+                    const uint32_t t0 = touch(hash + ((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node)),
+                                   t2 = touch(g.lines + ((top.key >> 18) >> 6));
+                    H.remove_top(n_heap);
+                    touch_done(t0, t1, t2);
                     --n_heap;
                     bool found;
                     hs = hash_find(hash, hmask, top.key, found, hval);
@@ -892,21 +907,34 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 auto admissible = [&](int length, int negative_count, double real_score) {
                     return a.prune > 0 ? ((length < 5 || negative_count <= a.prune) && real_score > 0.0) : true;
                 };
-                auto probe_open = [&](int64_t node_id, int state_no, int stt, int fval) -> bool {   // per-lane probe of this lane's own key
-                    const uint64_t key = make_key(node_id, state_no, stt);
-                    uint32_t ii = (uint32_t)mix64(key) & hmask;
+                // the probes of one expansion are independent: their first loads are issued together, then resolved, then the fvals of
+                // the open-list entries they found are fetched together (three dependent round trips instead of six)
+                auto ld_slot = [&](uint32_t ii) { return *reinterpret_cast<const uint4 *>(hash + ii); };
+                auto resolve = [&](uint64_t key, uint32_t ii, uint4 v) -> uint32_t {     // open-list node recorded for `key`, kNone = none
                     while (true) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(hash + ii);
                         const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
-                        if (k == 0) return true;
-                        if (k == key) {
-                            const uint32_t oi = v.z & kNone;
-                            if (oi == kNone) return true;
-                            return node_at(oi)->fval < fval;                           // got->second < next (:299-302); equal keys => only fval differs
-                        }
+                        if (k == 0) return kNone;
+                        if (k == key) return v.z & kNone;
                         ii = (ii + 1) & hmask;
+                        v = ld_slot(ii);
                     }
                 };
+                ANode cd;                                                              // delete child (:218-244), same in every lane
+                cd.parent = cur; cd.node_id = curr.node_id;
+                cd.state_no = (int16_t)next_state; cd.length = curr.length;
+                cd.real_score = curr.real_score + dt;
+                cd.max_score = curr.max_score;
+                cd.negative_count = (int16_t)(curr.negative_count + 1);
+                cd.score = curr.score + (dt - max_match);
+                cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
+                cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
+                bool del = want_del;
+                if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score);
+                const bool probe_d = del && !first;
+                const uint64_t key_d = make_key(cd.node_id, cd.state_no, ST_D);
+                const uint32_t slot_d = (uint32_t)mix64(key_d) & hmask;
+                uint4 vd = make_uint4(0, 0, 0, 0);
+                if (probe_d) vd = ld_slot(slot_d);
                 // node indices are handed out codon rank by codon rank (k), lane by lane, match before insert: the pool order is not
                 // observable, only the order of the commits below is
                 uint32_t nbase = n_nodes;
@@ -943,8 +971,21 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     }
                     bool open_m = use, open_i = use && ins_ok;
                     if (!first) {                                                      // :212-233: the first expansion neither prunes nor looks up
-                        if (open_m) open_m = admissible(cm.length, cm.negative_count, cm.real_score) && probe_open(cm.node_id, cm.state_no, ST_M, cm.fval);
-                        if (open_i) open_i = admissible(cin.length, cin.negative_count, cin.real_score) && probe_open(cin.node_id, cin.state_no, ST_I, cin.fval);
+                        open_m = open_m && admissible(cm.length, cm.negative_count, cm.real_score);
+                        open_i = open_i && admissible(cin.length, cin.negative_count, cin.real_score);
+                        const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
+                        const uint32_t slot_m = (uint32_t)mix64(key_m) & hmask, slot_i = (uint32_t)mix64(key_i) & hmask;
+                        uint4 vm = make_uint4(0, 0, 0, 0), vi = vm;
+                        if (open_m) vm = ld_slot(slot_m);
+                        if (open_i) vi = ld_slot(slot_i);
+                        uint32_t om = kNone, oi = kNone;
+                        if (open_m) om = resolve(key_m, slot_m, vm);
+                        if (open_i) oi = resolve(key_i, slot_i, vi);
+                        int old_m = 0, old_i = 0;
+                        if (om != kNone) old_m = node_at(om)->fval;
+                        if (oi != kNone) old_i = node_at(oi)->fval;
+                        if (om != kNone) open_m = old_m < cm.fval;                     // got->second < next (:299-302); equal keys => only fval differs
+                        if (oi != kNone) open_i = old_i < cin.fval;
                     }
                     const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
                     const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
@@ -956,17 +997,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (k == 0) { fm0 = cm.fval; fi0 = cin.fval; } else if (k == 1) { fm1 = cm.fval; fi1 = cin.fval; }
                     else if (k == 2) { fm2 = cm.fval; fi2 = cin.fval; } else { fm3 = cm.fval; fi3 = cin.fval; }
                 }
-                ANode cd;                                                              // delete child (:218-244), same in every lane
-                cd.parent = cur; cd.node_id = curr.node_id;
-                cd.state_no = (int16_t)next_state; cd.length = curr.length;
-                cd.real_score = curr.real_score + dt;
-                cd.max_score = curr.max_score;
-                cd.negative_count = (int16_t)(curr.negative_count + 1);
-                cd.score = curr.score + (dt - max_match);
-                cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
-                cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
-                bool del = want_del;
-                if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score) && probe_open(cd.node_id, cd.state_no, ST_D, cd.fval);
+                if (probe_d) {
+                    const uint32_t od = resolve(key_d, slot_d, vd);
+                    if (od != kNone) del = node_at(od)->fval < cd.fval;
+                }
                 const uint32_t idx_d = nbase;
                 if (del && gl == 0) store_node(node_at(idx_d), cd);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
