@@ -535,6 +535,13 @@ static int main_serve() {
             if (!e) break;
         }
         if (f[0] == "quit") break;
+        if (f[0] == "release") {                                          // hand the device memory back (another process is going to need it)
+            graph_drop();
+            if (g_sess.ctx) mgta_ctx_release_scratch(g_sess.ctx);
+            fprintf(rep, "DONE 0\n");
+            fflush(rep);
+            continue;
+        }
         std::string in_path, out_path;
         std::vector<char *> av;
         static char prog[] = "megagta";

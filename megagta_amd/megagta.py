@@ -32,6 +32,8 @@ USAGE = """Usage:
     -m/--memory 0.9        -t/--num-cpu-threads N   --min-contig-len 450   --max-tip-len 150
     --no-mercy  --mem-flag 1  --gpu-mem BYTES  --keep-tmp-files  --continue  --verbose
     --bin PATH       the multi-call `megagta` executable (default: this package's bin/megagta)
+    --gpus N         GPUs of this node for the search step: one process per GPU (torch.distributed over RCCL), seeds sharded by gene
+                     first, one all-gather of contigs (megagta_amd/search_dist.py); every other step runs on GPU 0
     --one-process-per-step   start every step as its own process, as the reference driver does (default: one worker process,
                      `megagta serve`, runs all steps and keeps the device context, the read library and the last graph between them)"""
 
@@ -63,6 +65,7 @@ class Opt:
         self.gene_info = {}
         self.bin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "megagta")
         self.one_process_per_step = False
+        self.gpus = 1
 
 
 opt = Opt()
@@ -70,7 +73,7 @@ cp = 0
 
 LONG = ["help", "read=", "12=", "out-dir=", "memory=", "gpu-mem=", "min-contig-len=", "num-cpu-threads=", "kmin-1pass", "k-list=",
         "min-count=", "max-tip-len=", "no-mercy", "keep-tmp-files", "mem-flag=", "version", "verbose", "continue", "gene-list=",
-        "prune-len=", "low-cov-penalty=", "bin=", "one-process-per-step"]
+        "prune-len=", "low-cov-penalty=", "bin=", "one-process-per-step", "gpus="]
 
 
 def parse_opt(argv):
@@ -115,6 +118,7 @@ def parse_opt(argv):
         elif o in ("-l", "--low-cov-penalty"): opt.low_cov_penalty = float(v)
         elif o == "--bin": opt.bin = v
         elif o == "--one-process-per-step": opt.one_process_per_step = True
+        elif o == "--gpus": opt.gpus = int(v)
         else:
             raise Usage("Invalid option " + o)
     opt.temp_dir = opt.out_dir + "tmp/"
@@ -359,13 +363,42 @@ def find_seed(k, gene):
     write_cp()
 
 
+def run_multi_gpu_search(par, k):
+    """the search step on opt.gpus GPUs: its own processes (one per GPU), same arguments and files as `megagta search`"""
+    logging.info("--- [%s] Searching contigs for k = %d on %d GPUs ---" % (datetime.now().strftime("%c"), k, opt.gpus))
+    if worker is not None:
+        worker.request(["release"])                      # the worker gives its device memory back while the ranks run
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "search_dist.py")] + par
+    logging.debug("cmd: " + " ".join(cmd))
+    p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+    for line in p.stderr:
+        logging.debug(line.decode(errors="replace").rstrip())
+    ret = p.wait()
+    if ret != 0:
+        logging.error("Error occurs when searching contigs for k = %d on %d GPUs, please refer to %s for detail" % (k, opt.gpus, log_file()))
+        logging.error("[Exit code %d]" % ret)
+        if worker is not None:
+            worker.close()
+        sys.exit(ret)
+
+
 def search_contigs(k):
     """search, then per gene filterbylen + translate.  Checkpoints as the reference writes them (:680-760): the two filters of every
     gene have their own, written INSIDE the search step, the search's own comes last -- a finished run continues identically under
     either driver"""
     if should_run():
-        run_step([opt.bin, "search", graph_prefix(k), opt.gene_list, graph_prefix(k), graph_prefix(k), str(opt.prune_len),
-                  str(opt.low_cov_penalty), str(min(12, opt.num_cpu_threads))], "Searching contigs for k = %d" % k)
+        par = [graph_prefix(k), opt.gene_list, graph_prefix(k), graph_prefix(k), str(opt.prune_len), str(opt.low_cov_penalty),
+               str(min(12, opt.num_cpu_threads))]
+        if opt.gpus > 1:
+            run_multi_gpu_search(par, k)
+        else:
+            run_step([opt.bin, "search"] + par, "Searching contigs for k = %d" % k)
         os.makedirs(opt.out_dir + "contigs", exist_ok=True)
         for gene in opt.gene_info:
             d = opt.out_dir + "contigs/" + gene

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""`megagta search` over several GPUs of one node: one process per GPU, seeds sharded by gene first, ONE all-gather of contigs.
+
+Same positional arguments, inputs and outputs as `megagta search` (search.cpp:72-90, megagta.py:682-684):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        megagta_amd/search_dist.py <sdbg_prefix> <gene_list> <starting_kmers_prefix> <output_prefix> <prune_len> <low_cov_penalty> [threads]
+
+(the driver does this for `megagta.py --gpus N`; with N = 1 it keeps the plain `megagta search`).  What replaces the reference's OpenMP
+loop over seeds (search.cpp:184-189) across GPUs:
+  * the graph (`<sdbg_prefix>.sdbg.*`) and the gene's two HMMs are replicated: every rank loads them onto its own GPU;
+  * seeds shard by GENE first, then round-robin inside a gene (`dist.gene_seed_share`): with N >= #genes every rank works on one gene;
+  * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW, default 16384):
+    seed j of a rank sees the paths of that rank's seeds <= j - B.  The result is a function of (seed order, N, B), never of timing;
+    N = 1 is exactly `megagta search`;
+  * ONE all-gather of the contig bytes per gene (RCCL over xGMI; gloo in the CPU tests), then rank 0 writes
+    `<output_prefix>_raw_contigs_<gene>.fasta` in seed order with the reference's record names (hmm_graph_search.h:79).
+No collective runs inside any kernel and none is needed before the end: the searches of different ranks share nothing.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def read_gene_list(path: str) -> list[tuple[str, str, str]]:
+    """name fwd.hmm rev.hmm [ref_aligned.faa] per line (search.cpp:105-122)"""
+    out = []
+    with open(path) as f:
+        for line in f:
+            a = line.split()
+            if len(a) >= 3:
+                out.append((a[0], a[1], a[2]))
+    return out
+
+
+def read_seeds(path: str) -> tuple[list[str], list[int]] | None:
+    """8 whitespace-separated columns; column 4 = k-mer, column 8 = 1-based model position (search.cpp:149-158)"""
+    if not os.path.exists(path):
+        return None
+    kmers, states = [], []
+    with open(path) as f:
+        for line in f:
+            a = line.split()
+            if len(a) >= 8:
+                kmers.append(a[3])
+                states.append(int(a[7]) - 1)
+    return kmers, states
+
+
+def fasta_text(gene: str, kmers: list[str], contigs: list[str]) -> str:
+    return "".join(f">{gene}_contig_{2 * i}_contig_{2 * i + 1}\n{c}\n" for i, c in enumerate(contigs))
+
+
+def main(argv: list[str]) -> int:
+    if len(argv) < 7:
+        print(f"Usage: {argv[0]} <succinct_dbg> <gene_list> <starting_kmers_prefix> <output_prefix> <prune_len> <low_cov_penalty> [num_threads=0]",
+              file=sys.stderr)
+        return 1
+    sdbg_prefix, gene_list, seeds_prefix, out_prefix = argv[1:5]
+    prune, pen = int(argv[5]), float(argv[6])
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    window = int(os.environ.get("MEGAGTA_CACHE_WINDOW", "16384"))
+    import torch
+    import torch.distributed as dist
+    from megagta_amd import api, dist as mdist, hmm as hmmlib
+    # MEGAGTA_DIST_BACKEND=gloo + MEGAGTA_DEVICE=0: several ranks on ONE GPU (tests on a one-GPU box; RCCL refuses two ranks per device)
+    backend = os.environ.get("MEGAGTA_DIST_BACKEND", "nccl")
+    device = int(os.environ.get("MEGAGTA_DEVICE", str(local)))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    t0 = time.time()
+    ctx = api.Context(device)
+    graph = api.Graph(ctx, api.read_sdbg(sdbg_prefix))
+    if rank == 0:
+        print(f"    [megagta_amd] rank 0 of {world}: graph of {graph.size} edges on the device ({time.time() - t0:.2f} s)", file=sys.stderr, flush=True)
+    genes = read_gene_list(gene_list)
+    seeds = [read_seeds(f"{seeds_prefix}_{name}_starting_kmers.txt") for name, _, _ in genes]
+    share = mdist.gene_seed_share([len(s[0]) if s else 0 for s in seeds], rank, world)
+    for gi, (name, fwd, rev) in enumerate(genes):
+        if seeds[gi] is None:                                         # search.cpp:163-167: report and go on with the next gene
+            if rank == 0:
+                print(f"    [ERROR] Fail to open {seeds_prefix}_{name}_starting_kmers.txt", file=sys.stderr)
+                open(f"{out_prefix}_raw_contigs_{name}.fasta", "w").close()
+            continue
+        kmers, states = seeds[gi]
+        mine = share[gi]
+        tg = time.time()
+        contigs, nexp = [], 0
+        if mine.size:
+            fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fwd)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rev))
+            res, st = api.astar_search(graph, fw, rv, [kmers[i] for i in mine], [states[i] for i in mine], prune, pen, cache_mode=window)
+            contigs = [r.contig(kmers[i]) for r, i in zip(res, mine.tolist())]
+            nexp = st["n_expansions"]
+            fw.free(); rv.free()
+        every = mdist.all_gather_contigs(len(kmers), mine, contigs) if world > 1 else contigs
+        if rank == 0:
+            with open(f"{out_prefix}_raw_contigs_{name}.fasta", "w") as f:
+                f.write(fasta_text(name, kmers, every))
+            print(f"    [megagta_amd] Done {name}: {len(kmers)} seeds over {world} rank(s), rank 0: {mine.size} seeds, {nexp} expansions, "
+                  f"{time.time() - tg:.2f} s", file=sys.stderr, flush=True)
+    graph.free()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -284,3 +284,46 @@ def test_worker_process_and_one_process_per_step_write_identical_artefacts(toy_i
     r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", str(bad), "-k", "45", "-o", str(d / "out_bad"), "-t", "4"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "Error occurs when running" in r.stderr
+
+
+def test_sharded_search_one_and_two_ranks_vs_megagta_search(two_gene_inputs):
+    """`search_dist.py` (the search step of `megagta.py --gpus N`): with one rank its FASTA files are `megagta search`'s byte for byte;
+    with two ranks (genes -> ranks first: rank 0 takes rplB, rank 1 nirK; gloo here, two processes on the one GPU of the box) every
+    gene is searched by one rank over all its seeds, so the files are again identical; with the seeds of ONE gene split over two ranks
+    (a one-gene list) every rank windows over its own half, and the multiset of contigs still equals the one-rank run on this input"""
+    assert os.path.exists(BIN)
+    d = two_gene_inputs
+    out = d / "out"
+    if not (out / "k44" / "44.sdbg_info").exists():
+        pytest.skip("needs the driver run of test_config3_two_genes_multi_k_stagewise_and_contig_multiset")
+    gl = str(d / "models" / "gene_list.txt")
+    pre = str(out / "k44" / "44")
+    env = {**os.environ, "MEGAGTA_CACHE_WINDOW": "16"}
+    subprocess.run([BIN, "search", pre, gl, pre, str(d / "sd_ref"), "20", "0.5", "4"], check=True, capture_output=True, env=env)
+    script = os.path.join(ROOT, "megagta_amd", "search_dist.py")
+    r = subprocess.run([sys.executable, script, pre, gl, pre, str(d / "sd_w1"), "20", "0.5", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for gene in ("rplB", "nirK"):
+        assert (d / f"sd_w1_raw_contigs_{gene}.fasta").read_bytes() == (d / f"sd_ref_raw_contigs_{gene}.fasta").read_bytes()
+
+    def two_ranks(gene_list, tag):
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        e2 = {**env, "MEGAGTA_DIST_BACKEND": "gloo", "MEGAGTA_DEVICE": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": "2"}
+        ps = [subprocess.Popen([sys.executable, script, pre, gene_list, pre, str(d / tag), "20", "0.5", "4"], env={**e2, "RANK": str(rk), "LOCAL_RANK": str(rk)},
+                               stderr=subprocess.PIPE, text=True) for rk in range(2)]
+        for p in ps:
+            _, err = p.communicate(timeout=600)
+            assert p.returncode == 0, err[-2000:]
+
+    two_ranks(gl, "sd_w2")
+    for gene in ("rplB", "nirK"):
+        assert (d / f"sd_w2_raw_contigs_{gene}.fasta").read_bytes() == (d / f"sd_ref_raw_contigs_{gene}.fasta").read_bytes()
+    one = d / "gene_list_rplB.txt"
+    one.write_text(open(gl).readline())
+    two_ranks(str(one), "sd_w2one")
+    from collections import Counter
+    a, b = _fasta_seqs(d / "sd_w2one_raw_contigs_rplB.fasta"), _fasta_seqs(d / "sd_ref_raw_contigs_rplB.fasta")
+    assert len(a) == len(b) and Counter(a) == Counter(b)
+    names = [l for l in open(d / "sd_w2one_raw_contigs_rplB.fasta") if l.startswith(">")]
+    assert names == [l for l in open(d / "sd_ref_raw_contigs_rplB.fasta") if l.startswith(">")]
