@@ -75,6 +75,16 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);
 int mgta_ctx_set_search_arena(mgta_ctx *, int log2_base_nodes, uint64_t pool_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * Read ingestion (`megagta buildlib`: SequenceManager::ReadShortReads + WriteBinarySequences, sequence_manager.cpp:109-216,375-410;
+ * base codes sequence_package.h:67-69).  `text` = the sequence characters of a batch of reads back to back (the host has inflated the
+ * file and cut it into records), read i = text[offsets[i] .. offsets[i+1]).  bin_words receives the batch's share of PREFIX.bin: per
+ * read uint32 length + ceil(length / 16) words, 2 bits per base (base j of a word at bits 30 - 2j, zero padded, forward orientation,
+ * A0 C1 G2 T3, N -> G, any other byte -> A); *n_words_out = words written (sum of 1 + ceil(len / 16)).
+ * ------------------------------------------------------------------------------------------------ */
+int mgta_reads_pack_text(mgta_ctx *, const char *text, uint64_t n_bytes, const uint64_t *offsets /* [n_reads + 1] */, uint64_t n_reads,
+                         uint32_t *bin_words, uint64_t capacity_words, uint64_t *n_words_out);
+
+/* ------------------------------------------------------------------------------------------------
  * SdBG construction  (replaces CX1::run() with the s2 plug-ins: cx1.h:443-623,
  * s2_lv0_calc_bucket_size / s2_lv1_fill_offset / s2_lv2_extract_substr_ / lv2_cpu_radix_sort_st /
  * output_: cx1_read2sdbg_s2.cpp:252-315,475-677,742-835; lv2_cpu_sort.h:133-150)

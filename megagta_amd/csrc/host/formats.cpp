@@ -164,7 +164,10 @@ FastxReader::~FastxReader() {
 
 // one record: a header line ('>' or '@'), sequence lines up to the next line that starts with '>', '@' or '+'; after '+' as many
 // quality characters as the sequence has are skipped (kseq.h kseq_read).  Codes: sequence_package.h:67-69 (N -> G)
-bool FastxReader::next(std::vector<uint8_t> &codes) {
+static bool fastx_next(FastxReader::Impl &r, std::vector<uint8_t> *codes_p, std::string *text_p);
+bool FastxReader::next(std::vector<uint8_t> &codes) { codes.clear(); return fastx_next(*p_, &codes, nullptr); }
+bool FastxReader::next_text(std::string &text) { return fastx_next(*p_, nullptr, &text); }
+static bool fastx_next(FastxReader::Impl &r, std::vector<uint8_t> *codes_p, std::string *text_p) {
     static const struct CodeTable {
         uint8_t t[256];
         CodeTable() {
@@ -174,9 +177,8 @@ bool FastxReader::next(std::vector<uint8_t> &codes) {
             t[(int)'T'] = t[(int)'t'] = 3;
         }
     } code;
-    codes.clear();
-    Impl &r = *p_;
     if (r.eof) return false;
+    const size_t text_at = text_p ? text_p->size() : 0;
     if (!r.have_pending) {                                   // look for the first header
         for (;;) {
             if (!r.getline(r.line)) { r.eof = true; return false; }
@@ -190,10 +192,13 @@ bool FastxReader::next(std::vector<uint8_t> &codes) {
         const char c = r.line[0];
         if (c == '>' || c == '@') { r.have_pending = true; return true; }
         if (c == '+') {
+            const size_t n_seq = codes_p ? codes_p->size() : text_p->size() - text_at;
             size_t got = 0;
-            while (got < codes.size() && r.getline(r.line)) got += r.line.size();
+            while (got < n_seq && r.getline(r.line)) got += r.line.size();
             return true;
         }
+        if (text_p) { text_p->append(r.line); continue; }
+        std::vector<uint8_t> &codes = *codes_p;
         const size_t at = codes.size();
         codes.resize(at + r.line.size());
         for (size_t i = 0; i < r.line.size(); ++i) codes[at + i] = code.t[(unsigned char)r.line[i]];
@@ -210,7 +215,7 @@ void load_fastx(const std::string &path, bool reverse, PackedReads &out) {
 // read_lib_file: per library one free-text line, then `pe f1 f2` | `se f` | `interleaved f`.  PREFIX.bin: per read uint32 length +
 // ceil(length / 16) words, 2 bit per base, base j of a word at bits 30-2j, zero padded, forward orientation, no N trimming;
 // PREFIX.lib_info: "total_bases total_reads" then per library its text line and "from to max_read_len pe|se".
-void build_read_lib(const std::string &lib_file, const std::string &out_prefix) {
+void build_read_lib(const std::string &lib_file, const std::string &out_prefix, PackTextFn pack, void *pack_user) {
     std::ifstream cfg(lib_file);
     if (!cfg.is_open()) die("File to open read_lib file: %s", lib_file.c_str());
     FILE *bin = fopen((out_prefix + ".bin").c_str(), "wb");
@@ -237,6 +242,28 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix) 
         total_bases += len;
         max_len = std::max(max_len, (int)len);
     };
+    // device path: the sequence characters of a batch of reads back to back + their offsets; `pack` returns the batch's bytes of
+    // PREFIX.bin (mgta_reads_pack_text).  The host keeps what belongs to the file: inflating it and cutting it into records.
+    std::string batch;
+    std::vector<uint64_t> batch_off{0};
+    std::vector<uint32_t> batch_bin;
+    constexpr size_t kBatchBytes = 256u << 20;
+    auto flush_batch = [&]() {
+        if (batch_off.size() == 1) return;
+        if (!pack(pack_user, batch.data(), batch.size(), batch_off.data(), batch_off.size() - 1, batch_bin)) die("packing reads on the device failed");
+        if (!batch_bin.empty() && fwrite(batch_bin.data(), 4, batch_bin.size(), bin) != batch_bin.size()) die("short write to %s.bin", out_prefix.c_str());
+        batch.clear();
+        batch_off.assign(1, 0);
+    };
+    auto end_read = [&](int &max_len) {                               // the read's characters are the tail of `batch`
+        const uint64_t len = batch.size() - batch_off.back();
+        if (len > 0xFFFFFFFFull) die("read longer than 2^32 bases");
+        batch_off.push_back(batch.size());
+        ++total_reads;
+        total_bases += (long long)len;
+        max_len = std::max(max_len, (int)len);
+        if (batch.size() >= kBatchBytes) flush_batch();
+    };
     std::string metadata, rest;
     while (std::getline(cfg, metadata)) {
         std::string type, f1, f2;
@@ -247,6 +274,15 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix) 
             FastxReader r1(f1), r2(f2);
             std::vector<uint8_t> c2;
             for (;;) {
+                if (pack) {
+                    const bool a = r1.next_text(batch);
+                    if (a) end_read(lib.max_len);
+                    const bool b = r2.next_text(batch);
+                    if (b) end_read(lib.max_len);
+                    if (a != b) die("PE library files hold different numbers of reads: %s", metadata.c_str());
+                    if (!a) break;
+                    continue;
+                }
                 const bool a = r1.next(codes), b = r2.next(c2);
                 if (a != b) die("PE library files hold different numbers of reads: %s", metadata.c_str());
                 if (!a) break;
@@ -256,7 +292,8 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix) 
         } else if (type == "se" || type == "interleaved") {
             if (!(cfg >> f1)) die("library needs a file: %s", metadata.c_str());
             FastxReader r1(f1);
-            while (r1.next(codes)) write_read(codes, lib.max_len);
+            if (pack) { while (r1.next_text(batch)) end_read(lib.max_len); }
+            else while (r1.next(codes)) write_read(codes, lib.max_len);
         } else {
             fprintf(stderr, "Cannot identify read library type %s\n", type.c_str());
             die("Valid types: pe, se, interleaved");
@@ -270,6 +307,7 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix) 
         libs.push_back(lib);
         std::getline(cfg, rest);                                     // the rest of the type line
     }
+    if (pack) flush_batch();
     fclose(bin);
     FILE *info = fopen((out_prefix + ".lib_info").c_str(), "w");
     if (!info) die("cannot write %s.lib_info", out_prefix.c_str());

@@ -52,13 +52,16 @@ class FastxReader {                                                             
     explicit FastxReader(const std::string &path);
     ~FastxReader();
     bool next(std::vector<uint8_t> &codes);                                              // false at end of file
+    bool next_text(std::string &text);                                                   // the same record, its sequence characters appended to `text`
     FastxReader(const FastxReader &) = delete;
     FastxReader &operator=(const FastxReader &) = delete;
-  private:
     struct Impl;
+  private:
     Impl *p_;
 };
-void build_read_lib(const std::string &lib_file, const std::string &out_prefix);          // `megagta buildlib`, build_read_lib.cpp
+// `megagta buildlib`, build_read_lib.cpp.  pack != nullptr: batches of sequence text are packed by it (the device: mgta_reads_pack_text)
+typedef bool (*PackTextFn)(void *user, const char *text, uint64_t n_bytes, const uint64_t *offsets, uint64_t n_reads, std::vector<uint32_t> &bin_words);
+void build_read_lib(const std::string &lib_file, const std::string &out_prefix, PackTextFn pack = nullptr, void *pack_user = nullptr);
 
 // ---- findstart ----------------------------------------------------------------------------------------
 struct RefWords {

@@ -599,7 +599,32 @@ static int dispatch(int argc, char **argv) {
     if (sub == "buildlib") {                                             // build_read_lib.cpp:8-20 (host only: file formats, no kernel)
         if (argc < 4) { fprintf(stderr, "Usage %s <read_lib_file> <out_prefix>\n", argv[1]); return 1; }
         RssLine rss;
-        build_read_lib(argv[2], argv[3]);
+        // the reads are packed on the device (mgta_reads_pack_text); the host inflates the files and cuts them into records.  Without a
+        // device (or with MEGAGTA_BUILDLIB_HOST=1) the same bytes come from the host packer, and the log says so.
+        const char *force_host = getenv("MEGAGTA_BUILDLIB_HOST");
+        mgta_ctx *ctx = (force_host && atoi(force_host)) ? nullptr : (g_sess.active ? ctx_get() : mgta_ctx_create(0));
+        if (!ctx) {
+            logf("buildlib: packing reads on the host (%s)", (force_host && atoi(force_host)) ? "MEGAGTA_BUILDLIB_HOST" : mgta_last_error());
+            build_read_lib(argv[2], argv[3]);
+            return 0;
+        }
+        struct Pack {
+            static bool run(void *user, const char *text, uint64_t n_bytes, const uint64_t *off, uint64_t n, std::vector<uint32_t> &out) {
+                uint64_t words = 0;
+                for (uint64_t r = 0; r < n; ++r) words += 1 + (off[r + 1] - off[r] + 15) / 16;
+                out.resize(words);
+                uint64_t got = 0;
+                if (mgta_reads_pack_text(static_cast<mgta_ctx *>(user), text, n_bytes, off, n, out.data(), words, &got) != MGTA_OK) {
+                    fprintf(stderr, "mgta_reads_pack_text: %s\n", mgta_last_error());
+                    return false;
+                }
+                return got == words;
+            }
+        };
+        double t0 = now_s();
+        build_read_lib(argv[2], argv[3], &Pack::run, ctx);
+        logf("buildlib: reads packed on the device (%.3f s)", now_s() - t0);
+        ctx_put(ctx);
         return 0;
     }
     if (sub == "libdump") {      // host-only check of the read loaders (tests): writes what buildgraph / findstart would upload
