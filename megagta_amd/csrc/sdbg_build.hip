@@ -1673,10 +1673,6 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     unsigned int max_len = 0;
     MGTA_HIP_CHECK(hipMemcpyAsync(&max_len, d_maxlen, 4, hipMemcpyDeviceToHost, stream));
     MGTA_HIP_CHECK(hipStreamSynchronize(stream));
-    if (need_mercy && (int)max_len > kMercyMaxLen) {
-        set_error("mercy edges: reads longer than %d bases (%u) are not supported", kMercyMaxLen, max_len);
-        return MGTA_EUNSUPPORTED;
-    }
     // base index -> read id table (one entry per 1024 bases, one past the end) and the left shift that puts the highest bit a mercy
     // candidate (base index << 2 | code) can have at bit 63
     if (n_reads >= 0xFFFFFFFFull) { set_error("stage 1: more than 2^32 reads"); return MGTA_EUNSUPPORTED; }
@@ -1785,9 +1781,21 @@ static int run_stage1(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             };
             Key<2> *cs = device_sort<2>(ctx, stream, d_mercy, d_tmp, n_cand, 4, low64, nullptr, nullptr);
             if (!cs) return MGTA_EUNSUPPORTED;
-            hipLaunchKernelGGL(mercy_kernel, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, stream, cs, n_cand, rd->d_start, n_reads, k, num_k1,
-                               d_solid, d_num_mercy, d_pos2id, cand_shift);
-            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            if ((int)max_len <= kMercyMaxLen) {
+                hipLaunchKernelGGL(mercy_kernel<false>, dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, stream, cs, n_cand, rd->d_start, n_reads, k,
+                                   num_k1, d_solid, d_num_mercy, d_pos2id, cand_shift, (uint8_t *)nullptr, (uint64_t)0);
+                MGTA_HIP_CHECK(hipGetLastError());
+                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            } else {     // reads longer than the LDS flags hold: the flags of every wave go to device memory, a fixed grid walks the groups
+                const uint64_t stride = ((uint64_t)max_len + 64 + 63) & ~63ull;
+                const unsigned grid = (unsigned)std::min<uint64_t>((n_cand + 255) / 256, (uint64_t)ctx->num_cus * 8);
+                DevBuf d_flags;
+                d_flags.alloc((uint64_t)grid * 4 * 3 * stride, &ctx->live_bytes, &ctx->peak_bytes);
+                hipLaunchKernelGGL(mercy_kernel<true>, dim3(grid), dim3(256), 0, stream, cs, n_cand, rd->d_start, n_reads, k, num_k1, d_solid,
+                                   d_num_mercy, d_pos2id, cand_shift, d_flags.as<uint8_t>(), stride);
+                MGTA_HIP_CHECK(hipGetLastError());
+                MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            }
         }
     }
     (void)S;
@@ -1843,7 +1851,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         Timer t_s1(stream);
         t_s1.start();
         if constexpr (W <= 7) rc1 = run_stage1<W>(ctx, rd, n_short, k, min_count, need_mercy, budget, &sol, &nk1, &S);
-        else set_error("min_count > 1 with k > 110 is not supported (sort record of %d words)", W + 2);
+        else set_error("min_count > 1 with k > 110 is not supported (sort record of %d words: the scatter stages 4096 keys in LDS)", W + 2);
         if (rc1 != MGTA_OK) return rc1;
         S.ms_stage1 = t_s1.stop();
         sa.is_solid = sol; sa.num_k1_per_read = nk1;

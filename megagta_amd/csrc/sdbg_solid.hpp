@@ -347,28 +347,37 @@ __global__ __launch_bounds__(256) void s1_apply_kernel(const Key<W1 + 2> *keys, 
 }
 
 // ---- mercy edges (s2_read_mercy_prepare, cx1_read2sdbg_s2.cpp:106-250) ---------------------------------
-constexpr int kMercyMaxLen = 1024;   // longest short read handled (flags live in LDS)
+constexpr int kMercyMaxLen = 1024;   // longest read whose flags live in LDS; longer reads take the variant with its flags in device memory
 
-// sorted candidates -> one wave per read: flag arrays, then the serial gap-filling scan
+// sorted candidates -> one wave per read: flag arrays, then the serial gap-filling scan.  GLOBAL: the three flag arrays of a wave
+// are `stride` bytes each in gflags (reads of any length), a fixed grid of waves walks the candidate groups.
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void mercy_kernel(const Key<2> *cands, uint64_t n_cand, const uint64_t *start_idx, uint64_t n_reads, int k,
                                                     int num_k1_per_read, unsigned long long *is_solid, unsigned long long *num_mercy,
-                                                    const uint32_t *pos_to_id, int cand_shift) {
-    __shared__ uint8_t s_flags[4][3][kMercyMaxLen + 64];
+                                                    const uint32_t *pos_to_id, int cand_shift, uint8_t *gflags, uint64_t stride) {
+    __shared__ uint8_t s_flags[GLOBAL ? 1 : 4][3][GLOBAL ? 64 : kMercyMaxLen + 64];
     const int lane = lane_id(), wv = wave_id();
-    uint8_t *no_in = s_flags[wv][0], *no_out = s_flags[wv][1], *has_k = s_flags[wv][2];
+    uint8_t *const fl = GLOBAL ? gflags + ((uint64_t)blockIdx.x * 4 + wv) * 3 * stride : &s_flags[GLOBAL ? 0 : wv][0][0];
+    const uint64_t fs = GLOBAL ? stride : (uint64_t)(kMercyMaxLen + 64);
+    uint8_t *no_in = fl, *no_out = fl + fs, *has_k = fl + 2 * fs;
+    auto sync_flags = [&]() {                                             // lanes hand the flags to each other: LDS is in order inside a wave,
+        if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // device memory needs the stores drained first
+    };
     auto val = [&](uint64_t i) { return (((uint64_t)cands[i].w[0] << 32) | cands[i].w[1]) >> cand_shift; };
     auto read_of = [&](uint64_t abs) { return read_of_base(start_idx, n_reads, pos_to_id, abs); };
     // every wave takes the candidate ranges whose first candidate index is a multiple-of-stride hit: simple static split by
     // candidate index: wave g handles the reads whose FIRST candidate lies in [g*64, g*64+64)
-    const uint64_t g = (uint64_t)blockIdx.x * 4 + wv;
+    const uint64_t n_groups = (n_cand + 63) / 64, n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wv; g < n_groups; g += n_waves) {
     const uint64_t c_lo = g * 64, c_hi = c_lo + 64 < n_cand ? c_lo + 64 : n_cand;
     for (uint64_t c = c_lo; c < c_hi; ++c) {
         const uint64_t read_id = read_of(val(c) >> 2);
         if (c > 0 && read_of(val(c - 1) >> 2) == read_id) continue;             // not the first candidate of its read
         const uint64_t st = start_idx[read_id];
         const int len = (int)(start_idx[read_id + 1] - st);
-        if (len > kMercyMaxLen) continue;                                        // (checked on the host: reported, never silent)
+        if (!GLOBAL && len > kMercyMaxLen) continue;                             // (the host launches the other variant then)
         for (int i = lane; i < len + 2; i += 64) { no_in[i] = 0; no_out[i] = 0; has_k[i] = 0; }
+        sync_flags();
         int first_0_out = 1 << 30, last_0_in = -1;
         uint64_t e = c;
         // candidates of this read are contiguous
@@ -394,12 +403,14 @@ __global__ __launch_bounds__(256) void mercy_kernel(const Key<2> *cands, uint64_
             last_0_in = o2 > last_0_in ? o2 : last_0_in;
         }
         if (last_0_in < first_0_out) continue;
+        sync_flags();
         auto solid = [&](int i) {
             uint64_t bit = (uint64_t)num_k1_per_read * read_id + (uint64_t)i;
             return (int)((is_solid[bit >> 6] >> (bit & 63)) & 1);
         };
         for (int i = lane; i + k < len; i += 64)
             if (solid(i)) { has_k[i] = 1; has_k[i + 1] = 1; }
+        sync_flags();
         if (lane == 0) {
             int last_no_out = -1;
             unsigned long long added = 0;
@@ -416,6 +427,8 @@ __global__ __launch_bounds__(256) void mercy_kernel(const Key<2> *cands, uint64_
             }
             if (added) atomicAdd(num_mercy, added);
         }
+        sync_flags();
+    }
     }
 }
 

@@ -241,6 +241,32 @@ def test_min_count_vs_oracle_seeded(ctx, oracle, k, m, mercy, assist):
     assert 0 < g.records.size < oracle.Stream.build(packed, start, k, threads=4).edges().records.size    # the filter removed something
 
 
+@pytest.mark.parametrize("k,m,max_len", [(31, 2, 3000), (63, 2, 1500), (44, 3, 9000)])
+def test_mercy_with_reads_longer_than_1024_bases(ctx, oracle, k, m, max_len):
+    """--need_mercy on reads of several thousand bases (round 1 refused them: the per-read flags sat in LDS; they now go to device
+    memory above 1024 bases): stage 1 + mercy + stage 2 == the oracle's restatement, mixed with short reads"""
+    rng = np.random.default_rng(7 * k + max_len)
+    genome = rng.integers(0, 4, 20000).astype(np.uint8)
+    reads = []
+    for i in range(260):
+        L = int(rng.integers(k - 2, 220)) if i % 3 else int(rng.integers(1025, max_len))
+        p = int(rng.integers(0, genome.size - L))
+        r = genome[p:p + L].copy()
+        err = rng.random(L) < 0.006
+        r[err] = (r[err] + rng.integers(1, 4, int(err.sum()))) & 3
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    assert max(r.size for r in reads) > 1024
+    packed, start = readlib.pack_for_build(reads)
+    g = ctx.build_sdbg(ctx.upload_reads(packed, start), k, min_count=m, need_mercy=True)
+    o = oracle.Stream.build_solid(packed, start, k, m, True, threads=4)
+    _same(g, o.edges())
+    assert np.array_equal(ctx.last_counting(), o.counting)
+    no_mercy = oracle.Stream.build_solid(packed, start, k, m, False, threads=4).edges()
+    assert g.records.size > no_mercy.records.size                     # mercy edges really were added
+
+
 def test_fourth_leading_byte_and_wide_run_prefix(ctx, oracle):
     """a bucket range so narrow and so full that three leading key bytes leave segments of > 700 keys: the sort takes a fourth global
     pass and the run prefix of the LDS tiles reaches into the second key word (the regime of memory-bound passes over 10^10 items)"""
@@ -344,7 +370,7 @@ def test_fuzz_small_inputs_vs_oracle(ctx, oracle, seed):
     assert np.array_equal(part.records, o.records[lo:hi]) and np.array_equal(part.bucket_items[b0:b1], o.bucket_items[b0:b1])
     if seed % 3 == 0 and k <= 110:
         m = int(rng.choice([2, 3]))
-        mercy = max(r.size for r in reads) <= 1024
+        mercy = True
         gs = ctx.build_sdbg(rd, k, min_count=m, need_mercy=mercy)
         os_ = oracle.Stream.build_solid(packed, start, k, m, mercy, threads=2)
         _same(gs, os_.edges())
