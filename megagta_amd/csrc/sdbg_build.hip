@@ -1445,9 +1445,11 @@ struct Timer {
     explicit Timer(hipStream_t s) : st(s) { MGTA_HIP_CHECK(hipEventCreate(&a)); MGTA_HIP_CHECK(hipEventCreate(&b)); }
     ~Timer() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     void start() { MGTA_HIP_CHECK(hipEventRecord(a, st)); }
-    double stop() {   // milliseconds, synchronises
+    double stop() {   // milliseconds, synchronises; a launch the runtime rejected inside the phase (grid or LDS limits) surfaces here
+        MGTA_HIP_CHECK(hipGetLastError());
         MGTA_HIP_CHECK(hipEventRecord(b, st));
         MGTA_HIP_CHECK(hipEventSynchronize(b));
+        MGTA_HIP_CHECK(hipGetLastError());
         float ms = 0;
         MGTA_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
         return ms;
@@ -1812,7 +1814,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     const int words_per_tip = (2 * k + 31) / 32;                       // sdbg_multi_io.h:63
     const uint64_t n_reads = rd->n_reads;
     const uint64_t n_blocks = (n_reads + kReadsPerBlock - 1) / kReadsPerBlock;
-    if (n_blocks > 0x7FFFFFFFull) { set_error("too many reads for one launch"); return MGTA_EINVAL; }
+    // the scan kernels run one workgroup of kScanBlock threads per kReadsPerBlock reads: a dispatch holds fewer than 2^32 work-items
+    if (n_blocks * (uint64_t)kScanBlock >= (1ull << 32)) { set_error("too many reads for one launch (%llu)", (unsigned long long)n_reads); return MGTA_EUNSUPPORTED; }
     mgta_build_stats S;
     memset(&S, 0, sizeof(S));
     S.k = k; S.words_per_key = W; S.words_per_tip = words_per_tip; S.n_reads = (int64_t)n_reads;

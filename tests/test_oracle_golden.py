@@ -173,3 +173,25 @@ def test_astar(oracle, golden_dir, mode, fname, prune):
         fasta = H.gz_lines(os.path.join(toy, "44_raw_contigs_rplB.fasta.gz"))
         assert fasta[0::2] == [f">rplB_contig_{2 * i}_contig_{2 * i + 1}" for i in range(len(gold))]
         assert fasta[1::2] == contigs
+
+
+@pytest.mark.parametrize("case,k,threads", [("toy", 44, 4), ("toy", 29, 2), ("ragged", 47, 3), ("ragged", 21, 8)])
+def test_oracle_sdbg_reader_pinned_by_fresh_reference_files(oracle, golden_dir, tmp_path, case, k, threads):
+    """the golden stream MD5s are computed by the oracle's own `.sdbg` reader: pin that reader directly.  A raw-file MD5 cannot serve
+    (the reference spreads the buckets over its `.sdbg.N` files by thread timing: two runs of the same command write different bytes),
+    so the reference binary is run HERE, with another thread count than the generator used, and the oracle's decoding of the files it
+    has just written must be the stream the fixture describes; the decoded file set is checked to hold every bucket exactly once."""
+    import glob
+    import subprocess
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "megagta")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/megagta (the prebuilt reference) is not present")
+    fx = H.load_streams(os.path.join(golden_dir, case, "sdbg_streams.json"))[str(k)]
+    prefix = str(tmp_path / "g")
+    subprocess.run([ref, "buildgraph", "-k", str(k), "-m", "1", "--host_mem", "2000000000", "--mem_flag", "1", "--gpu_mem", "0", "--output_prefix",
+                    prefix, "--num_cpu_threads", str(threads), "--num_output_threads", "1", "--read_lib_file", os.path.join(golden_dir, case, "reads.lib")],
+                   check=True, capture_output=True)
+    assert len(glob.glob(prefix + ".sdbg.*")) >= 1
+    e = oracle.Stream.read(prefix).edges()
+    _stream_matches(e, fx)
+    assert int(e.bucket_items.sum()) == fx["num_edges"]
