@@ -154,8 +154,11 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         MGTA_HIP_CHECK(hipMemcpyAsync(d_exit.p, exit_prob.data(), 3000 * 8, hipMemcpyHostToDevice, st));
         MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
 
-        // lanes per search: 16 (four searches per wavefront); MGTA_ASTAR_GROUP=64 runs one search per wavefront (diagnostic)
-        int G = 16;
+        // lanes per search: 16 (four searches per wavefront: 8192 in flight, the throughput shape) when the batch can fill them; a batch
+        // of fewer than 32768 seeds is bounded by its longest searches, and one search per wavefront (64 lanes: every iteration ~2.5x
+        // shorter, 2048 in flight) finishes those sooner (7.5 k / 9.9 k seeds, window 4096: 2.1 / 3.8 s instead of 4.8 / 6.4 s;
+        // 76 k / 103 k seeds: 16 lanes win).  MGTA_ASTAR_GROUP=16|64 overrides.
+        int G = n < 32768 ? 64 : 16;
         if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
@@ -227,10 +230,14 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
-            // pool = the slots' base arenas + what the searches grow into: 24 MB per search in flight unless the caller said otherwise
-            // (searches of 10^5 expansions hold 50-100 MB; no new search starts while 70 % of it is in use), everything that is free for
-            // the re-run passes
-            uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes : std::max<uint64_t>(256ull << 20, std::min<uint64_t>(slots, (uint64_t)work * 2) * (24ull << 20));
+            // pool = the slots' base arenas + what the searches grow into.  Mapping device memory costs ~27 ms/GB, so the pool follows the
+            // job: 1 MB per search of the batch, at least 2 GB, at most 8 MB per slot (64 GB) -- 24 MB per slot for batches of a million
+            // searches and more, which run for minutes.  No new search starts while 70 % of it is in use, so a small pool costs searches
+            // in flight, not failures; the re-run passes take everything that is free.
+            const uint64_t n_search = (uint64_t)work * 2;
+            uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
+                           : n_search >= (1ull << 20) ? slots * (24ull << 20)
+                                                      : std::min<uint64_t>(slots * (8ull << 20), std::max<uint64_t>(2ull << 30, n_search << 20));
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
             if (attempt > 0 && !ctx->astar_pool_bytes) dyn = avail;
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
@@ -265,7 +272,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
                 a.pool.stack = w + 14 + 4 * kNumClasses;
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
-            a.pool.soft_limit = dyn / 10 * 7;
+            a.pool.soft_limit = dyn / 2;
             a.gate = cache_mode > 0 && attempt == 0;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {

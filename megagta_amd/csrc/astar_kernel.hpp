@@ -29,6 +29,7 @@ constexpr uint32_t kLdsHeapSlots = 72;         // heap slots of a search kept in
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+constexpr uint32_t kStarveLimit = 1u << 15;    // iterations a search waits for memory before it gives up (about a second)
 constexpr uint32_t kMaxNew = 132;              // children one expansion can open (64 codons x {match, insert} + delete), rounded up
 
 enum { T_MM = 0, T_MI = 1, T_MD = 2, T_IM = 3, T_II = 4, T_DM = 5, T_DD = 6 };   // profile_hmm.h:25
@@ -592,6 +593,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     int hclass = base_hclass;
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
+    uint32_t starved = 0;                                             // iterations this search has waited for memory
+    bool have_curr = false;                                           // the node to expand is already popped (the search was waiting for memory)
     int32_t goal = -1, inter = 0, cur = 0;
     double inter_val = 0;                                             // (real_score + exit_prob[length]) / ln 2 of node `inter`
     bool first = true;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1; cap_heap = 2 * B0; h_levels = 1;
             hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
             n_closed = 0; n_expanded = 0; n_opened = 0;
-            status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true;
+            status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
             for (uint32_t i = (uint32_t)gl; i <= hmask; i += G) hash_put(hash, i, 0ull, 0u);
             const char *km = a.kmers + seed * a.klen;
             const int n_aa = a.klen / 3;
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         // ================= one expansion
         if (st == S_RUN) {
             bool stop = false;
-            if (!first) {
+            if (!first && !have_curr) {
                 // pop until a node that is not closed (hmm_graph_search.h:243-257)
                 bool have = false;
                 uint32_t hs = 0, hval = kNone;
@@ -774,7 +777,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
             }
             PROF(3)
-            // room for this expansion's children: the arena grows in place, the table is re-hashed when half full
+            // room for this expansion's children: the arena grows in place, the table is re-hashed when half full.  When the pool has
+            // nothing to give, the search keeps its popped node and asks again in the next iteration: memory comes back as other
+            // searches end (bounded: after kStarveLimit iterations it gives up with status 2 and is run again by the host)
+            bool wait_mem = false;
             if (!stop && n_nodes + kMaxNew > cap_nodes) {
                 uint32_t unit = 0;
                 if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -787,9 +793,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     ++n_levels;
                 }
                 wave_lds_fence();
-                if (n_nodes + kMaxNew > cap_nodes) { status = 2; stop = true; }
+                if (n_nodes + kMaxNew > cap_nodes) wait_mem = true;
             }
-            if (!stop && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {
+            if (!stop && !wait_mem && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {
                 uint32_t unit = 0;
                 const uint32_t need = heap_slots_needed(n_heap + kMaxNew);
                 while (need > cap_heap && h_levels < kMaxLevels && H.ar.chunk_class(h_levels) < kNumClasses) {
@@ -801,15 +807,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     ++h_levels;
                 }
                 wave_lds_fence();
-                if (need > cap_heap) { status = 2; stop = true; }
+                if (need > cap_heap) wait_mem = true;
             }
-            while (!stop && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
+            while (!stop && !wait_mem && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
                 uint32_t unit = kNoChunk;
                 if (hclass + 1 < kNumClasses && hmask < 0x7FFFFFFFu) {
                     if (gl == 0) unit = pool_alloc(a.pool, hclass + 1);
                     unit = GX::bcast(unit, 0, gbase);
                 }
-                if (unit == kNoChunk) { status = 2; stop = true; break; }
+                if (unit == kNoChunk) { wait_mem = true; break; }
                 HashEnt *nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)unit << kUnitLog));
                 const uint32_t nmask = hmask * 2 + 1;
                 for (uint64_t i = (uint64_t)gl; i <= nmask; i += G) hash_put(nt, (uint32_t)i, 0ull, 0u);
@@ -843,8 +849,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 hash = nt; hmask = nmask; ++hclass;
             }
 
+            have_curr = false;
+            if (wait_mem) {
+                have_curr = !first;
+                if (++starved > kStarveLimit) { status = 2; stop = true; }
+            } else {
+                starved = 0;
+            }
             PROF(4)
-            if (!stop) {
+            if (!stop && !wait_mem) {
                 const int cst = curr.em_state >> 9;
                 const int next_state = curr.state_no + 1;
                 // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
@@ -1055,6 +1068,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
             PROF(7)
             if (stop) st = S_DONE;
+        }
+        if (__ballot(st == S_RUN && starved == 0) == 0ull && __ballot(st == S_RUN) != 0ull) {   // every running search of the wave waits for memory
+#pragma unroll
+            for (int z = 0; z < 4; ++z) __builtin_amdgcn_s_sleep(127);
         }
         PROF(8)
 

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -255,7 +256,9 @@ static int main_search(int argc, char **argv) {
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
     // 16384: measured on 413 718 seeds (10 M reads): window 4096 36 s (1.0 G expansions, waits behind the longest search of every
     // window), 16384 21 s (1.4 G), 65536 24 s (3.0 G, little sharing left)
-    int cache_window = 16384;
+    // a gene with few seeds takes a window of half of them (at least 1024): with 7.5 k / 9.9 k seeds the default would share nothing
+    // (measured: window 16384 = cold 6 s per gene, 4096 2.1 / 3.8 s, 1024 3.2 / 5.3 s, 256 7 / 11 s)
+    int cache_window = -1;
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
     int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (measured: no gain at this window)
     if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
@@ -293,11 +296,14 @@ static int main_search(int argc, char **argv) {
         }
         FastaOut fo{out, &gene.name, &kmers};
         mgta_astar_stats st;
-        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, cache_window, sink_contig, &fo, &st) != MGTA_OK)
+        const int window = cache_window >= 0 ? cache_window : (int)std::min<size_t>(16384, std::max<size_t>(1024, kmers.size() / 2));
+        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
-        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device)", gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total);
+        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, pool %.1f of %.1f GB)",
+             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries,
+             st.pool_used / 1e9, st.pool_bytes / 1e9);
     }
     mgta_sdbg_free(g);
     ctx_put(ctx);

@@ -10,7 +10,7 @@ Same positional arguments, inputs and outputs as `megagta search` (search.cpp:72
 loop over seeds (search.cpp:184-189) across GPUs:
   * the graph (`<sdbg_prefix>.sdbg.*`) and the gene's two HMMs are replicated: every rank loads them onto its own GPU;
   * seeds shard by GENE first, then round-robin inside a gene (`dist.gene_seed_share`): with N >= #genes every rank works on one gene;
-  * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW, default 16384):
+  * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW; default 16384, or half the rank's seeds of the gene when those are fewer):
     seed j of a rank sees the paths of that rank's seeds <= j - B.  The result is a function of (seed order, N, B), never of timing;
     N = 1 is exactly `megagta search`;
   * ONE all-gather of the contig bytes per gene (RCCL over xGMI; gloo in the CPU tests), then rank 0 writes
@@ -65,7 +65,7 @@ def main(argv: list[str]) -> int:
     sdbg_prefix, gene_list, seeds_prefix, out_prefix = argv[1:5]
     prune, pen = int(argv[5]), float(argv[6])
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    window = int(os.environ.get("MEGAGTA_CACHE_WINDOW", "16384"))
+    window_env = os.environ.get("MEGAGTA_CACHE_WINDOW")
     import torch
     import torch.distributed as dist
     from megagta_amd import api, dist as mdist, hmm as hmmlib
@@ -100,6 +100,8 @@ def main(argv: list[str]) -> int:
         contigs, nexp = [], 0
         if mine.size:
             fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fwd)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rev))
+            # as `megagta search`: window 16384, half the seeds (at least 1024) for a gene with few of them; per rank: its own seeds
+            window = int(window_env) if window_env is not None else min(16384, max(1024, mine.size // 2))
             res, st = api.astar_search(graph, fw, rv, [kmers[i] for i in mine], [states[i] for i in mine], prune, pen, cache_mode=window)
             contigs = [r.contig(kmers[i]) for r, i in zip(res, mine.tolist())]
             nexp = st["n_expansions"]
