@@ -159,7 +159,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         // shorter, 2048 in flight) finishes those sooner (7.5 k / 9.9 k seeds, window 4096: 2.1 / 3.8 s instead of 4.8 / 6.4 s;
         // 76 k / 103 k seeds: 16 lanes win).  MGTA_ASTAR_GROUP=16|64 overrides.
         int G = n < 32768 ? 64 : 16;
-        if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 64) G = v; }
+        if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
 
@@ -184,7 +184,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
         d_prof.alloc(128);
         MGTA_HIP_CHECK(hipMemsetAsync(d_prof.p, 0, 128, st));
         a.prof = d_prof.as<unsigned long long>();
-        const size_t lds_fix = G == 16 ? lds_fixed<16>() : lds_fixed<64>();
+        const size_t lds_fix = G == 16 ? lds_fixed<16>() : G == 32 ? lds_fixed<32>() : lds_fixed<64>();
         const bool use_lds = lds_fix + tab_bytes + 1024 <= 160 * 1024;             // heap tops + level tables + HMM tables
         const size_t lds_bytes = lds_fix + (use_lds ? tab_bytes : 0);
 
@@ -289,6 +289,7 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             }
             MGTA_HIP_CHECK(hipEventRecord(ev.e[2], st));
             if (G == 16) launch_astar<16>(a, (int)blocks, lds_bytes, use_lds, st);
+            else if (G == 32) launch_astar<32>(a, (int)blocks, lds_bytes, use_lds, st);
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));

@@ -5,7 +5,10 @@ sys.path.insert(0, ".")
 import torch  # noqa: F401
 from megagta_amd import api, findstart, synth, hmm as hmmlib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-configs = [tuple(int(y) for y in (x + ":16:0").split(":")[:3]) for x in (sys.argv[2] if len(sys.argv) > 2 else "4096").split(",")]   # window[:lanes per search[:cost rate]]
+def _cfg(x):   # window[:lanes per search[:cost rate]]
+    a = [int(y) for y in x.split(":")]
+    return (a + [16, 0][len(a) - 1:])[:3]
+configs = [_cfg(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "4096").split(",")]
 mg = synth.make_metagenome(n, 150, (("rplB", 277),), seed=1)
 td = tempfile.mkdtemp()
 synth.write_gene_models(mg.genes, td)
