@@ -543,10 +543,18 @@ __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uin
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
+// keys staged in LDS per round of the scatter: 4096, or 2048 for the 10- and 11-word records of stage 1 at k > 110 (a 4096-key stage
+// of those would not fit the 160 KB); a tile stays 32768 keys either way (census and scatter agree on that)
+template <int W> struct ScatterCfg {
+    static constexpr int kIpt = W >= 10 ? 2 : kItemsPerThread;
+    static constexpr int kSub = kSortThreads * kIpt;
+    static constexpr int kChunk = kSub / kSortWaves;
+};
+
 // shared state of one scatter workgroup
 template <int W>
 struct ScatterShared {
-    Key<W> keys[kSubTile];
+    Key<W> keys[ScatterCfg<W>::kSub];
     uint16_t whist[kSortWaves][256];   // per wave: running count, then position of the wave's first key of the digit value in the sorted sub-tile
     uint64_t gbase[256];               // global destination of the next key of each digit value
     uint64_t gdelta[256];              // global destination minus position in the sorted sub-tile
@@ -557,6 +565,7 @@ struct ScatterShared {
 // call).  Four workgroup barriers per sub-tile; the next sub-tile's keys are on their way while the current one is placed.
 template <int W, bool BIASED = false>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
+    constexpr int kItemsPerThread = ScatterCfg<W>::kIpt, kSubTile = ScatterCfg<W>::kSub, kWaveChunk = ScatterCfg<W>::kChunk;   // (shadow the 4096-key constants)
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];               // wave-private row, updated lane-to-lane inside the wave
     for (int i = lane; i < 256; i += 64) whist[i] = 0;
@@ -1853,8 +1862,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         int rc1 = MGTA_EUNSUPPORTED;
         Timer t_s1(stream);
         t_s1.start();
-        if constexpr (W <= 7) rc1 = run_stage1<W>(ctx, rd, n_short, k, min_count, need_mercy, budget, &sol, &nk1, &S);
-        else set_error("min_count > 1 with k > 110 is not supported (sort record of %d words: the scatter stages 4096 keys in LDS)", W + 2);
+        if constexpr (W <= 9) rc1 = run_stage1<W>(ctx, rd, n_short, k, min_count, need_mercy, budget, &sol, &nk1, &S);
+        else set_error("min_count > 1: a key of %d words is not supported", W);
         if (rc1 != MGTA_OK) return rc1;
         S.ms_stage1 = t_s1.stop();
         sa.is_solid = sol; sa.num_k1_per_read = nk1;
