@@ -254,18 +254,15 @@ static int main_search(int argc, char **argv) {
     double pen = atof(argv[6]);
     // argv[7] (num_threads) is accepted and ignored: the batch runs on the device.  The shared term_nodes cache (search.cpp:182)
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
-    // 16384: measured on 413 718 seeds (10 M reads): window 4096 36 s (1.0 G expansions, waits behind the longest search of every
-    // window), 16384 21 s (1.4 G), 65536 24 s (3.0 G, little sharing left)
     // a gene with few seeds takes a window of half of them (at least 1024): with 7.5 k / 9.9 k seeds the default would share nothing
     // (measured: window 16384 = cold 6 s per gene, 4096 2.1 / 3.8 s, 1024 3.2 / 5.3 s, 256 7 / 11 s)
     int cache_window = -1;
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
-    int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (measured: no gain at this window)
+    int cost_rate = -1;                             // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate
     if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
     double t0 = now_s();
     logf("Loading SdBG...");
     mgta_ctx *ctx = ctx_get();
-    if (mgta_ctx_set_search_cost_rate(ctx, cost_rate) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
     int gk = 0;
     size_t n_edges = 0;
     mgta_sdbg *g = graph_get(ctx, argv[1], &gk, &n_edges);
@@ -296,7 +293,13 @@ static int main_search(int argc, char **argv) {
         }
         FastaOut fo{out, &gene.name, &kmers};
         mgta_astar_stats st;
-        const int window = cache_window >= 0 ? cache_window : (int)std::min<size_t>(16384, std::max<size_t>(1024, kmers.size() / 2));
+        // genes with many seeds: window 8192 with a cost term of 2 expansions per seed (a search that has run r expansions no longer holds
+        // back the seeds below j + B + r / 2: the window slides past the long searches).  Measured (one gene): 82 k seeds 4.7 s vs 5.5 s
+        // with the plain window 16384 (6144 + 2: 4.6 s, 8192 + 4: 4.8 s, 16384 + 2: 5.4 s); 414 k seeds 14.4 s vs 18.8 s.  Genes with few
+        // seeds: half of them, no cost term (7.5 k / 9.9 k seeds: 2.1 / 3.9 s; with the cost term 3.0 / 5.8 s).
+        const bool big = kmers.size() >= 32768;
+        const int window = cache_window >= 0 ? cache_window : big ? 8192 : (int)std::min<size_t>(8192, std::max<size_t>(1024, kmers.size() / 2));
+        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (big ? 2 : 0)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
         if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
