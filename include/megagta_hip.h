@@ -249,6 +249,15 @@ typedef int (*mgta_contig_sink)(void *user, int64_t seed_index, const char *left
 int mgta_astar_batch(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
                      const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
                      int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);
+/* The same batch run with the stream and the work memory of `run` (another context of the graph's device) instead of the graph's own:
+ * two host threads can search two genes of one gene_list side by side on one graph (search.cpp:124 loops over the genes one after the
+ * other).  mgta_ctx_set_search_share(run, 1, 2) on both contexts gives each batch half of the CUs.  Results do not depend on it.
+ * (Measured on two genes of 76 k / 103 k seeds: no faster than one after the other -- `megagta search` keeps the genes sequential
+ * unless MEGAGTA_SEARCH_LANES=2.) */
+int mgta_astar_batch_on(mgta_ctx *run, mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
+                        const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
+                        int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);
+int mgta_ctx_set_search_share(mgta_ctx *, int num, int den);     /* this context's search batches use num/den of the CUs (default 1/1) */
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,9 @@ SYMBOLS = {
     "mgta_ctx_set_search_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "mgta_ctx_keep_stream": (C.c_int, [C.c_void_p, C.c_int]),
     "mgta_sdbg_k": (C.c_int, [C.c_void_p]),
+    "mgta_ctx_set_search_share": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgta_astar_batch_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
+                                     C.c_int, CONTIG_SINK, C.c_void_p, C.POINTER(AstarStats)]),
     "mgta_reads_pack_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mgta_ctx_release_scratch": (C.c_int, [C.c_void_p]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

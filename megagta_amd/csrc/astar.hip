@@ -106,11 +106,23 @@ int mgta_ctx_set_search_arena(mgta_ctx *ctx, int log2_base_nodes, uint64_t pool_
     return MGTA_OK;
 }
 
+int mgta_ctx_set_search_share(mgta_ctx *ctx, int num, int den) {
+    if (!ctx || num < 1 || den < num) { set_error("mgta_ctx_set_search_share: 1 <= num <= den"); return MGTA_EINVAL; }
+    ctx->search_share_num = num; ctx->search_share_den = den;
+    return MGTA_OK;
+}
+
 int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
                      int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats) {
-    if (!g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
+    return mgta_astar_batch_on(g ? g->ctx : nullptr, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, sink, user, stats);
+}
+
+int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state,
+                        int64_t n, int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user,
+                        mgta_astar_stats *stats) {
+    if (!ctx || !g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
     if (cache_mode < 0) { set_error("cache_mode must be >= 0"); return MGTA_EINVAL; }
-    mgta_ctx *ctx = g->ctx;
+    if (ctx->device != g->ctx->device) { set_error("mgta_astar_batch_on: the context and the graph live on different devices"); return MGTA_EINVAL; }
     const int klen = g->dev.k + 1;
     if (klen > kMaxKmer) { set_error("k too large"); return MGTA_EINVAL; }
     try {
@@ -225,6 +237,8 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
             // persistent grid: one workgroup per CU and direction pair, fewer when there is little work; a pass that re-runs the
             // searches the pool could not hold runs fewer at a time
             int64_t blocks = std::min<int64_t>((int64_t)ctx->num_cus * (use_lds ? 1 : 2), 2 * ((work + spb - 1) / spb));
+            // a context that shares the device with another batch (two genes searched side by side) takes its share of the CUs
+            blocks = std::min<int64_t>(blocks, std::max<int64_t>(2, (int64_t)ctx->num_cus * (use_lds ? 1 : 2) * ctx->search_share_num / ctx->search_share_den));
             if (const char *e = getenv("MGTA_ASTAR_BLOCKS")) blocks = std::min<int64_t>(blocks, std::max(2, atoi(e)));   // (diagnostic)
             if (attempt == 2) blocks = std::max<int64_t>(2, blocks / 8);
             if (attempt == 3) blocks = 2;

@@ -73,6 +73,7 @@ struct mgta_ctx {
     int lsd_skip_left = 0;       // sorts left that go straight to LSD passes in LDS (the last look found mostly long runs)
     int astar_log_b0 = 0;        // base arena of a search slot = 1 << astar_log_b0 nodes (0 = default 12); searches grow beyond it in place
     uint64_t astar_pool_bytes = 0;   // device memory the searches may grow into (0 = auto)
+    int search_share_num = 1, search_share_den = 1;   // share of the CUs a search batch of this context takes (mgta_ctx_set_search_share)
     int search_cost_rate = 0;    // shared-cache searches: a path found with c expansions becomes visible c / rate seeds later (0 = no cost term)
     int force_lsd_tiles = 0;     // segment-local sort: LSD passes over every digit, no finish by comparison
     uint64_t live_bytes = 0, peak_bytes = 0;

@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -46,6 +48,7 @@ struct Session {
     std::string lib_key;          // path of the .bin the library was read from
     PackedReads lib;              // reversed, NOT finished (sequences of one step are appended behind it and taken off again)
     bool lib_loaded = false;
+    mgta_ctx *ctx2 = nullptr;     // second context of the device: the other lane of a two-gene search
     mgta_sdbg *graph = nullptr;   // graph of the last buildgraph, not used yet
     std::string graph_prefix;
 };
@@ -268,7 +271,7 @@ static int main_search(int argc, char **argv) {
     mgta_sdbg *g = graph_get(ctx, argv[1], &gk, &n_edges);
     logf("Done! Time elapsed: %.4lf", now_s() - t0);
     const size_t klen = (size_t)gk + 1;
-    for (const GeneEntry &gene : read_gene_list(argv[2])) {
+    auto run_gene = [&](const GeneEntry &gene, mgta_ctx *ctx) {
         double tg = now_s();
         logf("START %s", gene.name.c_str());
         mgta_hmm *fw = upload_hmm(ctx, gene.fwd_hmm), *rv = upload_hmm(ctx, gene.rev_hmm);
@@ -282,7 +285,7 @@ static int main_search(int argc, char **argv) {
             fprintf(stderr, "    [ERROR] Fail to open %s\n", sk.c_str());
             fclose(out);
             mgta_hmm_free(fw); mgta_hmm_free(rv);
-            continue;
+            return;
         }
         logf("Searching from %zu starting kmers", kmers.size());
         std::string flat;
@@ -300,13 +303,39 @@ static int main_search(int argc, char **argv) {
         const bool big = kmers.size() >= 32768;
         const int window = cache_window >= 0 ? cache_window : big ? 8192 : (int)std::min<size_t>(8192, std::max<size_t>(1024, kmers.size() / 2));
         if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (big ? 2 : 0)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
-        if (mgta_astar_batch(g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
+        if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
         logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, pool %.1f of %.1f GB)",
              gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries,
              st.pool_used / 1e9, st.pool_bytes / 1e9);
+    };
+    // the genes of the list one after the other (search.cpp:124).  MEGAGTA_SEARCH_LANES=2 searches two genes side by side on one
+    // graph, each batch on its own context (stream + work memory) and half of the CUs (mgta_astar_batch_on): measured and NOT the
+    // default -- rplB + nirK at 2 M reads took 18 s side by side (9.5 s and 17.7 s on the device) against 15.9 s one after the other:
+    // a batch on half the CUs takes twice as long, the idle time of one gene's window is not there for the other to use.
+    const std::vector<GeneEntry> genes = read_gene_list(argv[2]);
+    int lanes = 1;
+    if (const char *e = getenv("MEGAGTA_SEARCH_LANES")) lanes = std::max(1, std::min(2, atoi(e)));
+    if (lanes == 1) {
+        for (const GeneEntry &gene : genes) run_gene(gene, ctx);
+    } else {
+        mgta_ctx *ctx2 = g_sess.active && g_sess.ctx2 ? g_sess.ctx2 : mgta_ctx_create(0);
+        if (!ctx2) die("%s", mgta_last_error());
+        if (g_sess.active) g_sess.ctx2 = ctx2;
+        mgta_ctx_set_search_share(ctx, 1, 2);
+        mgta_ctx_set_search_share(ctx2, 1, 2);
+        std::atomic<size_t> next{0};
+        auto lane = [&](mgta_ctx *c) {
+            for (size_t i; (i = next.fetch_add(1)) < genes.size();) run_gene(genes[i], c);
+        };
+        std::thread other(lane, ctx2);
+        lane(ctx);
+        other.join();
+        mgta_ctx_set_search_share(ctx, 1, 1);
+        mgta_ctx_set_search_share(ctx2, 1, 1);
+        if (!g_sess.active) mgta_ctx_destroy(ctx2);
     }
     mgta_sdbg_free(g);
     ctx_put(ctx);
@@ -547,6 +576,7 @@ static int main_serve() {
         if (f[0] == "release") {                                          // hand the device memory back (another process is going to need it)
             graph_drop();
             if (g_sess.ctx) mgta_ctx_release_scratch(g_sess.ctx);
+            if (g_sess.ctx2) mgta_ctx_release_scratch(g_sess.ctx2);
             fprintf(rep, "DONE 0\n");
             fflush(rep);
             continue;
@@ -583,6 +613,7 @@ static int main_serve() {
         fflush(rep);
     }
     graph_drop();
+    if (g_sess.ctx2) mgta_ctx_destroy(g_sess.ctx2);
     if (g_sess.ctx) mgta_ctx_destroy(g_sess.ctx);
     return 0;
 }

@@ -345,7 +345,6 @@ constexpr int kItemsPerThread = 4;
 constexpr int kSubTile = kSortThreads * kItemsPerThread;   // 4096 keys staged in LDS at a time
 constexpr int kSubTilesPerBlock = 8;
 constexpr int kBlockTile = kSubTile * kSubTilesPerBlock;   // 32768 keys per workgroup
-constexpr int kWaveChunk = kSubTile / kSortWaves;          // 512 consecutive keys per wave
 
 struct Digit {
     int pos;     // bit position counted from the least significant bit of the whole key
