@@ -462,8 +462,8 @@ static int main_findstart(int argc, char **argv) {
     mgta_reads *rd = nullptr;
     if (mgta_reads_upload(ctx, pr.words.data(), pr.words.size(), pr.start.data(), n_reads, &rd) != MGTA_OK) die("%s", mgta_last_error());
     // room for the hits: a call that finds more than fit only counts them and the scan runs again, so start generously (16 B per hit:
-    // one hit per 64 windows of the reads; round 1 started at 65536 and rescanned every library of more than a few thousand reads)
-    std::vector<mgta_seed_hit> hits(std::max<size_t>(1u << 16, (size_t)(pr.start.back() / 32)));
+    // sized for one hit per 200 bases, about twice what the synthetic sets give; round 1 started at 65536 and rescanned every library of more than a few thousand reads)
+    std::vector<mgta_seed_hit> hits(std::max<size_t>(1u << 16, (size_t)(pr.start.back() / 200)));
     int64_t n_hits = 0;
     double ms = 0;
     for (;;) {
