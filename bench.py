@@ -112,7 +112,7 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
     try:
         sets = {}
 
-        def run(n, tag, extra):
+        def run(n, tag, extra, env=None):
             if n not in sets:
                 mg = synth.make_metagenome_device(n, 150, gene_specs, seed=1000 + n % 997, device=device, host_sample=n)
                 d = os.path.join(tmp, f"set_{n}")
@@ -124,7 +124,7 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             od = os.path.join(tmp, "out_" + tag)
             t = time.time()
             r = subprocess.run([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env={**os.environ, **(env or {})})
             dt = time.time() - t
             if r.returncode != 0:
                 raise RuntimeError(f"megagta.py ({tag}) failed: {r.stderr[-800:]}")
@@ -134,7 +134,13 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
 
         dt, nc = run(n_ours, "ours", ["-t", str(min(cores, 16))])
         note(f"e2e ours: {n_ours} reads in {dt:.1f} s")
-        out["ours"] = {"reads": n_ours, "seconds": dt, "reads_per_s": n_ours / dt, "contigs": nc}
+        out["ours"] = {"reads": n_ours, "seconds": dt, "reads_per_s": n_ours / dt, "contigs": nc,
+                       "note": "default: shared term_nodes caches under the ordered-commit window (the same files on every run)"}
+        dtu, ncu = run(n_ours, "ours_unordered", ["-t", str(min(cores, 16))], env={"MEGAGTA_CACHE_WINDOW": "-1"})
+        note(f"e2e ours, unordered cache sharing: {n_ours} reads in {dtu:.1f} s")
+        out["ours_unordered_cache"] = {"reads": n_ours, "seconds": dtu, "reads_per_s": n_ours / dtu, "contigs": ncu,
+                                       "note": "MEGAGTA_CACHE_WINDOW=-1: every search sees whatever paths are in the cache when it looks, as the "
+                                               "reference's multi-thread `search` does; which of several equally scored paths a seed takes depends on timing"}
         if n_ref > 0 and os.path.exists(REF):
             best = None
             for threads in sorted({min(cores, 32), cores}):

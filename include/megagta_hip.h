@@ -249,6 +249,9 @@ typedef int (*mgta_contig_sink)(void *user, int64_t seed_index, const char *left
 int mgta_astar_batch(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
                      const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
                      int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);
+/* cache_mode -1 = shared caches WITHOUT any ordering: every search sees whatever paths have been inserted when it looks (what the
+ * reference's `search` with more than one thread does, search.cpp:182-189).  Least work and no waiting, but which of several equally
+ * good paths a seed takes depends on timing: not the default anywhere; MEGAGTA_CACHE_WINDOW=-1 selects it in `megagta search`. */
 /* The same batch run with the stream and the work memory of `run` (another context of the graph's device) instead of the graph's own:
  * two host threads can search two genes of one gene_list side by side on one graph (search.cpp:124 loops over the genes one after the
  * other).  mgta_ctx_set_search_share(run, 1, 2) on both contexts gives each batch half of the CUs.  Results do not depend on it.

@@ -121,7 +121,9 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                         int64_t n, int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user,
                         mgta_astar_stats *stats) {
     if (!ctx || !g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
-    if (cache_mode < 0) { set_error("cache_mode must be >= 0"); return MGTA_EINVAL; }
+    if (cache_mode < -1) { set_error("cache_mode must be >= -1"); return MGTA_EINVAL; }
+    const bool free_share = cache_mode == -1;          // shared caches without any ordering (timing-dependent results, like the reference's OMP run)
+    if (free_share) cache_mode = 1;
     if (ctx->device != g->ctx->device) { set_error("mgta_astar_batch_on: the context and the graph live on different devices"); return MGTA_EINVAL; }
     const int klen = g->dev.k + 1;
     if (klen > kMaxKmer) { set_error("k too large"); return MGTA_EINVAL; }
@@ -170,7 +172,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         // shared-cache batch of fewer than 32768 seeds is bounded by its chain of longest searches, and one search per wavefront (64 lanes: every iteration ~2.5x
         // shorter, 2048 in flight) finishes those sooner (7.5 k / 9.9 k seeds, window 4096: 2.1 / 3.8 s instead of 4.8 / 6.4 s;
         // 76 k / 103 k seeds: 16 lanes win).  MGTA_ASTAR_GROUP=16|64 overrides.
-        int G = (cache_mode > 0 && n < 32768) ? 64 : 16;   // (cold batches have no chain of searches waiting for each other: 16 lanes at any size)
+        int G = (cache_mode > 0 && !free_share && n < 32768) ? 64 : 16;   // (cold batches have no chain of searches waiting for each other: 16 lanes at any size)
         if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
@@ -211,7 +213,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         // that finds the neighbourhood of its slot full is dropped (a missed cache entry costs expansions, never correctness)
         DevBuf d_cache[2], d_run_seed, d_run_progress, d_start_limit;
         a.window = cache_mode;
-        a.cost_rate = cache_mode > 0 ? ctx->search_cost_rate : 0;
+        a.cost_rate = cache_mode > 0 && !free_share ? ctx->search_cost_rate : 0;
         a.cache_probe_limit = 256;
         if (cache_mode > 0) {
             for (int d = 0; d < 2; ++d) {
@@ -245,15 +247,16 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
             // pool = the slots' base arenas + what the searches grow into.  Mapping device memory costs ~27 ms/GB, so the pool follows the
-            // job: 1 MB per search of the batch, at least 2 GB, at most 8 MB per slot (64 GB) -- 24 MB per slot for batches of a million
+            // job: 2 MB per search of the batch, at least 4 GB, at most 8 MB per slot (64 GB) -- 24 MB per slot for batches of a million
             // searches and more, which run for minutes.  No new search starts while 70 % of it is in use, so a small pool costs searches
             // in flight, not failures; the re-run passes take everything that is free.
             const uint64_t n_search = (uint64_t)work * 2;
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
                            : n_search >= (1ull << 20) ? slots * (24ull << 20)
-                                                      : std::min<uint64_t>(slots * (8ull << 20), std::max<uint64_t>(2ull << 30, n_search << 20));
+                                                      : std::min<uint64_t>(slots * (8ull << 20), std::max<uint64_t>(4ull << 30, n_search << 21));
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
-            if (attempt > 0 && !ctx->astar_pool_bytes) dyn = avail;
+            if (attempt == 1 && !ctx->astar_pool_bytes) dyn = std::max<uint64_t>(dyn * 2, 16ull << 30);   // (the re-runs are few: no need to map
+            if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;                                       //  everything that is free at once)
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
             dyn &= ~((1ull << kUnitLog) - 1);
             const uint64_t pool_bytes = slots * slot_bytes + dyn;
@@ -287,7 +290,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
             a.pool.soft_limit = dyn / 2;
-            a.gate = cache_mode > 0 && attempt == 0;
+            a.gate = cache_mode > 0 && attempt == 0 && !free_share;
+            a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);

@@ -115,6 +115,8 @@ struct AstarArgs {
     // become visible to them any more, however soon it ends.
     int window;
     int cost_rate;
+    int free_share;               // 1 = every path is visible to every search from the moment it is inserted (the reference's multi-thread
+                                  // behaviour: fastest, but the result depends on timing); no gate
     int gate;                     // 1 = seeds start in order behind the commit frontier (the normal shared-cache launch);
                                   // 0 with window > 0 = a re-run of searches the pool could not hold: the caches are read with the
                                   // same visibility rule but nothing waits
@@ -852,7 +854,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             have_curr = false;
             if (wait_mem) {
                 have_curr = !first;
-                if (++starved > kStarveLimit) { status = 2; stop = true; }
+                // when every search in flight waits, nobody ends and nothing comes back: searches give up after DIFFERENT waits (2^8 ..
+                // 2^15 iterations, by a hash of the seed), so the impatient ones free their memory for the others within milliseconds
+                if (++starved > (kStarveLimit >> (mix64((uint64_t)sid + 0x9E3779B97F4A7C15ull) & 7))) { status = 2; stop = true; }
             } else {
                 starved = 0;
             }
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     const ANode par = load_node(node_at((uint32_t)nd.parent));
                     if (a.window > 0 && gl == 0)
                         cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
-                                     seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
+                                     a.free_share ? 0 : seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
                     nd = par;
                 }
                 if (gl == 0) {

@@ -259,7 +259,7 @@ static int main_search(int argc, char **argv) {
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
     // a gene with few seeds takes a window of half of them (at least 1024): with 7.5 k / 9.9 k seeds the default would share nothing
     // (measured: window 16384 = cold 6 s per gene, 4096 2.1 / 3.8 s, 1024 3.2 / 5.3 s, 256 7 / 11 s)
-    int cache_window = -1;
+    int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
     int cost_rate = -1;                             // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate
     if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
@@ -301,7 +301,7 @@ static int main_search(int argc, char **argv) {
         // with the plain window 16384 (6144 + 2: 4.6 s, 8192 + 4: 4.8 s, 16384 + 2: 5.4 s); 414 k seeds 14.4 s vs 18.8 s.  Genes with few
         // seeds: half of them, no cost term (7.5 k / 9.9 k seeds: 2.1 / 3.9 s; with the cost term 3.0 / 5.8 s).
         const bool big = kmers.size() >= 32768;
-        const int window = cache_window >= 0 ? cache_window : big ? 8192 : (int)std::min<size_t>(8192, std::max<size_t>(1024, kmers.size() / 2));
+        const int window = cache_window >= -1 ? cache_window : big ? 8192 : (int)std::min<size_t>(8192, std::max<size_t>(1024, kmers.size() / 2));
         if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (big ? 2 : 0)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
@@ -479,17 +479,28 @@ static int main_findstart(int argc, char **argv) {
         const uint64_t len = pr.start[r + 1] - pr.start[r], q = pr.start[r] + (len - 1 - fwd_pos);
         return (int)((pr.words[q >> 4] >> (30 - 2 * (q & 15))) & 3);
     };
-    std::map<std::string, int32_t> seeds;
+    struct SeedInfo { int32_t ref; int64_t contig; };                  // contig: the lowest-numbered contig of the previous k that holds the k-mer, -1 = reads only
+    std::map<std::string, SeedInfo> seeds;
     std::string nucl((size_t)k, 'A');
     for (const mgta_seed_hit &h : hits) {
         const uint32_t pos = h.pos_strand >> 1, len = (uint32_t)(pr.start[h.read + 1] - pr.start[h.read]);
         for (int j = 0; j < k; ++j)
             nucl[(size_t)j] = (h.pos_strand & 1) ? "TGCA"[base_at(h.read, len - 1 - (pos + (uint32_t)j))] : "ACGT"[base_at(h.read, pos + (uint32_t)j)];
-        seeds.emplace(nucl, h.ref);
+        const int64_t contig = h.read >= n_lib ? (int64_t)(h.read - n_lib) : -1;
+        auto it = seeds.emplace(nucl, SeedInfo{h.ref, contig}).first;
+        if (contig >= 0 && (it->second.contig < 0 || contig < it->second.contig)) it->second.contig = contig;
     }
     for (const auto &kv : seeds)
-        printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", kv.first.c_str(), 1, ref.prot[(size_t)kv.second].c_str(),
-               ref.model_pos[(size_t)kv.second]);
+        printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", kv.first.c_str(), 1, ref.prot[(size_t)kv.second.ref].c_str(),
+               ref.model_pos[(size_t)kv.second.ref]);
+    // side file for `search` (MEGAGTA_CLUSTER_FILE): one line per seed, in the order of the seed lines: the contig of the previous k that
+    // holds the k-mer (-1 = none).  Seeds of one contig lie on one stretch of one gene copy: see the chain mode of `megagta search`.
+    if (const char *cf = getenv("MEGAGTA_CLUSTER_FILE")) {
+        FILE *f = fopen(cf, "w");
+        if (!f) die("cannot write %s", cf);
+        for (const auto &kv : seeds) fprintf(f, "%lld\n", (long long)kv.second.contig);
+        fclose(f);
+    }
     mgta_reads_free(rd);
     lib_put(pr, mk);
     ctx_put(ctx);
