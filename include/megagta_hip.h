@@ -66,7 +66,8 @@ int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, u
  * later seed waits for the longest unfinished search.  > 0: a search that has already run r expansions cannot become visible to the
  * seeds below j + B + r / expansions_per_seed any more, so those start without waiting for it.  Either way the result is a function
  * of (seed order, B, expansions_per_seed) only, never of timing. */
-int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);
+int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);   /* < 0 (down to -64): seeds per expansion, i.e. the path is
+                                                                            * seen from seed j + B + c_j * |value| on */
 /* Work memory of the searches.  The reference's node pool, open list and hash maps grow without bound (pool_st.h:43,
  * hash_table_st.h:559-568); here every search slot owns a base arena of 1 << log2_base_nodes nodes (0 = default 12; 7..20) and a search
  * that outgrows it takes further chunks from a device-side pool of pool_bytes (0 = sized from the number of searches in flight), its

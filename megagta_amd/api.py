@@ -241,7 +241,8 @@ def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str
                  low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate: int = 0) -> tuple[list[SeedResult], dict]:
     """Batched HMM-guided A* (mgta_astar_batch).  start_states[i] = model position - 1 (search.cpp:157).
     cache_mode = B >= 1 shares paths between seeds: seed j's path (c_j expansions) is seen by the seeds >= j + B + c_j // cost_rate
-    (cost_rate 0: no cost term; B = 1 then is the reference's sequential run)."""
+    (cost_rate 0: no cost term; B = 1 then is the reference's sequential run; cost_rate < 0: j + B + c_j * |cost_rate|).
+    cache_mode = -1: no ordering at all (timing-dependent, the reference's multi-thread behaviour)."""
     ctx = graph.ctx
     check(ctx._L.mgta_ctx_set_search_cost_rate(ctx.h, int(cost_rate)), "mgta_ctx_set_search_cost_rate")
     klen = graph.k + 1

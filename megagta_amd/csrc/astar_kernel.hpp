@@ -477,6 +477,10 @@ __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64
     }
 }
 
+// the cost term of the sharing rule: c expansions delay a path's visibility by c / rate seeds (rate > 0) or c * |rate| seeds (rate < 0)
+__device__ __forceinline__ long long cost_term(int rate, unsigned long long c) {
+    return rate > 0 ? (long long)(c / (unsigned)rate) : rate < 0 ? (long long)(c * (unsigned)(-rate)) : 0ll;
+}
 // Highest seed that may start now: no unfinished search can still become visible to it (see AstarArgs::window).  Every lane of
 // the WAVE calls it and returns the same value; start_limit keeps the maximum ever computed (the bound only grows).  The table
 // reads are atomics performed at the coherence point, four in flight per lane.
@@ -497,13 +501,13 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
             js[u] = -1; pr[u] = 0;
             if (t < n_dir) {
                 js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a.cost_rate > 0) pr[u] = __hip_atomic_fetch_add(&a.run_progress[sl], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.cost_rate != 0) pr[u] = __hip_atomic_fetch_add(&a.run_progress[sl], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (js[u] >= 0) {
-                const long long b = js[u] + a.window - 1 + (a.cost_rate > 0 ? (long long)(pr[u] / (unsigned)a.cost_rate) : 0ll);
+                const long long b = js[u] + a.window - 1 + cost_term(a.cost_rate, pr[u]);
                 bound = b < bound ? b : bound;
             }
     }
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 if (!valid) od3 = 0;
                 n_expanded++;
-                if (a.gate && a.cost_rate > 0 && (n_expanded & 63) == 0 && gl == 0)
+                if (a.gate && a.cost_rate != 0 && (n_expanded & 63) == 0 && gl == 0)
                     __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
                 PROF(5)
@@ -1112,7 +1116,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     const ANode par = load_node(node_at((uint32_t)nd.parent));
                     if (a.window > 0 && gl == 0)
                         cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
-                                     a.free_share ? 0 : seed + a.window + (a.cost_rate > 0 ? n_expanded / a.cost_rate : 0), nd.em_state);
+                                     a.free_share ? 0 : seed + a.window + cost_term(a.cost_rate, n_expanded), nd.em_state);
                     nd = par;
                 }
                 if (gl == 0) {

@@ -56,7 +56,7 @@ int mgta_ctx_set_full_lsd(mgta_ctx *ctx, int on) {
 }
 
 int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
-    if (!ctx || expansions_per_seed < 0) return MGTA_EINVAL;
+    if (!ctx || expansions_per_seed < -64) return MGTA_EINVAL;
     ctx->search_cost_rate = expansions_per_seed;
     return MGTA_OK;
 }

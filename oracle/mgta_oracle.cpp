@@ -1543,7 +1543,7 @@ orc_searcher *orc_searcher_new(const orc_graph *g, const orc_hmm *fwd, const orc
 void orc_searcher_free(orc_searcher *s) { s->release(); delete s; }
 void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); s->pending.clear(); s->seed_counter = 0; }
 void orc_searcher_set_window(orc_searcher *s, int window) { s->window = window < 1 ? 1 : window; }
-void orc_searcher_set_cost_rate(orc_searcher *s, int rate) { s->cost_rate = rate < 0 ? 0 : rate; }
+void orc_searcher_set_cost_rate(orc_searcher *s, int rate) { s->cost_rate = rate; }   // < 0: the cost term is c * |rate| (see the header)
 
 int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, orc_astar_result *right, orc_astar_result *left,
                         char *contig, int64_t cap) {
@@ -1575,7 +1575,7 @@ int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, or
     for (auto &p : s->pending)
         if (p.visible_from < 0) {
             const int64_t c = p.dir == 0 ? o1.expanded : o2.expanded;
-            p.visible_from = p.seed + s->window + (s->cost_rate > 0 ? c / s->cost_rate : 0);
+            p.visible_from = p.seed + s->window + (s->cost_rate > 0 ? c / s->cost_rate : s->cost_rate < 0 ? c * (int64_t)(-s->cost_rate) : 0);
         }
     s->release();
     s->seed_counter++;

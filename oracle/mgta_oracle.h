@@ -110,7 +110,8 @@ void orc_searcher_free(orc_searcher *);
 void orc_searcher_clear_cache(orc_searcher *);                    /* drop the term_nodes caches (cold mode) */
 /* windowed sharing: seed j sees the paths found by seeds <= j - window; 1 = the reference's sequential run */
 void orc_searcher_set_window(orc_searcher *, int window);
-/* cost term of the sharing rule: the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j / rate; 0 = none */
+/* cost term of the sharing rule: the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j / rate; 0 = none;
+ * rate < 0: by the seeds >= j + window + c_j * |rate| */
 void orc_searcher_set_cost_rate(orc_searcher *, int rate);
 /* one seed = HMMGraphSearch::search [hmm_graph_search.h:60-81]; kmer is lower/upper-case ACGT of
  * length k+1; contig receives "<left><kmer><right>" (lower case).  Returns contig length or <0. */
