@@ -126,6 +126,11 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             r = subprocess.run([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env={**os.environ, **(env or {})})
             dt = time.time() - t
+            if os.environ.get("MEGAGTA_E2E_LOG_DIR"):                   # the driver's own log (per-step times), for profiles/
+                with open(os.path.join(os.environ["MEGAGTA_E2E_LOG_DIR"], f"e2e_{tag}.log"), "w") as f:
+                    f.write(r.stderr)
+                    if os.path.exists(os.path.join(od, "log")):
+                        f.write("\n==== <out>/log ====\n" + open(os.path.join(od, "log"), errors="replace").read())
             if r.returncode != 0:
                 raise RuntimeError(f"megagta.py ({tag}) failed: {r.stderr[-800:]}")
             n_contigs = {g: sum(1 for l in open(os.path.join(od, "contigs", g, "nucl_merged.fasta")) if l.startswith(">")) for g in names}
@@ -425,6 +430,9 @@ def main():
             torch.cuda.empty_cache()
             if args.e2e_reads > 0:
                 try:
+                    # the driver clears the ~250 GB this process has just released before it hands them to the next process: the first
+                    # allocations of the leg's child processes waited 5 s for that (profiles/r02/vmm_probe.log: 20-90 ms/GB)
+                    time.sleep(8 if args.reads > 20_000_000 else 1)
                     note("e2e leg ...")
                     out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}")
                     note("e2e leg done")

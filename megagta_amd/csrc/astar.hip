@@ -246,17 +246,21 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
-            // pool = the slots' base arenas + what the searches grow into.  Mapping device memory costs ~27 ms/GB, so the pool follows the
-            // job: 2 MB per search of the batch, at least 4 GB, at most 8 MB per slot (64 GB) -- 24 MB per slot for batches of a million
-            // searches and more, which run for minutes.  No new search starts while 70 % of it is in use, so a small pool costs searches
-            // in flight, not failures; the re-run passes take everything that is free.
+            // pool = the slots' base arenas + what the searches grow into.  Device memory beyond the first ~24 GB of a process costs
+            // 20-90 ms/GB to obtain (profiles/r02/vmm_probe.log), so the pool follows the job: at least 4 GB; 24 MB per search in
+            // flight (196 GB for a full grid) for independent searches -- at 100 M reads they average 29 k expansions
+            // and hold 62 GB together -- and 8 MB per slot (64 GB) where the searches share their paths and most end after a few
+            // hundred; 24 MB again for batches of a million searches and more, which run for minutes.  No new search starts while half
+            // of it is in use, so a small pool costs searches in flight, not failures.
             const uint64_t n_search = (uint64_t)work * 2;
+            const uint64_t per_slot = (cache_mode == 0 || n_search >= (1ull << 20)) ? (24ull << 20) : (8ull << 20);
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
-                           : n_search >= (1ull << 20) ? slots * (24ull << 20)
-                                                      : std::min<uint64_t>(slots * (8ull << 20), std::max<uint64_t>(4ull << 30, n_search << 21));
+                                                 : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
-            if (attempt == 1 && !ctx->astar_pool_bytes) dyn = std::max<uint64_t>(dyn * 2, 16ull << 30);   // (the re-runs are few: no need to map
-            if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;                                       //  everything that is free at once)
+            // the first re-run has the pool of the first pass to itself with a fraction of the searches; only the later ones ask for
+            // everything that is free (obtaining 200 GB takes seconds)
+            if (attempt == 1 && !ctx->astar_pool_bytes && ar.pool.bytes > slots * slot_bytes) dyn = std::max<uint64_t>(dyn, ar.pool.bytes - slots * slot_bytes);
+            if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
             dyn &= ~((1ull << kUnitLog) - 1);
             const uint64_t pool_bytes = slots * slot_bytes + dyn;
@@ -327,6 +331,10 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 todo[d].swap(again);
             }
             ST.n_retries += (int64_t)(todo[0].size() + todo[1].size());
+            if (getenv("MGTA_ASTAR_VERBOSE"))
+                fprintf(stderr, "[astar] pass %d: %lld workgroups, pool %.1f GB, handed out once %.1f GB, most in use %.1f GB, %llu chunks reused, "
+                        "%llu requests refused, %.0f ms, %zu searches to run again\n", attempt, (long long)blocks, pool_bytes / 1e9, h_pool[0] / 1e9,
+                        (slots * slot_bytes + h_pool[6]) / 1e9, h_pool[1], h_pool[2], ms, todo[0].size() + todo[1].size());
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         }
         if (!todo[0].empty() || !todo[1].empty()) {

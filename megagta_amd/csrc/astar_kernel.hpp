@@ -179,24 +179,31 @@ __device__ __forceinline__ void st_agent(unsigned int *p, unsigned int v) {
 // at a time runs the whole lock / unlock sequence): two lanes of a wave must never compete for a lock, because a lane that has left
 // a spin loop waits at the reconvergence point for the lanes still in it -- with the lock in its hands (and the compiler is free to
 // move a critical section behind the loop that guards it).  A single spinning lane only ever waits for OTHER waves, which run on.
-__device__ __forceinline__ uint32_t pool_alloc_one(const PoolDev &P, int c) {
+// A chunk is named by its first 4 KB unit (28 bits: pools up to 1 TB); bits 28-29 say how many classes LARGER than asked for the
+// chunk really is (it goes back to the list it came from).
+constexpr uint32_t kUnitMask = 0x0FFFFFFFu;
+constexpr int kBorrowShift = 28;
+__device__ __forceinline__ uint32_t pool_pop(const PoolDev &P, int c) {
     uint32_t res = kNoChunk;
-    if (ld_agent(&P.cnt[c]) != 0u) {
-        for (int spins = 0; spins < (1 << 20); ++spins) {
-            unsigned int expect = 0u;
-            if (__hip_atomic_compare_exchange_strong(&P.lock[c], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                const unsigned int n = ld_agent(&P.cnt[c]);
-                if (n > 0u) {
-                    res = ld_agent(&P.stack[P.meta[c] + n - 1u]);
-                    st_agent(&P.cnt[c], n - 1u);
-                }
-                st_agent(&P.lock[c], 0u);
-                break;
+    if (ld_agent(&P.cnt[c]) == 0u) return res;
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+        unsigned int expect = 0u;
+        if (__hip_atomic_compare_exchange_strong(&P.lock[c], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const unsigned int n = ld_agent(&P.cnt[c]);
+            if (n > 0u) {
+                res = ld_agent(&P.stack[P.meta[c] + n - 1u]);
+                st_agent(&P.cnt[c], n - 1u);
             }
-            __builtin_amdgcn_s_sleep(4);                              // (bounded: fall through to the bump pointer)
+            st_agent(&P.lock[c], 0u);
+            break;
         }
-        if (res != kNoChunk) __hip_atomic_fetch_add(&P.stat[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(4);                                  // (bounded: fall through to the bump pointer)
     }
+    return res;
+}
+__device__ __forceinline__ uint32_t pool_alloc_one(const PoolDev &P, int c) {
+    uint32_t res = pool_pop(P, c);
+    if (res != kNoChunk) __hip_atomic_fetch_add(&P.stat[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (res == kNoChunk) {
         const unsigned long long size = 1ull << (c + kUnitLog);
         unsigned long long old = ld_agent(P.bump);
@@ -206,8 +213,14 @@ __device__ __forceinline__ uint32_t pool_alloc_one(const PoolDev &P, int c) {
                 break;
             }
         }
-        if (res == kNoChunk) __hip_atomic_fetch_add(&P.stat[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The bump pointer never comes back and the lists are per size: late in a batch the memory that is free sits in the lists of
+    // OTHER sizes.  Take a free chunk of the next two sizes up as it is (nothing is split: it returns to its own list).
+    for (int e = 1; e <= 2 && res == kNoChunk && c + e < kNumClasses; ++e) {
+        res = pool_pop(P, c + e);
+        if (res != kNoChunk) res |= (uint32_t)e << kBorrowShift;
+    }
+    if (res == kNoChunk) __hip_atomic_fetch_add(&P.stat[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return res;
 }
 __device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
@@ -221,12 +234,15 @@ __device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
     }
     // a chunk another CU may have used: drop whatever this CU's L1 still holds of it (once per chunk, not per poll)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (res != kNoChunk) __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // bytes in use
+    if (res != kNoChunk)                                                  // bytes in use
+        __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + (int)(res >> kBorrowShift) + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return res;
 }
 // The caller has issued pool_release_fence() since its last store into the chunk.
 __device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit) {
     const int lane = lane_id();
+    c += (int)(unit >> kBorrowShift);                                 // a borrowed chunk goes back to its own list
+    unit &= kUnitMask;
     __hip_atomic_fetch_sub(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t turn = __ballot(true);
     while (turn) {
@@ -268,7 +284,7 @@ struct Grow {
         const uint32_t hi = i >> log_b0;
         const int level = hi ? 32 - __builtin_clz(hi) : 0;
         const uint32_t off = level ? i - (1u << (log_b0 + level - 1)) : i;
-        return pool + ((uint64_t)seg[level] << kUnitLog) + ((uint64_t)off << ELEM_LOG);
+        return pool + ((uint64_t)(seg[level] & kUnitMask) << kUnitLog) + ((uint64_t)off << ELEM_LOG);
     }
     __device__ __forceinline__ int chunk_class(int level) const { return ELEM_LOG + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
 };
@@ -597,6 +613,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     HashEnt *hash = base_hash;
     uint32_t hmask = 2 * B0 - 1;
     int hclass = base_hclass;
+    uint32_t hunit = 0;                                               // chunk of the current table once it has left the base arena
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     unit = GX::bcast(unit, 0, gbase);
                 }
                 if (unit == kNoChunk) { wait_mem = true; break; }
-                HashEnt *nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)unit << kUnitLog));
+                HashEnt *nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(unit & kUnitMask) << kUnitLog));
                 const uint32_t nmask = hmask * 2 + 1;
                 for (uint64_t i = (uint64_t)gl; i <= nmask; i += G) hash_put(nt, (uint32_t)i, 0ull, 0u);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -849,18 +866,21 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new table was filled behind this CU's L1
                 if (hclass > base_hclass) {
                     pool_release_fence();
-                    if (gl == 0) pool_free(a.pool, hclass, (uint32_t)((reinterpret_cast<char *>(hash) - a.pool.base) >> kUnitLog));
+                    if (gl == 0) pool_free(a.pool, hclass, hunit);
                 }
                 if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hash = nt; hmask = nmask; ++hclass;
+                hash = nt; hmask = nmask; ++hclass; hunit = unit;
             }
 
             have_curr = false;
             if (wait_mem) {
                 have_curr = !first;
-                // when every search in flight waits, nobody ends and nothing comes back: searches give up after DIFFERENT waits (2^8 ..
-                // 2^15 iterations, by a hash of the seed), so the impatient ones free their memory for the others within milliseconds
-                if (++starved > (kStarveLimit >> (mix64((uint64_t)sid + 0x9E3779B97F4A7C15ull) & 7))) { status = 2; stop = true; }
+                // when every search in flight waits, nobody ends and nothing comes back: a search gives up after a wait in proportion
+                // to the work it would lose (a quarter of its expansions so far in iterations, 2^8 .. 2^17), so the young ones free
+                // their memory for the others within milliseconds and the ones that have run for seconds wait for seconds
+                uint32_t patience = n_expanded >> 2;
+                patience = patience < 256u ? 256u : patience > (kStarveLimit << 2) ? (kStarveLimit << 2) : patience;
+                if (++starved > patience) { status = 2; stop = true; }
             } else {
                 starved = 0;
             }
@@ -1135,7 +1155,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (gl == 0) {
                     for (int l = 1; l < n_levels; ++l) pool_free(a.pool, AR.chunk_class(l), seg[l]);
                     for (int l = 1; l < h_levels; ++l) pool_free(a.pool, H.ar.chunk_class(l), hseg[l]);
-                    if (hclass > base_hclass) pool_free(a.pool, hclass, (uint32_t)((reinterpret_cast<char *>(hash) - a.pool.base) >> kUnitLog));
+                    if (hclass > base_hclass) pool_free(a.pool, hclass, hunit);
                 }
             }
             n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
