@@ -212,12 +212,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # rehearsal of the N > 1 path on a one-GPU box: MEGAGTA_DIST_BACKEND=gloo MEGAGTA_DEVICE=0 (RCCL refuses two ranks per device)
+    backend = os.environ.get("MEGAGTA_DIST_BACKEND", "nccl")
+    if "MEGAGTA_DEVICE" in os.environ:
+        local_rank = int(os.environ["MEGAGTA_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from megagta_amd import api, synth
     from megagta_amd import dist as mdist
@@ -259,6 +266,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1:
+        ctx.keep_stream(True)                               # a shard that takes several memory-bound passes is handed over whole
     for _ in range(args.warmup):
         step()
     fence()

@@ -44,10 +44,11 @@ mgta_ctx *mgta_ctx_create(int device_id);            /* NULL on failure (see mgt
 void mgta_ctx_destroy(mgta_ctx *);
 /* memory the build may use on the device; 0 = 90 % of what is free (cf. --host_mem/--mem_flag, build_graph.cpp:40-47) */
 int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
-/* on: a whole-range build (every bucket) also leaves its WHOLE edge stream on the device when memory forces it into several bucket-range
- * passes (each pass is appended to a stream buffer), so that mgta_sdbg_load_resident can hand the graph to `denovo` / `search` without
- * the disk or host round trip of `<prefix>.sdbg.*` (succinct_dbg.cpp:595-723) at any input size.  off (default): only a single-pass
- * build can be handed over.  Turning it off frees the buffer. */
+/* on: a build also leaves the WHOLE edge stream of its bucket range on the device when memory forces it into several bucket-range
+ * passes (each pass is appended to a stream buffer), so that mgta_sdbg_load_resident can hand the graph of a whole-range build to
+ * `denovo` / `search` without the disk or host round trip of `<prefix>.sdbg.*` (succinct_dbg.cpp:595-723) at any input size, and
+ * mgta_sdbg_export_records_device hands a rank's shard (a bucket sub-range) to the all-gather in one piece.  off (default): only the
+ * last pass stays.  Turning it off frees the buffer. */
 int mgta_ctx_keep_stream(mgta_ctx *, int on);
 /* frees the grow-only work memory the context keeps between calls (build pool, search pool); a stream left in the build pool by a
  * single-pass build is dropped with it (one kept by mgta_ctx_keep_stream stays) */

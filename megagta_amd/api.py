@@ -129,7 +129,8 @@ class Context:
 
 
 def export_records_to_torch(ctx: "Context"):
-    """records of the last build pass as a torch uint8 CUDA tensor (device -> device copy, no host round trip)"""
+    """records the last build left on the device (its last pass; every pass with Context.keep_stream) as a torch uint8 CUDA tensor:
+    device -> device copy, no host round trip"""
     import torch
     n = C.c_uint64()
     check(ctx._L.mgta_sdbg_export_records_device(ctx.h, None, 0, C.byref(n)), "mgta_sdbg_export_records_device")

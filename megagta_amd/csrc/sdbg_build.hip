@@ -1836,7 +1836,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     uint64_t budget = ctx->mem_limit ? std::min<uint64_t>(ctx->mem_limit, avail) : (uint64_t)(avail * 0.9);
 
     // whole-stream hand-off of a multi-pass build (mgta_ctx_keep_stream)
-    const bool acc = ctx->keep_stream && bucket_begin == 0 && bucket_end == (uint32_t)MGTA_NUM_BUCKETS;
+    const bool acc = ctx->keep_stream != 0;           // (of a bucket sub-range too: the shard a rank hands to the all-gather)
+    const double range_frac = (double)(bucket_end - bucket_begin) / (double)MGTA_NUM_BUCKETS;
     ctx->acc_valid = false;
     ctx->acc_n_rec = 0; ctx->acc_n_tips = 0;
     if (acc) ctx->acc_items.assign(MGTA_NUM_BUCKETS, 0);
@@ -1932,7 +1933,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
         if (acc) {     // room for the stream the passes leave behind: ~0.6 edges of 2 bytes per (k+1)-mer, tips, slack
-            const uint64_t est = (uint64_t)S.n_kmers * 3 / 2 + (64ull << 20);
+            const uint64_t est = (uint64_t)((double)S.n_kmers * 1.5 * range_frac) + (64ull << 20);
             const uint64_t have = ctx->acc_rec.bytes + ctx->acc_tips.bytes;
             other += est > have ? est - have : 0;
         }
@@ -2046,7 +2047,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                 // append this pass to the whole-stream buffers (device to device); capacity from the share of the buckets done so far
                 auto ensure = [&](DevBuf &buf, uint64_t used, uint64_t add) {
                     if (used + add <= buf.bytes) return;
-                    const double done = (double)(b_hi) / (double)MGTA_NUM_BUCKETS;
+                    const double done = (double)(b_hi - bucket_begin) / (double)(bucket_end - bucket_begin);
                     uint64_t want = (uint64_t)((double)(used + add) / std::max(done, 1e-3) * 1.1) + (1u << 20);
                     want = std::max<uint64_t>(want, used + add);
                     DevBuf bigger;
@@ -2106,7 +2107,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         b_lo = b_hi;
     }
     if (acc) {
-        ctx->last_rec = ctx->acc_rec.p; ctx->last_n_rec = ctx->acc_n_rec; ctx->last_bucket_lo = 0; ctx->last_bucket_hi = (uint32_t)MGTA_NUM_BUCKETS;
+        ctx->last_rec = ctx->acc_rec.p; ctx->last_n_rec = ctx->acc_n_rec; ctx->last_bucket_lo = bucket_begin; ctx->last_bucket_hi = bucket_end;
         ctx->last_tips = ctx->acc_tips.p; ctx->last_n_tips = ctx->acc_n_tips; ctx->last_first = nullptr; ctx->last_k = k;
         ctx->last_words_per_tip = words_per_tip;
         ctx->acc_valid = true;

@@ -148,6 +148,29 @@ def test_graph_from_resident_stream_of_a_multi_pass_build(ctx, golden_dir):
         assert d == q["od"] and o[:max(d, 0)] == q["out"]
 
 
+def test_shard_of_a_multi_pass_build_stays_whole_on_the_device(ctx, golden_dir):
+    """the shard a rank hands to the all-gather is the edge stream of ITS bucket range -- of every pass when memory forces
+    several: with mgta_ctx_keep_stream the records exported device to device equal the ones the sink collected for that range"""
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "toy", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    lo, hi = api.NUM_BUCKETS // 3, api.NUM_BUCKETS
+    try:
+        ctx.set_mem_limit(12 << 20)
+        want = ctx.build_sdbg(rd, 44, bucket_range=(lo, hi))
+        assert want.stats["n_passes"] >= 2
+        ctx.keep_stream(True)
+        st = ctx.build_sdbg(rd, 44, collect=False, bucket_range=(lo, hi)).stats
+        assert st["n_passes"] >= 2
+        got = api.export_records_to_torch(ctx).cpu().numpy().view(np.uint16)
+        with pytest.raises(api.MegaGtaError):              # a sub-range is not a graph
+            api.Graph(ctx, None, 44)
+    finally:
+        ctx.set_mem_limit(0)
+        ctx.keep_stream(False)
+    assert got.size == want.records.size and np.array_equal(got, want.records)
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_fuzz_navigation_vs_oracle(ctx, oracle, seed):
     """random small graphs (any k, tips, $ edges, hot k-mers): OutgoingEdges of every edge and IndexBinarySearchEdge of present and absent
