@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kMaxBranches = 16;      // kMaxBranchesPerGroup, assembly_algorithms.cpp:248
 constexpr uint32_t kBubbleWindowMax = 1u << 18;
-constexpr int kReachHash = 4096, kReachMax = 2048, kReachFrontier = 512;   // per-candidate reach search: hash slots, edges, edges per level
+constexpr int kReachHash = 32768, kReachMax = 16384, kReachFrontier = 2048;   // per-candidate reach search: hash slots, edges, edges per level
 constexpr int kMaxK = 255;
 
 struct Dn {
@@ -353,55 +353,79 @@ __global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64
 // Every edge a search from `begin` can read or write in ANY graph that has a subset of today's valid edges: the edges within max_len
 // forward steps and the valid edges into them.  Stamped with `key`; false when the region does not fit the scratch (the caller then
 // holds back every higher candidate of the round).
+// One WAVE per candidate: the lanes take the edges of a level side by side (a region of thousands of edges in a repeat would
+// otherwise keep one lane busy for milliseconds while the round waits for it).  Which edges end up stamped, and whether the region
+// fits, depends on the region alone (counts per level and in all), not on the order the lanes find them in.
 __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, unsigned long long *owner, unsigned long long key,
-                                   unsigned long long round, int reach_max) {
+                                   unsigned long long round, int reach_max, int *s_cnt /* LDS: [0] edges of the next level, [1] edges seen, [2] overflow */) {
     if (!g_valid(g, begin)) return true;
-    int64_t *hash = scratch, *cur = scratch + kReachHash, *nxt = cur + kReachFrontier;
+    const int lane = threadIdx.x;
+    unsigned long long *hash = reinterpret_cast<unsigned long long *>(scratch);
+    int64_t *cur = scratch + kReachHash, *nxt = cur + kReachFrontier;
     // hash entries carry the round in their top 24 bits: whatever an earlier round or a search left in the scratch reads as empty
     // (edge ids stay below 2^40), so nothing is cleared
-    const int64_t tag = (int64_t)((round & 0x3FFFFFull) + 1) << 40;
-    auto insert = [&](int64_t e) -> bool {           // true = new
-        uint32_t h = (uint32_t)(((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 52) & (kReachHash - 1);
+    const unsigned long long tag = ((round & 0x3FFFFFull) + 1) << 40;
+    auto insert = [&](int64_t e) -> bool {           // true = new; slots are claimed at the L2 (other lanes insert at the same time)
+        uint32_t h = (uint32_t)(((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 49) & (kReachHash - 1);
+        const unsigned long long mine = tag | (unsigned long long)e;
         for (;;) {
-            const int64_t v = hash[h];
-            if (v == (tag | e)) return false;
-            if ((v & ~0xFFFFFFFFFFll) != tag) { hash[h] = tag | e; return true; }
+            unsigned long long v = __hip_atomic_load(&hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == mine) return false;
+            if ((v & ~0xFFFFFFFFFFull) != tag) {
+                if (__hip_atomic_compare_exchange_strong(&hash[h], &v, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+                if (v == mine) return false;
+                continue;                            // another lane took the slot for another edge: look at it again
+            }
             h = (h + 1) & (kReachHash - 1);
         }
     };
-    int n_seen = 1, n_cur = 1;
-    insert(begin);
-    cur[0] = begin;
-    atomicMax(&owner[begin], key);
+    if (lane == 0) {
+        s_cnt[0] = 0; s_cnt[1] = 1; s_cnt[2] = 0;
+        insert(begin);
+        __hip_atomic_store(&cur[0], begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(&owner[begin], key);
+    }
+    __syncthreads();
+    int n_cur = 1;
     for (int level = 0; level < max_len && n_cur > 0; ++level) {
-        int n_nxt = 0;
-        for (int i = 0; i < n_cur; ++i) {
-            int64_t out[8];
-            const int od = d_outgoing(g, cur[i], out);
-            for (int x = 0; x < od; ++x) {
-                if (!insert(out[x])) continue;
-                if (++n_seen > reach_max || n_nxt >= kReachFrontier) return false;
-                nxt[n_nxt++] = out[x];
-                atomicMax(&owner[out[x]], key);
-                int64_t in[8];
-                const int id = d_incoming(g, out[x], in);
-                for (int y = 0; y < id; ++y) atomicMax(&owner[in[y]], key);
+        for (int i0 = 0; i0 < n_cur; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < n_cur) {
+                int64_t out[8];
+                const int od = d_outgoing(g, __hip_atomic_load(&cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), out);
+                for (int x = 0; x < od; ++x) {
+                    if (!insert(out[x])) continue;
+                    const int seen = atomicAdd(&s_cnt[1], 1) + 1, at = atomicAdd(&s_cnt[0], 1);
+                    if (seen > reach_max || at >= kReachFrontier) { s_cnt[2] = 1; continue; }
+                    __hip_atomic_store(&nxt[at], out[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicMax(&owner[out[x]], key);
+                    int64_t in[8];
+                    const int id = d_incoming(g, out[x], in);
+                    for (int y = 0; y < id; ++y) atomicMax(&owner[in[y]], key);
+                }
             }
         }
+        __syncthreads();
+        if (s_cnt[2]) return false;
+        n_cur = s_cnt[0];
+        __syncthreads();
+        if (lane == 0) s_cnt[0] = 0;
+        __syncthreads();
         int64_t *t = cur; cur = nxt; nxt = t;
-        n_cur = n_nxt;
     }
     return true;
 }
 
 __global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
                                                           unsigned long long *owner, unsigned long long round, int reach_max, uint32_t *barrier) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    __shared__ int s_cnt[4];
+    const uint32_t i = blockIdx.x;                                     // one wave per candidate
     if (i >= n) return;
     const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
-    if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max)) return;
+    if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt)) return;
     // the region does not fit: nobody above may commit this round (what this one can reach is not known), and it stamps at least what
     // its search reads today, so that it can still commit itself once nothing below reaches that
+    if (threadIdx.x != 0) return;
     atomicMin(barrier, i);
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkStamp s{owner, key};
@@ -689,7 +713,7 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         const int64_t *c = b.win[cur].as<int64_t>();
         const uint32_t init[2] = {0xFFFFFFFFu, 0u};
         MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 8, hipMemcpyHostToDevice, w.st));
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
                            b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.reach_max, barrier);
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
                            b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.ok.as<uint32_t>());
@@ -714,7 +738,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     DevBuf branching, found, cand, flag, again, counter;
     uint64_t nb = edges_where(w, PredBranching{}, branching);
     b.per = std::max<size_t>((size_t)kMaxBranches * max_len, (size_t)kReachHash + 2 * kReachFrontier);
-    b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, (6ull << 30) / (b.per * 8)));
+    b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, (8ull << 30) / (b.per * 8)));
     // test knobs: tiny windows exercise the carry of pending candidates, a tiny reach limit the hold-back of a region that does not fit
     if (const char *e = getenv("MGTA_DENOVO_WINDOW")) b.window = (uint32_t)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));
