@@ -479,28 +479,56 @@ static int main_findstart(int argc, char **argv) {
         const uint64_t len = pr.start[r + 1] - pr.start[r], q = pr.start[r] + (len - 1 - fwd_pos);
         return (int)((pr.words[q >> 4] >> (30 - 2 * (q & 15))) & 3);
     };
-    struct SeedInfo { int32_t ref; int64_t contig; };                  // contig: the lowest-numbered contig of the previous k that holds the k-mer, -1 = reads only
-    std::map<std::string, SeedInfo> seeds;
-    std::string nucl((size_t)k, 'A');
-    for (const mgta_seed_hit &h : hits) {
+    // a hit as its k-mer packed two bits per base, first base in the top bits (k <= 72: three words): sorting the packed words IS the
+    // lexicographic order of the strings, and equal k-mers end up side by side (a std::map of strings took 5 s for 7 M hits)
+    struct Seed { uint64_t w[3]; int32_t ref; int64_t contig; };      // contig: the lowest-numbered contig of the previous k that holds the k-mer, -1 = reads only
+    std::vector<Seed> seeds(hits.size());
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)hits.size(); ++i) {
+        const mgta_seed_hit &h = hits[(size_t)i];
         const uint32_t pos = h.pos_strand >> 1, len = (uint32_t)(pr.start[h.read + 1] - pr.start[h.read]);
-        for (int j = 0; j < k; ++j)
-            nucl[(size_t)j] = (h.pos_strand & 1) ? "TGCA"[base_at(h.read, len - 1 - (pos + (uint32_t)j))] : "ACGT"[base_at(h.read, pos + (uint32_t)j)];
-        const int64_t contig = h.read >= n_lib ? (int64_t)(h.read - n_lib) : -1;
-        auto it = seeds.emplace(nucl, SeedInfo{h.ref, contig}).first;
-        if (contig >= 0 && (it->second.contig < 0 || contig < it->second.contig)) it->second.contig = contig;
+        Seed sd{{0, 0, 0}, h.ref, h.read >= n_lib ? (int64_t)(h.read - n_lib) : -1};
+        for (int j = 0; j < k; ++j) {
+            const int b = (h.pos_strand & 1) ? 3 - base_at(h.read, len - 1 - (pos + (uint32_t)j)) : base_at(h.read, pos + (uint32_t)j);
+            sd.w[j >> 5] |= (uint64_t)b << (62 - 2 * (j & 31));
+        }
+        seeds[(size_t)i] = sd;
     }
-    for (const auto &kv : seeds)
-        printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", kv.first.c_str(), 1, ref.prot[(size_t)kv.second.ref].c_str(),
-               ref.model_pos[(size_t)kv.second.ref]);
+    // of equal k-mers: the reference position of the first hit in scan order (what the map kept), the lowest contig
+    std::vector<uint32_t> order(seeds.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+    if (seeds.size() >= (1ull << 32)) die("findstart: too many hits (%zu)", seeds.size());
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const Seed &x = seeds[a], &y = seeds[b];
+        if (x.w[0] != y.w[0]) return x.w[0] < y.w[0];
+        if (x.w[1] != y.w[1]) return x.w[1] < y.w[1];
+        if (x.w[2] != y.w[2]) return x.w[2] < y.w[2];
+        return a < b;
+    });
+    FILE *cf_out = nullptr;
     // side file for `search` (MEGAGTA_CLUSTER_FILE): one line per seed, in the order of the seed lines: the contig of the previous k that
     // holds the k-mer (-1 = none).  Seeds of one contig lie on one stretch of one gene copy: see the chain mode of `megagta search`.
     if (const char *cf = getenv("MEGAGTA_CLUSTER_FILE")) {
-        FILE *f = fopen(cf, "w");
-        if (!f) die("cannot write %s", cf);
-        for (const auto &kv : seeds) fprintf(f, "%lld\n", (long long)kv.second.contig);
-        fclose(f);
+        cf_out = fopen(cf, "w");
+        if (!cf_out) die("cannot write %s", cf);
     }
+    std::string nucl((size_t)k, 'A');
+    for (size_t i = 0; i < order.size();) {
+        const Seed &first = seeds[order[i]];
+        int64_t contig = first.contig;
+        size_t j = i + 1;
+        for (; j < order.size(); ++j) {
+            const Seed &o = seeds[order[j]];
+            if (o.w[0] != first.w[0] || o.w[1] != first.w[1] || o.w[2] != first.w[2]) break;
+            if (o.contig >= 0 && (contig < 0 || o.contig < contig)) contig = o.contig;
+        }
+        for (int q = 0; q < k; ++q) nucl[(size_t)q] = "ACGT"[(first.w[q >> 5] >> (62 - 2 * (q & 31))) & 3];
+        printf("dump_gene_name\tdump_seq_name\tdump\t%s\ttrue\t%d\t%s\t%d\n", nucl.c_str(), 1, ref.prot[(size_t)first.ref].c_str(),
+               ref.model_pos[(size_t)first.ref]);
+        if (cf_out) fprintf(cf_out, "%lld\n", (long long)contig);
+        i = j;
+    }
+    if (cf_out) fclose(cf_out);
     mgta_reads_free(rd);
     lib_put(pr, mk);
     ctx_put(ctx);
