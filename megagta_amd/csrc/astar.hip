@@ -168,11 +168,11 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         MGTA_HIP_CHECK(hipMemcpyAsync(d_exit.p, exit_prob.data(), 3000 * 8, hipMemcpyHostToDevice, st));
         MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
 
-        // lanes per search: 16 (four searches per wavefront: 8192 in flight, the throughput shape) when the batch can fill them; a
-        // shared-cache batch of fewer than 32768 seeds is bounded by its chain of longest searches, and one search per wavefront (64 lanes: every iteration ~2.5x
-        // shorter, 2048 in flight) finishes those sooner (7.5 k / 9.9 k seeds, window 4096: 2.1 / 3.8 s instead of 4.8 / 6.4 s;
-        // 76 k / 103 k seeds: 16 lanes win).  MGTA_ASTAR_GROUP=16|64 overrides.
-        int G = (cache_mode > 0 && !free_share && n < 32768) ? 64 : 16;   // (cold batches have no chain of searches waiting for each other: 16 lanes at any size)
+        // lanes per search: 16 (four searches per wavefront, 8192 in flight).  One search per wavefront (64 lanes: an iteration is ~2.5x
+        // shorter, 2048 in flight) was the choice for shared-cache batches below 32768 seeds while their window was thousands of seeds
+        // wide; with the small windows + cost term `megagta search` uses now 16 lanes win at every size measured (7.4 k / 9.7 k seeds:
+        // 2.0 / 3.0 s vs 2.6 / 4.6 s; 18 k / 24 k: 3.0 / 3.9 s vs 5.0 / 10.0 s, profiles/r02/e2e_window_sweep.log).  MGTA_ASTAR_GROUP=16|32|64 overrides.
+        int G = 16;
         if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup

@@ -257,8 +257,6 @@ static int main_search(int argc, char **argv) {
     double pen = atof(argv[6]);
     // argv[7] (num_threads) is accepted and ignored: the batch runs on the device.  The shared term_nodes cache (search.cpp:182)
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
-    // a gene with few seeds takes a window of half of them (at least 1024): with 7.5 k / 9.9 k seeds the default would share nothing
-    // (measured: window 16384 = cold 6 s per gene, 4096 2.1 / 3.8 s, 1024 3.2 / 5.3 s, 256 7 / 11 s)
     int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
     int cost_rate = -1;                             // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate
@@ -296,13 +294,17 @@ static int main_search(int argc, char **argv) {
         }
         FastaOut fo{out, &gene.name, &kmers};
         mgta_astar_stats st;
-        // genes with many seeds: window 8192 with a cost term of 2 expansions per seed (a search that has run r expansions no longer holds
-        // back the seeds below j + B + r / 2: the window slides past the long searches).  Measured (one gene): 82 k seeds 4.7 s vs 5.5 s
-        // with the plain window 16384 (6144 + 2: 4.6 s, 8192 + 4: 4.8 s, 16384 + 2: 5.4 s); 414 k seeds 14.4 s vs 18.8 s.  Genes with few
-        // seeds: half of them, no cost term (7.5 k / 9.9 k seeds: 2.1 / 3.9 s; with the cost term 3.0 / 5.8 s).
-        const bool big = kmers.size() >= 32768;
-        const int window = cache_window >= -1 ? cache_window : big ? 8192 : (int)std::min<size_t>(8192, std::max<size_t>(1024, kmers.size() / 2));
-        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (big ? 2 : 0)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
+        // The ordered-commit window B and the cost term R (a search that has run r expansions no longer holds back the seeds below
+        // j + B + r / R: the window slides past the long searches) by the number of seeds, from reads -> contigs runs of 0.2 .. 5 M reads
+        // (profiles/r02/e2e_window_sweep.log; seeds of rplB / nirK, search seconds):
+        //    7 k / 10 k: 1024 + 4  2.0 / 3.0    (half the seeds, no cost term: 2.4 / 3.7)
+        //   18 k / 24 k: 1024 + 4  3.0 / 3.9    (half the seeds: 3.9 / 5.8;  2048 + 4: 3.0 / 4.0)
+        //   37 k / 50 k: 2048 + 4  3.5 / 5.4    (8192 + 2: 4.1 / 7.4;  1024 + 4: 3.7 / 5.4;  4096 + 4: 3.6 / 5.5)
+        //   80 k / 108 k: 4096 + 2  5.3 / 8.7   (8192 + 2: 5.6 / 9.2;  4096 + 4: 5.5 / 8.6;  2048 + 2: 7.0 / 8.4)
+        //  200 k / 270 k: 8192 + 2  9.0 / 15.8  (8192 + 4: 10.3 / 16.7;  4096 + 4: 11.8 / 18.2);  414 k: 8192 + 2 14.4 (4096 + 2: 15.4)
+        const size_t ns = kmers.size();
+        const int window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
+        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);

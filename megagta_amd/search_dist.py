@@ -10,8 +10,8 @@ Same positional arguments, inputs and outputs as `megagta search` (search.cpp:72
 loop over seeds (search.cpp:184-189) across GPUs:
   * the graph (`<sdbg_prefix>.sdbg.*`) and the gene's two HMMs are replicated: every rank loads them onto its own GPU;
   * seeds shard by GENE first, then round-robin inside a gene (`dist.gene_seed_share`): with N >= #genes every rank works on one gene;
-  * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE; defaults as `megagta search`: 8192 + cost term 2 from 32768 seeds on, else half the
-    rank's seeds of the gene, at least 1024):
+  * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW /
+    MEGAGTA_CACHE_COST_RATE; defaults as `megagta search`: window 1024 .. 8192 and cost term 4 or 2 by the number of the rank's seeds):
     seed j of a rank sees the paths of that rank's seeds <= j - B.  The result is a function of (seed order, N, B), never of timing;
     N = 1 is exactly `megagta search`;
   * ONE all-gather of the contig bytes per gene (RCCL over xGMI; gloo in the CPU tests), then rank 0 writes
@@ -101,11 +101,10 @@ def main(argv: list[str]) -> int:
         contigs, nexp = [], 0
         if mine.size:
             fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fwd)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rev))
-            # as `megagta search`: window 8192 + cost term 2 for 32768 seeds and more, else half the seeds (at least 1024) and no cost
-            # term; per rank: over its own seeds
-            big = mine.size >= 32768
-            window = int(window_env) if window_env is not None else 8192 if big else min(8192, max(1024, mine.size // 2))
-            rate = int(os.environ["MEGAGTA_CACHE_COST_RATE"]) if "MEGAGTA_CACHE_COST_RATE" in os.environ else (2 if big else 0)
+            # as `megagta search` (megagta_main.cpp: window and cost term by the number of seeds); per rank: over its own seeds
+            ns = int(mine.size)
+            window = int(window_env) if window_env is not None else 1024 if ns < 32768 else 2048 if ns < 65536 else 4096 if ns < 196608 else 8192
+            rate = int(os.environ["MEGAGTA_CACHE_COST_RATE"]) if "MEGAGTA_CACHE_COST_RATE" in os.environ else (4 if ns < 65536 else 2)
             res, st = api.astar_search(graph, fw, rv, [kmers[i] for i in mine], [states[i] for i in mine], prune, pen, cache_mode=window,
                                        cost_rate=rate)
             contigs = [r.contig(kmers[i]) for r, i in zip(res, mine.tolist())]
