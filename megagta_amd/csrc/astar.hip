@@ -250,10 +250,10 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             // 20-90 ms/GB to obtain (profiles/r02/vmm_probe.log), so the pool follows the job: at least 4 GB; 24 MB per search in
             // flight (196 GB for a full grid) for independent searches -- at 100 M reads they average 29 k expansions
             // and hold 62 GB together -- and 8 MB per slot (64 GB) where the searches share their paths and most end after a few
-            // hundred; 24 MB again for batches of a million searches and more, which run for minutes.  No new search starts while half
+            // hundred; 16 MB for batches of a million searches and more (20 M reads: 68 GB in use at most, 93 GB handed out).  No new search starts while half
             // of it is in use, so a small pool costs searches in flight, not failures.
             const uint64_t n_search = (uint64_t)work * 2;
-            const uint64_t per_slot = (cache_mode == 0 || n_search >= (1ull << 20)) ? (24ull << 20) : (8ull << 20);
+            const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : n_search >= (1ull << 20) ? (16ull << 20) : (8ull << 20);
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
                                                  : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
@@ -262,6 +262,11 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             if (attempt == 1 && !ctx->astar_pool_bytes && ar.pool.bytes > slots * slot_bytes) dyn = std::max<uint64_t>(dyn, ar.pool.bytes - slots * slot_bytes);
             if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
+            // a pool of nearly that size is there (the previous gene's, sized from a slightly different count of free bytes): keep it
+            // rather than obtain 100+ GB again for a few per cent more
+            if (attempt == 0 && !ctx->astar_pool_bytes && ar.pool.p && ar.pool.bytes > slots * slot_bytes &&
+                ar.pool.bytes - slots * slot_bytes >= dyn - dyn / 4 && ar.pool.bytes - slots * slot_bytes < dyn)
+                dyn = ar.pool.bytes - slots * slot_bytes;
             dyn &= ~((1ull << kUnitLog) - 1);
             const uint64_t pool_bytes = slots * slot_bytes + dyn;
             if (ar.pool.bytes < pool_bytes || !ar.pool.p) {
