@@ -744,9 +744,14 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));
     b.scratch.alloc((size_t)b.window * b.per * 8, w.live(), w.peak());
     found.alloc(nb * 4 + 64, w.live(), w.peak());
-    if (nb)
-        hipLaunchKernelGGL(bubble_find_kernel, dim3(b.window / 64), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len, b.scratch.as<int64_t>(), b.per,
-                           found.as<uint32_t>());
+    if (nb) {
+        // the read-only searches need kMaxBranches * max_len words each, not a reach table: as many threads as the scratch holds of those
+        // (10 M reads: 8.5 M branching edges took 1 s with one thread per window slot)
+        const size_t per_find = (size_t)kMaxBranches * max_len;
+        const uint64_t threads = std::min<uint64_t>((nb + 63) / 64 * 64, ((uint64_t)b.window * b.per / per_find) / 64 * 64);
+        hipLaunchKernelGGL(bubble_find_kernel, dim3((unsigned)(threads / 64)), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len, b.scratch.as<int64_t>(),
+                           per_find, found.as<uint32_t>());
+    }
     const uint64_t nc = compact_list(w, branching, found, nb, cand);
     n_candidates = (int64_t)nc;
     note(w, "bubbles: %llu branching edges, %llu candidates, window %u", (unsigned long long)nb, (unsigned long long)nc, b.window);
