@@ -1486,7 +1486,9 @@ static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
     DevBuf &b = ctx->pool[slot];
     if (b.bytes < bytes || !b.p) {
         b.release();
-        b.alloc(bytes + bytes / 16, &ctx->live_bytes, &ctx->peak_bytes);
+        // an eighth of headroom (the pass planner leaves that much): the builds of a multi-k run need a few per cent more from one k to
+        // the next (contigs join the reads), and obtaining the buffers again costs more than a build (20 M reads: 1.7 s for 9 % more)
+        b.alloc(bytes + bytes / 8, &ctx->live_bytes, &ctx->peak_bytes);
     }
     return b.as<T>();
 }
