@@ -497,9 +497,9 @@ static int main_findstart(int argc, char **argv) {
         seeds[(size_t)i] = sd;
     }
     // of equal k-mers: the reference position of the first hit in scan order (what the map kept), the lowest contig
+    if (seeds.size() >= (1ull << 32)) die("findstart: too many hits (%zu)", seeds.size());
     std::vector<uint32_t> order(seeds.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-    if (seeds.size() >= (1ull << 32)) die("findstart: too many hits (%zu)", seeds.size());
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const Seed &x = seeds[a], &y = seeds[b];
         if (x.w[0] != y.w[0]) return x.w[0] < y.w[0];
