@@ -251,14 +251,8 @@ def main():
             # drained first (the block it hands out may still be read by the previous step's collectives)
             torch.cuda.current_stream().synchronize()
             shard = api.export_records_to_torch(ctx)
-            n = torch.tensor([shard.numel()], device="cuda", dtype=torch.int64)
-            ns = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(ns, n)
-            mx = max(int(x.item()) for x in ns)
-            pad = torch.zeros(max(mx, 1), dtype=torch.uint8, device="cuda")
-            pad[: shard.numel()] = shard
-            out = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(out, pad)
+            whole = mdist.all_gather_bytes(shard)          # (torch.cat of the pieces = the stream; the graph loader takes them as they are)
+            del whole
         return g.stats
 
     def fence():
@@ -325,13 +319,14 @@ def main():
             for gi in (range(len(mg.genes)) if genes is None else genes):
                 mine = share[gi]
                 kmers, states = [seeds[gi][i][0] for i in mine], [seeds[gi][i][1] - 1 for i in mine]
-                res, st = api.astar_search(graph, hm[gi][0], hm[gi][1], kmers, states, 20, 0.5) if len(mine) else ([], None)
+                cont, offs, st = api.astar_search_packed(graph, hm[gi][0], hm[gi][1], kmers, states, 20, 0.5) if len(mine) else \
+                    (np.zeros(0, np.uint8), np.zeros(1, np.int64), None)
                 if st:
                     for key in ("n_expansions", "ms_kernel", "n_retries", "n_grown"):
                         tot[key] += st[key]
                     tot["pool_used"] = max(tot["pool_used"], st["pool_used"])
                 if world > 1:
-                    mdist.all_gather_contigs(len(seeds[gi]), mine, [r.contig(km) for r, km in zip(res, kmers)])
+                    mdist.all_gather_packed_contigs(len(seeds[gi]), mine, cont, offs)
             return tot
 
         # warm-up: the first gene alone at 100 M reads (it obtains the pool at its full size and loads the kernels; a whole step takes

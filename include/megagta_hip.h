@@ -72,8 +72,12 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);   /* < 0
 /* Work memory of the searches.  The reference's node pool, open list and hash maps grow without bound (pool_st.h:43,
  * hash_table_st.h:559-568); here every search slot owns a base arena of 1 << log2_base_nodes nodes (0 = default 12; 7..20) and a search
  * that outgrows it takes further chunks from a device-side pool of pool_bytes (0 = sized from the number of searches in flight), its
- * hash table being re-built at twice the size when half full: no search is ever re-run for lack of room.  Small values exercise the
- * growth paths on small inputs (tests). */
+ * hash table being re-built at twice the size when half full.  When the pool itself runs dry: an independent search (cache_mode 0 / -1)
+ * that has waited in vain is run again by the host with fewer searches at a time (mgta_astar_stats.n_retries); under the ordered-commit
+ * window (cache_mode B >= 1) a starved search gives its memory back and starts again IN PLACE -- its slot keeps holding the window, the
+ * lowest running seed never yields -- so the result stays a function of (seed order, B, cost rate) whatever starved when; only if the
+ * lowest seed alone finds no room is the whole batch started again (caches empty, a note on stderr).  Small values exercise these paths
+ * on small inputs (tests). */
 int mgta_ctx_set_search_arena(mgta_ctx *, int log2_base_nodes, uint64_t pool_bytes);
 
 /* ------------------------------------------------------------------------------------------------
@@ -157,6 +161,10 @@ int mgta_sdbg_load(mgta_ctx *, int k, const uint16_t *recs, int64_t size, const 
  * mgta_sdbg_build* call of this context left on the device (one pass over all 65536 buckets), read where it lies — the records
  * never visit the host.  MGTA_EINVAL when there is no such stream (no build yet, a bucket sub-range, several passes). */
 int mgta_sdbg_load_resident(mgta_ctx *, mgta_sdbg **out);
+/* The same load from the files `buildgraph` wrote: PREFIX.sdbg_info + PREFIX.sdbg.0 .. N-1 (SdbgReader + LoadFromMultiFile,
+ * sdbg_multi_io.h:201-417, succinct_dbg.cpp:595-723).  The host maps the files and copies them to the device; the variable-length records
+ * are parsed there, one bucket per lane.  What every rank of a multi-GPU search and every one-shot `megagta denovo|search` calls. */
+int mgta_sdbg_load_files(mgta_ctx *, const char *prefix, mgta_sdbg **out);
 void mgta_sdbg_free(mgta_sdbg *);
 int64_t mgta_sdbg_size(const mgta_sdbg *);
 int mgta_sdbg_k(const mgta_sdbg *);                 /* the graph's k (node length), -1 for NULL */
@@ -231,7 +239,8 @@ typedef struct mgta_astar_side {
 } mgta_astar_side;
 
 typedef struct mgta_astar_stats {
-    int64_t n_seeds, n_expansions, n_opened, n_retries;   /* n_retries: searches run again because the pool was exhausted (normally 0) */
+    int64_t n_seeds, n_expansions, n_opened, n_retries;   /* n_retries: searches run again because the pool was exhausted (normally 0): by
+                                                           * the host after the pass (independent searches) or in place (ordered window) */
     double ms_total, ms_kernel;
     int64_t n_grown, n_rehash, n_recycled;                /* searches that outgrew their base arena, hash tables re-built, chunks re-used */
     uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / most of it in use at once */
@@ -262,6 +271,12 @@ int mgta_astar_batch(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, cons
 int mgta_astar_batch_on(mgta_ctx *run, mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers,
                         const int32_t *start_state, int64_t n, int prune_len, double low_cov_penalty,
                         int cache_mode, mgta_contig_sink sink, void *user, mgta_astar_stats *stats);
+/* The same batch with its results in flat arrays instead of one call-back per seed: contig i = (*contigs)[offsets[i] .. offsets[i + 1]) =
+ * left + lower-cased seed k-mer (k + 1 characters) + right, the sequence line `search` writes (hmm_graph_search.h:60-81).  *contigs is
+ * malloc'd (mgta_host_free); offsets [n + 1] and sides [2 n] (right, left per seed; may be NULL) are the caller's. */
+int mgta_astar_batch_packed(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
+                            int prune_len, double low_cov_penalty, int cache_mode, char **contigs, uint64_t *offsets, mgta_astar_side *sides,
+                            mgta_astar_stats *stats);
 int mgta_ctx_set_search_share(mgta_ctx *, int num, int den);     /* this context's search batches use num/den of the CUs (default 1/1) */
 
 #ifdef __cplusplus

@@ -81,6 +81,7 @@ SYMBOLS = {
                                  C.c_int, EDGE_SINK, C.c_void_p, C.POINTER(BuildStats)]),
     "mgta_findstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgta_sdbg_load_resident": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgta_sdbg_load_files": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_ctx_set_search_cost_rate": (C.c_int, [C.c_void_p, C.c_int]),
     "mgta_ctx_set_search_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
@@ -89,6 +90,8 @@ SYMBOLS = {
     "mgta_ctx_set_search_share": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgta_astar_batch_on": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
                                      C.c_int, CONTIG_SINK, C.c_void_p, C.POINTER(AstarStats)]),
+    "mgta_astar_batch_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int,
+                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.POINTER(AstarStats)]),
     "mgta_reads_pack_text": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mgta_ctx_release_scratch": (C.c_int, [C.c_void_p]),
     "mgta_denovo": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

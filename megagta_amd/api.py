@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import hashlib
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -161,6 +162,18 @@ class Graph:
         self.h = out
         self.size = ctx._L.mgta_sdbg_size(self.h)
 
+    @classmethod
+    def from_files(cls, ctx: Context, prefix: str) -> "Graph":
+        """PREFIX.sdbg_info + PREFIX.sdbg.* -> graph on the device (mgta_sdbg_load_files: the records are parsed on the device)"""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        out = C.c_void_p()
+        check(ctx._L.mgta_sdbg_load_files(ctx.h, os.fsencode(prefix), C.byref(out)), "mgta_sdbg_load_files")
+        self.h = out
+        self.size = ctx._L.mgta_sdbg_size(self.h)
+        self.k = ctx._L.mgta_sdbg_k(self.h)
+        return self
+
     def outgoing(self, edges) -> tuple[np.ndarray, np.ndarray]:
         """OutgoingEdges (succinct_dbg.cpp:78-97) for a batch: (outdeg int8[n], out int64[n,4])"""
         e = np.ascontiguousarray(edges, dtype=np.int64)
@@ -269,6 +282,32 @@ def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str
     check(ctx._L.mgta_astar_batch(graph.h, fwd.h, rev.h, buf, ss.ctypes.data, n, prune_len, low_cov_penalty, cache_mode,
                                   _lib.CONTIG_SINK(sink), None, C.byref(st)), "mgta_astar_batch")
     return results, st.as_dict()
+
+
+def astar_search_packed(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str], start_states, prune_len: int = 20,
+                        low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate: int = 0, want_sides: bool = False):
+    """astar_search with the results in flat arrays (mgta_astar_batch_packed): -> (contigs uint8[total], offsets int64[n + 1], stats[, sides]);
+    contig i = contigs[offsets[i]:offsets[i + 1]] = left + lower-cased k-mer + right.  No Python work per seed."""
+    ctx = graph.ctx
+    check(ctx._L.mgta_ctx_set_search_cost_rate(ctx.h, int(cost_rate)), "mgta_ctx_set_search_cost_rate")
+    klen = graph.k + 1
+    n = len(kmers)
+    if any(len(s) < klen for s in kmers):
+        raise MegaGtaError(f"seed k-mer shorter than k+1={klen}")
+    buf = "".join(s[:klen] for s in kmers).encode()
+    ss = np.ascontiguousarray(start_states, dtype=np.int32)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    sides = (_lib.AstarSide * (2 * n))() if want_sides else None
+    text, st = C.c_void_p(), _lib.AstarStats()
+    check(ctx._L.mgta_astar_batch_packed(graph.h, fwd.h, rev.h, buf, ss.ctypes.data, n, prune_len, low_cov_penalty, cache_mode, C.byref(text),
+                                         offsets.ctypes.data, C.cast(sides, C.c_void_p) if want_sides else None, C.byref(st)), "mgta_astar_batch_packed")
+    try:
+        total = int(offsets[n])
+        contigs = np.frombuffer((C.c_char * total).from_address(text.value), dtype=np.uint8).copy() if total else np.zeros(0, np.uint8)
+    finally:
+        ctx._L.mgta_host_free(text)
+    out = (contigs, offsets.astype(np.int64), st.as_dict())
+    return out + (sides,) if want_sides else out
 
 
 def counting_text(hist: np.ndarray) -> str:

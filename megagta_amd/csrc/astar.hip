@@ -224,12 +224,16 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, cap * sizeof(CacheEnt), st));
                 a.cache[d] = d_cache[d].as<CacheEnt>(); a.cache_mask[d] = cap - 1;
             }
-            d_start_limit.alloc(32);                                                // [0..1] limit per direction, [2..3] scan lock
-            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 32, st));
+            d_start_limit.alloc(64);                                                // [0..1] limit per direction, [2..3] scan lock, [4] pass given up
+            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 64, st));
             a.start_limit = d_start_limit.as<unsigned long long>();
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         }
 
+        // ordered launches (window B >= 1) never re-run single searches: a search that starves yields its memory and starts again in place
+        // (astar_kernel.hpp), so the result stays a function of (seed order, B, rate).  Only when the LOWEST running seed itself cannot
+        // be served does the pass give up; the whole batch then starts again, caches empty, with more room and fewer searches at a time.
+        const bool gated = cache_mode > 0 && !free_share;
         const int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 12;
         const uint64_t slot_bytes = 128ull << log_b0;                               // per node of the base arena: 64 B + 2 heap slots + 2 hash entries of 16 B
         AstarArenas &ar = ctx->astar;
@@ -260,7 +264,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             // the first re-run has the pool of the first pass to itself with a fraction of the searches; only the later ones ask for
             // everything that is free (obtaining 200 GB takes seconds)
             if (attempt == 1 && !ctx->astar_pool_bytes && ar.pool.bytes > slots * slot_bytes) dyn = std::max<uint64_t>(dyn, ar.pool.bytes - slots * slot_bytes);
-            if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;
+            if ((attempt > 1 || (gated && attempt == 1)) && !ctx->astar_pool_bytes) dyn = avail;
             dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
             // a pool of nearly that size is there (the previous gene's, sized from a slightly different count of free bytes): keep it
             // rather than obtain 100+ GB again for a few per cent more
@@ -281,25 +285,25 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 meta[c] = (uint32_t)stack_words; meta[kNumClasses + c] = (uint32_t)fit;
                 stack_words += fit;
             }
-            const size_t meta_words = 2 + 2 * kNumClasses /*lock, cnt*/ + 12 /*stat (u64 x 6)*/ + 2 * kNumClasses /*meta*/;
+            const size_t meta_words = 2 + 2 * kNumClasses /*lock, cnt*/ + 14 /*stat (u64 x 7)*/ + 2 * kNumClasses /*meta*/;
             if (ar.meta.bytes < (meta_words + stack_words) * 4 + 64) ar.meta.alloc((meta_words + stack_words) * 4 + 64, &ctx->live_bytes, &ctx->peak_bytes);
             {
-                // layout (32-bit words): [bump u64][stat u64 x 6][lock NC][cnt NC][meta 2 NC][stacks]
+                // layout (32-bit words): [bump u64][stat u64 x 7][lock NC][cnt NC][meta 2 NC][stacks]
                 uint32_t *w = ar.meta.as<uint32_t>();
-                MGTA_HIP_CHECK(hipMemsetAsync(w, 0, (14 + 2 * kNumClasses) * 4, st));
-                MGTA_HIP_CHECK(hipMemcpyAsync(w + 14 + 2 * kNumClasses, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+                MGTA_HIP_CHECK(hipMemsetAsync(w, 0, (16 + 2 * kNumClasses) * 4, st));
+                MGTA_HIP_CHECK(hipMemcpyAsync(w + 16 + 2 * kNumClasses, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
                 const unsigned long long bump0 = slots * slot_bytes;
                 MGTA_HIP_CHECK(hipMemcpyAsync(w, &bump0, 8, hipMemcpyHostToDevice, st));
                 a.pool.base = ar.pool.as<char>(); a.pool.bytes = pool_bytes;
                 a.pool.bump = reinterpret_cast<unsigned long long *>(w);
                 a.pool.stat = reinterpret_cast<unsigned long long *>(w + 2);
-                a.pool.lock = w + 14; a.pool.cnt = w + 14 + kNumClasses;
-                a.pool.meta = w + 14 + 2 * kNumClasses;
-                a.pool.stack = w + 14 + 4 * kNumClasses;
+                a.pool.lock = w + 16; a.pool.cnt = w + 16 + kNumClasses;
+                a.pool.meta = w + 16 + 2 * kNumClasses;
+                a.pool.stack = w + 16 + 4 * kNumClasses;
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
             a.pool.soft_limit = dyn / 2;
-            a.gate = cache_mode > 0 && attempt == 0 && !free_share;
+            a.gate = gated;
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {
@@ -320,14 +324,15 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            unsigned long long h_pool[7];                                           // bump, stat[0..5]
-            MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 56, hipMemcpyDeviceToHost, st));
+            unsigned long long h_pool[8];                                           // bump, stat[0..6]
+            MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 64, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
             MGTA_HIP_CHECK(hipGetLastError());
             float ms = 0;
             MGTA_HIP_CHECK(hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
             ST.ms_kernel += ms;
             ST.n_recycled += (int64_t)h_pool[1]; ST.n_rehash += (int64_t)h_pool[3]; ST.n_grown += (int64_t)h_pool[4];
+            ST.n_retries += (int64_t)h_pool[7];                                      // searches that started again in place
             ST.pool_bytes = pool_bytes;
             ST.pool_used = std::max<uint64_t>(ST.pool_used, slots * slot_bytes + h_pool[6]);   // base arenas + most ever handed out at once
             for (int d = 0; d < 2; ++d) {
@@ -335,11 +340,23 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
                 todo[d].swap(again);
             }
+            if (gated && (!todo[0].empty() || !todo[1].empty())) {
+                fprintf(stderr, "[megagta_amd] search: %zu searches found no memory even as the lowest running seeds (pool %.1f GB); the batch of %lld seeds "
+                        "starts again with more room\n", todo[0].size() + todo[1].size(), pool_bytes / 1e9, (long long)n);
+                for (int d = 0; d < 2; ++d) {
+                    todo[d].resize(n);
+                    for (int64_t s = 0; s < n; ++s) todo[d][s] = s;
+                    MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, d_cache[d].bytes, st));
+                }
+                MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
+                MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 64, st));
+            }
             ST.n_retries += (int64_t)(todo[0].size() + todo[1].size());
             if (getenv("MGTA_ASTAR_VERBOSE"))
                 fprintf(stderr, "[astar] pass %d: %lld workgroups, pool %.1f GB, handed out once %.1f GB, most in use %.1f GB, %llu chunks reused, "
-                        "%llu requests refused, %.0f ms, %zu searches to run again\n", attempt, (long long)blocks, pool_bytes / 1e9, h_pool[0] / 1e9,
-                        (slots * slot_bytes + h_pool[6]) / 1e9, h_pool[1], h_pool[2], ms, todo[0].size() + todo[1].size());
+                        "%llu requests refused, %llu searches started again in place, %.0f ms, %zu searches to run again\n", attempt, (long long)blocks,
+                        pool_bytes / 1e9, h_pool[0] / 1e9, (slots * slot_bytes + h_pool[6]) / 1e9, h_pool[1], h_pool[2], h_pool[7], ms,
+                        todo[0].size() + todo[1].size());
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         }
         if (!todo[0].empty() || !todo[1].empty()) {
@@ -401,6 +418,46 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         if (stats) *stats = ST;
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }
+}
+
+// The same batch with the results in flat arrays instead of one call-back per seed (a Python caller pays microseconds per call-back:
+// minutes at millions of seeds): contig i = (*contigs)[offsets[i] .. offsets[i + 1]) = left + lower-cased k-mer + right, exactly the
+// sequence line `search` writes (hmm_graph_search.h:60-81).
+namespace {
+struct PackSink {
+    std::string text;
+    uint64_t *offsets;
+    mgta_astar_side *sides;
+    const char *kmers;
+    int klen;
+};
+int pack_sink(void *user, int64_t i, const char *left, int64_t ll, const char *right, int64_t rl, const mgta_astar_side *rs, const mgta_astar_side *ls) {
+    PackSink &p = *static_cast<PackSink *>(user);
+    p.offsets[i] = p.text.size();
+    p.text.append(left, (size_t)ll);
+    const char *km = p.kmers + (size_t)i * p.klen;
+    for (int j = 0; j < p.klen; ++j) p.text.push_back((char)tolower((unsigned char)km[j]));       // the seed k-mer, lower case (search.cpp:156)
+    p.text.append(right, (size_t)rl);
+    if (p.sides) { p.sides[2 * i] = *rs; p.sides[2 * i + 1] = *ls; }
+    return 0;
+}
+}  // namespace
+
+int mgta_astar_batch_packed(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
+                            int prune_len, double low_cov_penalty, int cache_mode, char **contigs, uint64_t *offsets, mgta_astar_side *sides,
+                            mgta_astar_stats *stats) {
+    if (!g || !contigs || !offsets) { set_error("mgta_astar_batch_packed: bad argument"); return MGTA_EINVAL; }
+    *contigs = nullptr;
+    PackSink ps{std::string(), offsets, sides, kmers, g->dev.k + 1};
+    const int rc = mgta_astar_batch_on(g->ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, pack_sink, &ps, stats);
+    if (rc != MGTA_OK) return rc;
+    offsets[n] = ps.text.size();
+    char *buf = static_cast<char *>(malloc(ps.text.size() + 1));
+    if (!buf) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
+    memcpy(buf, ps.text.data(), ps.text.size());
+    buf[ps.text.size()] = 0;
+    *contigs = buf;
+    return MGTA_OK;
 }
 
 }  // extern "C"

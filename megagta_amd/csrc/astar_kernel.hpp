@@ -34,7 +34,7 @@ constexpr uint32_t kMaxNew = 132;              // children one expansion can ope
 
 enum { T_MM = 0, T_MI = 1, T_MD = 2, T_IM = 3, T_II = 4, T_DM = 5, T_DD = 6 };   // profile_hmm.h:25
 enum { ST_M = 0, ST_I = 1, ST_D = 2 };
-enum { S_IDLE = 0, S_WAIT = 1, S_START = 2, S_RUN = 3, S_DONE = 4, S_EXIT = 5 };
+enum { S_IDLE = 0, S_WAIT = 1, S_START = 2, S_RUN = 3, S_DONE = 4, S_EXIT = 5, S_BACKOFF = 6 };
 
 struct ANode {                    // AStarNode, a_star_node.h:9-33
     double score, real_score, max_score;
@@ -83,7 +83,8 @@ struct PoolDev {
     unsigned int *stack;          // free chunks (4 KB units) of class c at stack[meta[c] .. meta[c] + meta[kNumClasses + c])
     const unsigned int *meta;
     unsigned long long *stat;     // [0] chunks served by the free lists, [1] failed allocations, [2] re-hashes, [3] searches that grew,
-                                  // [4] bytes handed out and not yet returned, [5] its high-water mark (sampled when a search starts)
+                                  // [4] bytes handed out and not yet returned, [5] its high-water mark (sampled when a search starts),
+                                  // [6] searches that gave their memory back and started again in place (ordered launches only)
     unsigned long long soft_limit;   // no new search starts while more than this is in use: the ones that run keep room to grow
 };
 
@@ -125,7 +126,8 @@ struct AstarArgs {
     uint32_t cache_probe_limit;   // an insert gives up after this many probes (a missed entry is always correct)
     long long *run_seed;          // [slots] seed a search slot is working on (a lower bound while it is taking one from the queue), -1 = none
     unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
-    unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last refresh by a waiting wave
+    unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last
+                                        // refresh by a waiting wave, [4] the pass has given up (no further seed is taken)
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
@@ -532,6 +534,29 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
     return bound;
 }
 
+// Lowest search (2 * seed + direction) any slot of the launch is working on (-1: none).  Every lane of the WAVE calls it and returns the
+// same value.  Under the gate seeds are taken in order, so this is the one search nobody is ahead of: the one that never yields its memory.
+template <int G>
+__device__ __forceinline__ long long lowest_running(const AstarArgs &a, int lane) {
+    constexpr uint32_t SPB = kAstarWaves * Grp<G>::kGroups;
+    long long lo = 0x7FFFFFFFFFFFFFFFll;
+    for (uint32_t t0 = 0; t0 < a.n_slots; t0 += 256) {
+        long long js[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t sl = t0 + u * 64 + (uint32_t)lane;
+            js[u] = -1;
+            if (sl < a.n_slots) js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (js[u] >= 0) js[u] = js[u] * 2 + (long long)((sl / SPB) & 1u);      // workgroup 2b + dir
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (js[u] >= 0 && js[u] < lo) lo = js[u];
+    }
+    lo = wave_min_ll(lo);
+    return lo == 0x7FFFFFFFFFFFFFFFll ? -1ll : lo;
+}
+
 __device__ __forceinline__ int base_of(char ch) {
     return (ch == 'A' || ch == 'a') ? 0 : (ch == 'C' || ch == 'c') ? 1 : (ch == 'G' || ch == 'g' || ch == 'N' || ch == 'n') ? 2
            : (ch == 'T' || ch == 't') ? 3 : -1;
@@ -617,6 +642,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
+    bool yield_check = false;                                         // ordered launch: starved for long -- give the memory back unless this is the lowest running seed
+    uint32_t prog_floor = 0;                                          // expansions already announced for this seed before it started again in place
     bool have_curr = false;                                           // the node to expand is already popped (the search was waiting for memory)
     int32_t goal = -1, inter = 0, cur = 0;
     double inter_val = 0;                                             // (real_score + exit_prob[length]) / ln 2 of node `inter`
@@ -629,6 +656,18 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     while (true) {
         // ================= next search for the idle slots
         if (st == S_IDLE && lslot >= a.active_slots) st = S_EXIT;
+        if (st == S_BACKOFF) {    // a search that gave its memory back: it starts again (same seed, same place in the order) once there is room
+            unsigned long long used = 0, quit = 0;
+            if (gl == 0) { used = ld_agent(&a.pool.stat[4]); quit = ld_agent(&a.start_limit[4]); }
+            used = GX::bcast(used, 0, gbase);
+            quit = GX::bcast(quit, 0, gbase);
+            if (quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }       // (status stays 0: the pass is run again)
+            else if (used <= a.pool.soft_limit) st = S_START;
+        }
+        if (__ballot(st == S_BACKOFF) != 0ull && __ballot(st == S_START || st == S_RUN || st == S_DONE) == 0ull) {
+#pragma unroll
+            for (int z = 0; z < 4; ++z) __builtin_amdgcn_s_sleep(127);
+        }
         bool admit = true;
         if (st == S_IDLE) {       // admission: searches in flight are bounded by the memory they hold, not only by the number of slots
             unsigned long long used = 0;
@@ -642,7 +681,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         if (st == S_IDLE && admit) {
             long long qi = 0;
             if (gl == 0) {
-                if (a.gate) {
+                if (a.gate && ld_agent(&a.start_limit[4]) != 0ull) {
+                    qi = n_todo;                                                       // the pass has given up (a search that fits nowhere): take nothing more
+                } else if (a.gate) {
                     // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also
                     // sees a slot that holds it (or its committed paths)
                     st_agent(&a.run_progress[slot], 0ull);
@@ -659,6 +700,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             } else {
                 seed = todo[qi];
                 sid = seed * 2 + dir;
+                prog_floor = 0;
                 if (a.gate) {
                     if (gl == 0) st_agent(&a.run_seed[slot], (long long)seed);
                     st = S_WAIT; need_scan = true; spins = 0;
@@ -683,9 +725,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (__ballot(st == S_WAIT) != 0ull) {
                 bool scan = __ballot(st == S_WAIT && need_scan) != 0ull;
                 if (!scan) {
-                    long long lim = 0;
-                    if (lane == 0) lim = (long long)ld_agent(&a.start_limit[dir]);
+                    long long lim = 0, quit = 0;
+                    if (lane == 0) { lim = (long long)ld_agent(&a.start_limit[dir]); quit = (long long)ld_agent(&a.start_limit[4]); }
                     lim = __shfl(lim, 0, 64);
+                    quit = __shfl(quit, 0, 64);
+                    if (st == S_WAIT && quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }   // the pass has given up and is run again
                     if (st == S_WAIT && lim >= seed) st = S_START;
                     if (__ballot(st == S_WAIT) != 0ull) {
                         int refresh = 0;
@@ -711,6 +755,46 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (__ballot(st == S_START || st == S_RUN) == 0ull) {  // nothing to do in this wave but wait
 #pragma unroll
                     for (int z = 0; z < 8; ++z) __builtin_amdgcn_s_sleep(127);
+                }
+            }
+        }
+
+        // ================= ordered launches never hand a starved search to the host (a re-run after the others would see other paths than a
+        // run in its place): a search that has waited long for memory gives back what it holds and starts again IN PLACE -- same seed,
+        // its slot keeps announcing it, so every later seed waits for it exactly as before and nobody ever saw anything of it -- unless it
+        // is the lowest running seed: that one keeps what it has and is served by the others' memory.  Wave-level scan, rare.
+        if (a.gate && __ballot(st == S_RUN && yield_check) != 0ull) {
+            const long long lo = lowest_running<G>(a, lane);
+            if (st == S_RUN && yield_check) {
+                yield_check = false;
+                if (sid == lo) {
+                    // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
+                    // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
+                    unsigned long long own = 0;
+                    for (int l = 1; l < n_levels; ++l) own += 1ull << (AR.chunk_class(l) + (int)(seg[l] >> kBorrowShift) + kUnitLog);
+                    for (int l = 1; l < h_levels; ++l) own += 1ull << (H.ar.chunk_class(l) + (int)(hseg[l] >> kBorrowShift) + kUnitLog);
+                    if (hclass > base_hclass) own += 1ull << (hclass + (int)(hunit >> kBorrowShift) + kUnitLog);
+                    unsigned long long used = 0;
+                    if (gl == 0) used = ld_agent(&a.pool.stat[4]);
+                    used = GX::bcast(used, 0, gbase);
+                    if (used <= own) {
+                        status = 2; st = S_DONE;
+                        if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
+                    }
+                } else {
+                    if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
+                        pool_release_fence();
+                        if (gl == 0) {
+                            for (int l = 1; l < n_levels; ++l) pool_free(a.pool, AR.chunk_class(l), seg[l]);
+                            for (int l = 1; l < h_levels; ++l) pool_free(a.pool, H.ar.chunk_class(l), hseg[l]);
+                            if (hclass > base_hclass) pool_free(a.pool, hclass, hunit);
+                        }
+                    }
+                    n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+                    if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    prog_floor = n_expanded > prog_floor ? n_expanded : prog_floor;
+                    starved = 0; have_curr = false;
+                    st = S_BACKOFF;
                 }
             }
         }
@@ -880,7 +964,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // their memory for the others within milliseconds and the ones that have run for seconds wait for seconds
                 uint32_t patience = n_expanded >> 2;
                 patience = patience < 256u ? 256u : patience > (kStarveLimit << 2) ? (kStarveLimit << 2) : patience;
-                if (++starved > patience) { status = 2; stop = true; }
+                if (++starved > patience) {
+                    if (a.gate) {                                                      // ordered launch: yield in place (above), never a host re-run
+                        if (((starved - patience) & 255u) == 1u) yield_check = true;
+                        if (starved > (1u << 18)) {                                    // (backstop) no room for seconds: the host starts the batch again
+                            status = 2; stop = true;
+                            if (gl == 0) st_agent(&a.start_limit[4], 1ull);
+                        }
+                    } else { status = 2; stop = true; }
+                }
             } else {
                 starved = 0;
             }
@@ -914,7 +1006,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 if (!valid) od3 = 0;
                 n_expanded++;
-                if (a.gate && a.cost_rate != 0 && (n_expanded & 63) == 0 && gl == 0)
+                if (a.gate && a.cost_rate != 0 && (n_expanded & 63) == 0 && gl == 0 && n_expanded > prog_floor)
                     __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
                 PROF(5)

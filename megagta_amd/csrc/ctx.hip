@@ -64,7 +64,11 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
 int mgta_ctx_keep_stream(mgta_ctx *ctx, int on) {
     if (!ctx) return MGTA_EINVAL;
     ctx->keep_stream = on ? 1 : 0;
-    if (!on) { ctx->acc_rec.release(); ctx->acc_tips.release(); ctx->acc_valid = false; }
+    if (!on) {
+        // after a keep-stream build last_rec / last_tips point INTO the stream buffers: they go with them
+        if (ctx->acc_valid) { ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0; }
+        ctx->acc_rec.release(); ctx->acc_tips.release(); ctx->acc_valid = false;
+    }
     return MGTA_OK;
 }
 

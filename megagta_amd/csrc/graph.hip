@@ -3,9 +3,14 @@
 //
 // Replaces SuccinctDBG::LoadFromMultiFile + init (succinct_dbg.cpp:595-723, succinct_dbg.h:62-86)
 // and RankAndSelect{4Bits,1Bit}::Build (rank_and_select.h:80-150,430-500).
-#include <memory>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -93,6 +98,37 @@ __global__ __launch_bounds__(256) void graph_hint_kernel(GraphDev g, GLine *line
         }
         lines[li].fwd_hint[a - 1] = (uint32_t)h;
     }
+}
+
+// PREFIX.sdbg.N -> logical edge stream (SdbgReader::NextItem, sdbg_multi_io.h:335-382).  A bucket's records are variable-length (a
+// record word, then the full multiplicity when the stored one is 255, then words_per_tip label words when it is a tip), so a bucket is
+// parsed front to back; the 65536 buckets are independent and their places in the output are known from the index file: one lane per
+// bucket.  `bytes` = a piece of one file, already on the device; every size was checked against the file by the host.
+struct BucketSrc {
+    uint64_t src;        // byte offset of the bucket inside `bytes` (even)
+    uint64_t n_bytes;    // 2 items + 2 large + 4 words_per_tip tips
+    int64_t items, rec_out, tip_out;   // records, index of its first record, index of its first tip
+};
+__global__ __launch_bounds__(64) void sdbg_decode_kernel(const uint16_t *bytes, const BucketSrc *buckets, uint32_t n, int words_per_tip, uint16_t *recs,
+                                                         uint32_t *tips, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const BucketSrc b = buckets[i];
+    const uint16_t *p = bytes + (b.src >> 1), *end = p + (b.n_bytes >> 1);
+    uint16_t *out = recs + b.rec_out;
+    uint32_t *tp = tips + b.tip_out * words_per_tip;
+    bool ok = true;
+    for (int64_t r = 0; r < b.items; ++r) {
+        if (p >= end) { ok = false; break; }
+        const uint32_t it = *p++;
+        out[r] = (uint16_t)it;
+        if ((it >> 8) == 255u) ++p;                                      // the full multiplicity: not part of the graph (need_multiplicity = false)
+        if ((it >> 5) & 1u) {
+            if (p + 2 * words_per_tip > end) { ok = false; break; }
+            for (int w = 0; w < words_per_tip; ++w) { *tp++ = (uint32_t)p[0] | ((uint32_t)p[1] << 16); p += 2; }
+        }
+    }
+    if (!ok || p != end) atomicAdd(bad, 1u);
 }
 
 __global__ void graph_rankf_kernel(GraphDev g, int64_t *rank_f) {
@@ -202,6 +238,141 @@ int mgta_sdbg_load(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, con
                    int64_t n_tip_words, int words_per_tip, mgta_sdbg **out) {
     if (!ctx || !out || size < 0 || (size > 0 && !recs) || !bucket_items) { set_error("mgta_sdbg_load: bad argument"); return MGTA_EINVAL; }
     return load_graph(ctx, k, recs, size, bucket_items, tips, n_tip_words, words_per_tip, false, out);
+}
+
+// SuccinctDBG::LoadFromMultiFile (succinct_dbg.cpp:595-723) from the files themselves: the host reads the index, maps the record files
+// and copies them to the device piece by piece (pinned staging, several copy threads); the records are parsed THERE.
+int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
+    if (!ctx || !prefix_c || !out) { set_error("mgta_sdbg_load_files: bad argument"); return MGTA_EINVAL; }
+    const std::string prefix = prefix_c;
+    struct Fd { int fd = -1; const unsigned char *map = nullptr; size_t size = 0; };
+    std::vector<Fd> files;
+    struct Cleanup {
+        std::vector<Fd> &f; void *pin[2] = {nullptr, nullptr};
+        ~Cleanup() { for (Fd &x : f) { if (x.map && x.size) munmap(const_cast<unsigned char *>(x.map), x.size); if (x.fd >= 0) close(x.fd); }
+                     for (void *q : pin) if (q) (void)hipHostFree(q); }
+    } cleanup{files};
+    try {
+        FILE *info = fopen((prefix + ".sdbg_info").c_str(), "r");
+        if (!info) { set_error("cannot open %s.sdbg_info", prefix.c_str()); return MGTA_EINVAL; }
+        int k = 0, wpt = 0, nb = 0, nf = 0;
+        long long total = 0, ntips = 0, nlarge = 0;
+        struct Line { int tid; long long off, items, tips, large; };
+        std::vector<Line> bl(MGTA_NUM_BUCKETS);
+        bool good = fscanf(info, "k %d\n", &k) == 1 && fscanf(info, "words_per_tip_label %d\n", &wpt) == 1 && fscanf(info, "num_buckets %d\n", &nb) == 1 &&
+                    fscanf(info, "num_threads %d\n", &nf) == 1 && fscanf(info, "total_size %lld\n", &total) == 1 && fscanf(info, "num_tips %lld\n", &ntips) == 1 &&
+                    fscanf(info, "large_multi %lld\n", &nlarge) == 1 && nb == MGTA_NUM_BUCKETS && nf >= 1 && nf <= 65536 && k >= 1 && wpt == (2 * k + 31) / 32 &&
+                    total >= 0 && ntips >= 0;
+        for (int b = 0; good && b < nb; ++b) {
+            int id = -1;
+            good = fscanf(info, "%d %d %lld %lld %lld %lld\n", &id, &bl[b].tid, &bl[b].off, &bl[b].items, &bl[b].tips, &bl[b].large) == 6 && id == b &&
+                   bl[b].tid < nf && bl[b].items >= 0 && bl[b].tips >= 0 && bl[b].large >= 0 && bl[b].off >= 0 && (bl[b].off & 1) == 0;
+        }
+        fclose(info);
+        if (!good) { set_error("%s.sdbg_info: not an SdBG index (sdbg_multi_io.h:117-187)", prefix.c_str()); return MGTA_EINVAL; }
+        files.resize(nf);
+        for (int t = 0; t < nf; ++t) {
+            const std::string path = prefix + ".sdbg." + std::to_string(t);
+            files[t].fd = open(path.c_str(), O_RDONLY);
+            struct stat sb;
+            if (files[t].fd < 0 || fstat(files[t].fd, &sb) != 0) { set_error("cannot open %s", path.c_str()); return MGTA_EINVAL; }
+            files[t].size = (size_t)sb.st_size;
+            if (files[t].size) {
+                void *m = mmap(nullptr, files[t].size, PROT_READ, MAP_PRIVATE, files[t].fd, 0);
+                if (m == MAP_FAILED) { set_error("cannot map %s", path.c_str()); return MGTA_EINVAL; }
+                files[t].map = static_cast<const unsigned char *>(m);
+                (void)madvise(m, files[t].size, MADV_SEQUENTIAL);
+            }
+        }
+        // where every bucket's records and tips go, and the pieces to copy: the buckets of a file in offset order, cut every ~512 MB
+        std::vector<int64_t> items(MGTA_NUM_BUCKETS), rec_out(MGTA_NUM_BUCKETS), tip_out(MGTA_NUM_BUCKETS);
+        long long acc_r = 0, acc_t = 0;
+        std::vector<std::vector<int>> of_file(nf);
+        for (int b = 0; b < nb; ++b) {
+            const bool has = bl[b].tid >= 0 && bl[b].items > 0;
+            items[b] = has ? bl[b].items : 0;
+            rec_out[b] = acc_r; tip_out[b] = acc_t;
+            if (!has) continue;
+            const unsigned long long nbytes = 2ull * bl[b].items + 2ull * bl[b].large + 4ull * wpt * bl[b].tips;
+            if ((unsigned long long)bl[b].off + nbytes > files[bl[b].tid].size || bl[b].tips > bl[b].items || bl[b].large > bl[b].items) {
+                set_error("%s.sdbg_info: bucket %d does not fit %s.sdbg.%d", prefix.c_str(), b, prefix.c_str(), bl[b].tid);
+                return MGTA_EINVAL;
+            }
+            acc_r += bl[b].items; acc_t += bl[b].tips;
+            of_file[bl[b].tid].push_back(b);
+        }
+        if (acc_r != total || acc_t != ntips) { set_error("%s.sdbg_info: the bucket lines hold %lld records / %lld tips, the header says %lld / %lld",
+                                                          prefix.c_str(), acc_r, acc_t, total, ntips); return MGTA_EINVAL; }
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        DevBuf d_recs, d_tips, d_piece[2], d_desc[2], d_bad;
+        d_recs.alloc((size_t)total * 2 + 64, &ctx->live_bytes, &ctx->peak_bytes);
+        d_tips.alloc((size_t)ntips * 4 * wpt + 64, &ctx->live_bytes, &ctx->peak_bytes);
+        d_bad.alloc(64);
+        MGTA_HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 64, st));
+        const size_t kPiece = 512ull << 20, kStage = 64ull << 20;
+        for (auto &q : cleanup.pin) MGTA_HIP_CHECK(hipHostMalloc(&q, kStage, hipHostMallocDefault));
+        hipEvent_t ev[2];
+        for (auto &e : ev) MGTA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int stage = 0;
+        bool used_stage[2] = {false, false};
+        const unsigned n_copy = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        auto upload = [&](const unsigned char *src, size_t n, char *dst) {       // file bytes -> device, through the two pinned buffers
+            for (size_t o = 0; o < n; o += kStage) {
+                const size_t m = std::min(kStage, n - o);
+                if (used_stage[stage]) MGTA_HIP_CHECK(hipEventSynchronize(ev[stage]));
+                char *pin = static_cast<char *>(cleanup.pin[stage]);
+                std::vector<std::thread> th;
+                const size_t per = (m + n_copy - 1) / n_copy;
+                for (unsigned t = 1; t < n_copy && t * per < m; ++t)
+                    th.emplace_back([=] { memcpy(pin + t * per, src + o + t * per, std::min(per, m - t * per)); });
+                memcpy(pin, src + o, std::min(per, m));
+                for (auto &x : th) x.join();
+                MGTA_HIP_CHECK(hipMemcpyAsync(dst + o, pin, m, hipMemcpyHostToDevice, st));
+                MGTA_HIP_CHECK(hipEventRecord(ev[stage], st));
+                used_stage[stage] = true;
+                stage ^= 1;
+            }
+        };
+        int pc = 0;
+        std::vector<BucketSrc> desc;
+        for (int t = 0; t < nf; ++t) {
+            std::vector<int> &bs = of_file[t];
+            std::sort(bs.begin(), bs.end(), [&](int a, int b) { return bl[a].off < bl[b].off; });
+            for (size_t i = 0; i < bs.size();) {
+                const unsigned long long lo = (unsigned long long)bl[bs[i]].off;
+                unsigned long long hi = lo;
+                desc.clear();
+                size_t j = i;
+                for (; j < bs.size(); ++j) {
+                    const Line &L = bl[bs[j]];
+                    const unsigned long long nbytes = 2ull * L.items + 2ull * L.large + 4ull * wpt * L.tips;
+                    if (j > i && (unsigned long long)L.off + nbytes - lo > kPiece) break;
+                    hi = std::max(hi, (unsigned long long)L.off + nbytes);
+                    desc.push_back(BucketSrc{(uint64_t)L.off - lo, nbytes, L.items, rec_out[bs[j]], tip_out[bs[j]]});
+                }
+                // (the piece buffers alternate: the kernel of one piece runs while the next is being staged; a buffer is re-used two
+                // pieces later, behind that kernel in stream order)
+                if (d_piece[pc].bytes < hi - lo + 64) d_piece[pc].alloc((size_t)(hi - lo) + 64, &ctx->live_bytes, &ctx->peak_bytes);
+                if (d_desc[pc].bytes < desc.size() * sizeof(BucketSrc)) d_desc[pc].alloc(std::max<size_t>(desc.size(), 4096) * sizeof(BucketSrc));
+                upload(files[t].map + lo, (size_t)(hi - lo), d_piece[pc].as<char>());
+                MGTA_HIP_CHECK(hipMemcpyAsync(d_desc[pc].p, desc.data(), desc.size() * sizeof(BucketSrc), hipMemcpyHostToDevice, st));
+                MGTA_HIP_CHECK(hipStreamSynchronize(st));                             // (desc is re-used by the host; pieces are hundreds of MB)
+                hipLaunchKernelGGL(sdbg_decode_kernel, dim3((unsigned)((desc.size() + 63) / 64)), dim3(64), 0, st, d_piece[pc].as<uint16_t>(),
+                                   d_desc[pc].as<BucketSrc>(), (uint32_t)desc.size(), wpt, d_recs.as<uint16_t>(), d_tips.as<uint32_t>(), d_bad.as<uint32_t>());
+                MGTA_HIP_CHECK(hipGetLastError());
+                pc ^= 1;
+                i = j;
+            }
+        }
+        uint32_t bad = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        d_piece[0].release(); d_piece[1].release();
+        if (bad) { set_error("%s: %u buckets do not parse to the sizes the index gives", prefix.c_str(), bad); return MGTA_EINVAL; }
+        return load_graph(ctx, k, d_recs.as<uint16_t>(), (int64_t)total, items.data(), d_tips.as<uint32_t>(), (int64_t)ntips * wpt, wpt, true, out);
+    } catch (const HipError &e) { return e.code; }
 }
 
 int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {

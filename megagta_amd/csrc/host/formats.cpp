@@ -317,19 +317,28 @@ void build_read_lib(const std::string &lib_file, const std::string &out_prefix, 
 }
 
 // ----------------------------------------------------------------------------------------------------
-void write_sdbg(const std::string &prefix, const EdgeStream &s) {
-    FILE *f = fopen((prefix + ".sdbg.0").c_str(), "wb");
-    if (!f) die("cannot write %s.sdbg.0", prefix.c_str());
-    FILE *info = fopen((prefix + ".sdbg_info").c_str(), "w");
-    if (!info) die("cannot write %s.sdbg_info", prefix.c_str());
+// The records of the buckets [b_lo, b_hi) go to PREFIX.sdbg.<file_id>.  part = false: that is the whole graph, PREFIX.sdbg_info is
+// written with it (one file).  part = true: one rank's share of a build over several GPUs: PREFIX.sdbg_info.part<file_id> keeps this
+// file's bucket lines and counts until merge_sdbg_parts puts the index together (the reference's writer also deals the buckets to
+// num_threads files, sdbg_multi_io.h:83-187: a reader does not care who wrote which).
+void write_sdbg(const std::string &prefix, const EdgeStream &s, int file_id, int b_lo, int b_hi, bool part) {
+    const std::string fname = prefix + ".sdbg." + std::to_string(file_id);
+    FILE *f = fopen(fname.c_str(), "wb");
+    if (!f) die("cannot write %s", fname.c_str());
+    const std::string iname = part ? prefix + ".sdbg_info.part" + std::to_string(file_id) : prefix + ".sdbg_info";
+    FILE *info = fopen(iname.c_str(), "w");
+    if (!info) die("cannot write %s", iname.c_str());
     int64_t n_tips = s.words_per_tip ? (int64_t)s.tips.size() / s.words_per_tip : 0;
-    fprintf(info, "k %d\nwords_per_tip_label %d\nnum_buckets %d\nnum_threads %d\n", s.k, s.words_per_tip, 65536, 1);
-    fprintf(info, "total_size %lld\nnum_tips %lld\nlarge_multi %lld\n", (long long)s.recs.size(), (long long)n_tips, (long long)s.large.size());
+    if (part) fprintf(info, "%d %d %d %d %lld %lld %lld\n", s.k, s.words_per_tip, b_lo, b_hi, (long long)s.recs.size(), (long long)n_tips, (long long)s.large.size());
+    else {
+        fprintf(info, "k %d\nwords_per_tip_label %d\nnum_buckets %d\nnum_threads %d\n", s.k, s.words_per_tip, 65536, 1);
+        fprintf(info, "total_size %lld\nnum_tips %lld\nlarge_multi %lld\n", (long long)s.recs.size(), (long long)n_tips, (long long)s.large.size());
+    }
     std::vector<unsigned char> buf;
     size_t ri = 0, li = 0, ti = 0;
     long long off = 0;
-    for (int b = 0; b < 65536; ++b) {
-        int64_t n = s.bucket_items[b];
+    for (int b = part ? b_lo : 0; b < (part ? b_hi : 65536); ++b) {
+        int64_t n = (b >= b_lo && b < b_hi) ? s.bucket_items[b] : 0;
         if (n == 0) { fprintf(info, "%d -1 0 0 0 0\n", b); continue; }
         const size_t worst = (size_t)n * (size_t)(4 + 4 * s.words_per_tip);      // record + large multiplicity + tip label
         if (buf.size() < worst) buf.resize(worst);
@@ -347,12 +356,48 @@ void write_sdbg(const std::string &prefix, const EdgeStream &s) {
         }
         ri += (size_t)n;
         const size_t bytes = (size_t)(q - buf.data());
-        if (fwrite(buf.data(), 1, bytes, f) != bytes) die("write error on %s.sdbg.0", prefix.c_str());
-        fprintf(info, "%d 0 %lld %lld %lld %lld\n", b, off, (long long)n, (long long)nt, (long long)nl);
+        if (fwrite(buf.data(), 1, bytes, f) != bytes) die("write error on %s", fname.c_str());
+        fprintf(info, "%d %d %lld %lld %lld %lld\n", b, file_id, off, (long long)n, (long long)nt, (long long)nl);
         off += (long long)bytes;
     }
-    fclose(f);
-    fclose(info);
+    if (fclose(f) != 0 || fclose(info) != 0) die("write error on %s", fname.c_str());
+}
+void write_sdbg(const std::string &prefix, const EdgeStream &s) { write_sdbg(prefix, s, 0, 0, 65536, false); }
+
+// PREFIX.sdbg_info from the parts of `n_parts` ranks (file r = PREFIX.sdbg.r holds the buckets of part r); the parts are removed
+void merge_sdbg_parts(const std::string &prefix, int n_parts) {
+    int k = -1, wpt = -1, next_b = 0;
+    long long total = 0, tips = 0, large = 0;
+    std::vector<std::string> lines;
+    lines.reserve(65536);
+    char *lp = nullptr;
+    size_t cap = 0;
+    for (int r = 0; r < n_parts; ++r) {
+        const std::string pn = prefix + ".sdbg_info.part" + std::to_string(r);
+        FILE *f = fopen(pn.c_str(), "r");
+        if (!f) die("cannot open %s (rank %d of the build did not finish?)", pn.c_str(), r);
+        int pk, pw, lo, hi;
+        long long n, nt, nl;
+        if (fscanf(f, "%d %d %d %d %lld %lld %lld\n", &pk, &pw, &lo, &hi, &n, &nt, &nl) != 7) die("%s: bad header", pn.c_str());
+        if (r == 0) { k = pk; wpt = pw; }
+        if (pk != k || pw != wpt || lo != next_b || hi < lo) die("%s: part %d covers buckets [%d, %d), expected to start at %d with k = %d", pn.c_str(), r, lo, hi, next_b, k);
+        total += n; tips += nt; large += nl;
+        for (int b = lo; b < hi; ++b) {
+            if (getline(&lp, &cap, f) <= 0 || atoi(lp) != b) die("%s: bucket line %d missing", pn.c_str(), b);
+            lines.emplace_back(lp);
+        }
+        next_b = hi;
+        fclose(f);
+    }
+    free(lp);
+    if (next_b != 65536) die("%s: the %d parts cover %d of 65536 buckets", prefix.c_str(), n_parts, next_b);
+    FILE *info = fopen((prefix + ".sdbg_info").c_str(), "w");
+    if (!info) die("cannot write %s.sdbg_info", prefix.c_str());
+    fprintf(info, "k %d\nwords_per_tip_label %d\nnum_buckets %d\nnum_threads %d\n", k, wpt, 65536, n_parts);
+    fprintf(info, "total_size %lld\nnum_tips %lld\nlarge_multi %lld\n", total, tips, large);
+    for (const std::string &l : lines) fputs(l.c_str(), info);
+    if (fclose(info) != 0) die("write error on %s.sdbg_info", prefix.c_str());
+    for (int r = 0; r < n_parts; ++r) remove((prefix + ".sdbg_info.part" + std::to_string(r)).c_str());
 }
 
 void read_sdbg(const std::string &prefix, EdgeStream &s) {

@@ -80,6 +80,9 @@ struct EdgeStream {
     std::vector<uint32_t> tips;
 };
 void write_sdbg(const std::string &prefix, const EdgeStream &s);   // one file PREFIX.sdbg.0 + PREFIX.sdbg_info
+// one rank's share of a build over several GPUs: the buckets [b_lo, b_hi) -> PREFIX.sdbg.<file_id> (+ PREFIX.sdbg_info.part<file_id> when `part`)
+void write_sdbg(const std::string &prefix, const EdgeStream &s, int file_id, int b_lo, int b_hi, bool part);
+void merge_sdbg_parts(const std::string &prefix, int n_parts);      // the parts of n_parts ranks -> PREFIX.sdbg_info (num_threads = n_parts)
 void read_sdbg(const std::string &prefix, EdgeStream &s);
 
 // ---- profile HMM --------------------------------------------------------------------------------------

@@ -54,9 +54,14 @@ struct Session {
 };
 static Session g_sess;
 
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+// MEGAGTA_DEVICE: the GPU of this process (a rank of a multi-GPU step is started with its own; default 0)
 static mgta_ctx *ctx_get() {
     if (g_sess.active && g_sess.ctx) return g_sess.ctx;
-    mgta_ctx *ctx = mgta_ctx_create(0);
+    mgta_ctx *ctx = mgta_ctx_create(env_int("MEGAGTA_DEVICE", 0));
     if (!ctx) die("%s", mgta_last_error());
     if (g_sess.active) g_sess.ctx = ctx;
     return ctx;
@@ -92,13 +97,9 @@ static mgta_sdbg *graph_get(mgta_ctx *ctx, const std::string &prefix, int *k_out
         return g;
     }
     graph_drop();
-    EdgeStream s;
-    read_sdbg(prefix, s);
-    mgta_sdbg *g = nullptr;
-    if (mgta_sdbg_load(ctx, s.k, s.recs.data(), (int64_t)s.recs.size(), s.bucket_items.data(), s.tips.data(), (int64_t)s.tips.size(),
-                       s.words_per_tip, &g) != MGTA_OK)
-        die("mgta_sdbg_load: %s", mgta_last_error());
-    *k_out = s.k; *n_edges = s.recs.size();
+    mgta_sdbg *g = nullptr;                                              // the files are copied to the device as they are and parsed there
+    if (mgta_sdbg_load_files(ctx, prefix.c_str(), &g) != MGTA_OK) die("mgta_sdbg_load_files: %s", mgta_last_error());
+    *k_out = mgta_sdbg_k(g); *n_edges = (size_t)mgta_sdbg_size(g);
     return g;
 }
 
@@ -170,6 +171,13 @@ static int main_buildgraph(int argc, char **argv) {
     }
     (void)mem_flag;
     if (min_count < 1) min_count = 1;
+    // A build over several GPUs (`megagta.py --gpus N`): N processes, MEGAGTA_RANK / MEGAGTA_WORLD / MEGAGTA_DEVICE each.  The 65536
+    // prefix buckets are independent once every rank holds the reads (cx1.h:494-590 loops over bucket ranges for the same reason): rank r
+    // builds its share and writes it as PREFIX.sdbg.r, the file a writer thread r of the reference would have written
+    // (sdbg_multi_io.h:83-187); `megagta sdbgmerge PREFIX N` then writes the index.  No data leaves a GPU except into its file.
+    const int world = std::max(1, env_int("MEGAGTA_WORLD", 1)), rank = env_int("MEGAGTA_RANK", 0);
+    if (rank < 0 || rank >= world || world > 65536) die("MEGAGTA_RANK = %d outside MEGAGTA_WORLD = %d", rank, world);
+    const int share = (65536 + world - 1) / world, b_lo = std::min(65536, rank * share), b_hi = std::min(65536, (rank + 1) * share);
 
     double t0 = now_s();
     PackedReads local;
@@ -183,7 +191,8 @@ static int main_buildgraph(int argc, char **argv) {
 
     mgta_ctx *ctx = ctx_get();
     graph_drop();
-    if (g_sess.active) mgta_ctx_keep_stream(ctx, 1);
+    const bool hand_over = g_sess.active && world == 1;
+    if (hand_over) mgta_ctx_keep_stream(ctx, 1);
     // --gpu_mem: device budget in bytes.  Unset, a one-shot process takes 64 GB at most: device memory is mapped at ~27 ms/GB
     // (measured: 194 GB cost 5.3 s before the first kernel ran), which outweighs the few extra bucket-range passes of a tighter budget
     // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  A resident caller (bench, multi-k API) keeps the pool.
@@ -191,16 +200,18 @@ static int main_buildgraph(int argc, char **argv) {
     EdgeStream s;
     s.k = k; s.words_per_tip = (2 * k + 31) / 32;
     mgta_build_stats st;
-    int rc = mgta_sdbg_build(ctx, pr.words.data(), pr.words.size(), pr.start.data(), pr.start.size() - 1, pr.n_short, k, min_count,
-                             min_count > 1 ? need_mercy : 0, sink_collect, &s, &st);
+    mgta_reads *rd = nullptr;
+    if (mgta_reads_upload(ctx, pr.words.data(), pr.words.size(), pr.start.data(), pr.start.size() - 1, &rd) != MGTA_OK) die("mgta_reads_upload: %s", mgta_last_error());
+    int rc = mgta_sdbg_build_resident(ctx, rd, pr.n_short, k, min_count, min_count > 1 ? need_mercy : 0, b_lo, b_hi, sink_collect, &s, &st);
     if (rc != MGTA_OK) die("mgta_sdbg_build: %s", mgta_last_error());
+    mgta_reads_free(rd);
     lib_put(pr, mk);
-    if (g_sess.active) {                                                 // the graph stays on the device for the step that uses it
+    if (hand_over) {                                                     // the graph stays on the device for the step that uses it
         if (mgta_sdbg_load_resident(ctx, &g_sess.graph) != MGTA_OK) die("mgta_sdbg_load_resident: %s", mgta_last_error());
         g_sess.graph_prefix = out_prefix;
         mgta_ctx_keep_stream(ctx, 0);
     }
-    if (min_count > 1) {                                                 // PREFIX.counting (s1_post_proc, cx1_read2sdbg_s1.cpp:923-930)
+    if (min_count > 1 && rank == 0) {                                    // PREFIX.counting (s1_post_proc, cx1_read2sdbg_s1.cpp:923-930); every rank counts all (k+1)-mers
         std::vector<int64_t> hist(65536);
         if (mgta_sdbg_last_counting(ctx, hist.data()) != MGTA_OK) die("%s", mgta_last_error());
         FILE *cf = fopen((out_prefix + ".counting").c_str(), "w");
@@ -213,7 +224,11 @@ static int main_buildgraph(int argc, char **argv) {
     logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
          (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);
     double t1 = now_s();
-    write_sdbg(out_prefix, s);
+    if (world == 1) write_sdbg(out_prefix, s);
+    else {
+        write_sdbg(out_prefix, s, rank, b_lo, b_hi, true);
+        logf("rank %d of %d: buckets [%d, %d) -> %s.sdbg.%d", rank, world, b_lo, b_hi, out_prefix.c_str(), rank);
+    }
     long long nw[9] = {0};
     for (uint16_t r : s.recs) nw[r & 15]++;
     logf("Number of $ A C G T A- C- G- T-:");                           // s2_post_proc, cx1_read2sdbg_s2.cpp:899-915
@@ -259,8 +274,9 @@ static int main_search(int argc, char **argv) {
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
     int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
     if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
-    int cost_rate = -1;                             // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate
-    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) cost_rate = atoi(e);
+    int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (> 0: expansions per seed, < 0: seeds
+    bool cost_rate_set = false;                     // per expansion, 0: no cost term); unset = chosen per gene by its number of seeds
+    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) { cost_rate = atoi(e); cost_rate_set = true; }
     double t0 = now_s();
     logf("Loading SdBG...");
     mgta_ctx *ctx = ctx_get();
@@ -304,7 +320,7 @@ static int main_search(int argc, char **argv) {
         //  200 k / 270 k: 8192 + 2  9.0 / 15.8  (8192 + 4: 10.3 / 16.7;  4096 + 4: 11.8 / 18.2);  414 k: 8192 + 2 14.4 (4096 + 2: 15.4)
         const size_t ns = kmers.size();
         const int window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
-        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate >= 0 ? cost_rate : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= 0");
+        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
@@ -603,6 +619,8 @@ static int main_serve() {
     if (!req || !rep) die("serve: cannot duplicate the standard descriptors");
     const int null_in = open("/dev/null", O_RDONLY);
     dup2(null_in, 0);                                                     // steps never read the request channel
+    dup2(2, 1);                                                           // ... nor write into the reply channel: a step's stdout that no ">PATH" field
+                                                                          // redirects (dumpversion, a stray printf) goes to stderr, never between the DONE lines
     char *line = nullptr;
     size_t cap = 0;
     ssize_t n;
@@ -733,6 +751,11 @@ static int dispatch(int argc, char **argv) {
         double t1 = now_s();
         write_sdbg(argv[3], s);
         logf("%zu records: read %.3f s, write %.3f s", s.recs.size(), t1 - t0, now_s() - t1);
+        return 0;
+    }
+    if (sub == "sdbgmerge") {    // after a build over N GPUs: <prefix> <N> -> PREFIX.sdbg_info naming the N files (host only)
+        if (argc < 4 || atoi(argv[3]) < 1) { fprintf(stderr, "Usage %s <sdbg_prefix> <num_parts>\n", argv[1]); return 1; }
+        merge_sdbg_parts(argv[2], atoi(argv[3]));
         return 0;
     }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }

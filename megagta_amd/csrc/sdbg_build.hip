@@ -2220,7 +2220,7 @@ int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, u
 int mgta_sdbg_export_records_device(mgta_ctx *ctx, void *d_dst, uint64_t capacity_bytes, uint64_t *n_records) {
     if (!ctx || !n_records) { set_error("mgta_sdbg_export_records_device: null argument"); return MGTA_EINVAL; }
     *n_records = ctx->last_n_rec;
-    if (!ctx->last_rec && ctx->last_n_rec) { set_error("no device-resident build output"); return MGTA_EINVAL; }
+    if (ctx->last_k == 0 || (!ctx->last_rec && ctx->last_n_rec)) { set_error("no device-resident build output"); return MGTA_EINVAL; }
     if (!d_dst) return MGTA_OK;                                    // size query
     if (capacity_bytes < ctx->last_n_rec * 2) { set_error("destination too small"); return MGTA_EINVAL; }
     try {

@@ -1,10 +1,11 @@
 """Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
 
 The path shards in two places:
-  * SdBG build: the 65536 prefix buckets are independent once every rank holds the reads -> rank r
-    builds buckets [r*S, (r+1)*S); ONE all-gather of the record shards makes the graph whole everywhere;
-  * A* search: seeds are independent given the (replicated) graph -> seeds are dealt round-robin,
-    ONE all-gather of the contig bytes at the end; rank 0 writes FASTA in seed order.
+  * SdBG build: the 65536 prefix buckets are independent once every rank holds the reads -> rank r builds buckets [r*S, (r+1)*S).
+    Product path (`megagta.py --gpus N`): every rank writes its share as <prefix>.sdbg.<r>, no exchange at all.  bench.py's timed step
+    keeps the whole stream on every GPU instead: ONE device-to-device all-gather of the record shards (`all_gather_record_shards`);
+  * A* search: seeds are independent given the (replicated) graph -> seeds shard by GENE first, then round-robin inside a gene
+    (`gene_seed_share`); ONE all-gather of the contig bytes at the end (`all_gather_packed_contigs`); rank 0 writes FASTA in seed order.
 No collective runs inside any kernel.  Works with any backend (gloo on CPU tensors in the tests).
 """
 from __future__ import annotations
@@ -13,7 +14,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .api import NUM_BUCKETS, EdgeStream
+from .api import NUM_BUCKETS
 
 
 def bucket_share(rank: int, world: int) -> tuple[int, int]:
@@ -25,54 +26,44 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def _all_gather_var(arr: np.ndarray, group=None) -> list[np.ndarray]:
-    """all-gather of variable-length 1-D arrays: lengths first, then payloads (as bytes) padded to the maximum"""
+def all_gather_bytes(flat: torch.Tensor, group=None) -> list[torch.Tensor]:
+    """all-gather of uint8 tensors of different lengths (they stay where they are: device tensors over RCCL, CPU tensors over gloo):
+    an 8-byte all-gather tells the sizes, then ONE all-gather of the payloads padded to the longest"""
     world = dist.get_world_size(group)
-    dev = _dev()
-    flat = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).copy()).to(dev)
-    n = torch.tensor([flat.numel()], dtype=torch.int64, device=dev)
+    n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
     ns = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(ns, n, group=group)
     sizes = [int(x.item()) for x in ns]
-    mx = max(max(sizes), 1)
-    pad = torch.zeros(mx, dtype=flat.dtype, device=dev)
+    pad = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=flat.device)
     pad[: flat.numel()] = flat
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
-    return [o[:s].cpu().numpy().view(arr.dtype).copy() for o, s in zip(out, sizes)]
+    return [o[:s] for o, s in zip(out, sizes)]
 
 
-def all_gather_edge_stream(local: EdgeStream, group=None) -> EdgeStream:
-    """Every rank passes the stream of ITS bucket range (other buckets empty); every rank gets the whole stream."""
-    world = dist.get_world_size(group)
-    recs = _all_gather_var(local.records, group)
-    large = _all_gather_var(local.large, group)
-    tips = _all_gather_var(local.tips, group)
-    counts = np.stack([local.bucket_items, local.bucket_large if local.bucket_large is not None else np.zeros(NUM_BUCKETS, np.int64),
-                       local.bucket_tips if local.bucket_tips is not None else np.zeros(NUM_BUCKETS, np.int64)]).astype(np.int64)
-    t = torch.from_numpy(counts).to(_dev())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)          # shards are disjoint in bucket space
-    counts = t.cpu().numpy()
-    return EdgeStream(k=local.k, words_per_tip=local.words_per_tip, bucket_items=counts[0], records=np.concatenate(recs),
-                      large=np.concatenate(large), tips=np.concatenate(tips), bucket_large=counts[1], bucket_tips=counts[2])
-
-
-def seed_share(n_seeds: int, rank: int, world: int) -> np.ndarray:
-    return np.arange(rank, n_seeds, world, dtype=np.int64)
+def all_gather_record_shards(shard: torch.Tensor, group=None) -> torch.Tensor:
+    """Every rank passes the records of ITS bucket range (uint8 view of the uint16 records, on its device); every rank gets the whole
+    stream in bucket order (ranks own ascending bucket ranges).  The shard never visits the host."""
+    return torch.cat(all_gather_bytes(shard, group))
 
 
 def gene_seed_share(seeds_per_gene: list[int], rank: int, world: int) -> list[np.ndarray]:
     """Seeds shard by GENE first, then round-robin inside a gene (BASELINE.json north_star): with at least as many
     ranks as genes every gene gets a group of ranks (sizes proportional to its seeds, at least one each) and its seeds are dealt
-    round-robin inside the group, so a rank stages ONE gene's HMM tables; with fewer ranks than genes whole genes are dealt round-robin
-    over the ranks.  Returns, per gene, the seed indices this rank runs (ascending; empty for genes it does not take)."""
+    round-robin inside the group, so a rank stages ONE gene's HMM tables; with fewer ranks than genes whole genes are dealt to the
+    ranks, heaviest first onto the rank with the fewest seeds so far (5 genes on 4 GPUs: the two lightest share a rank).
+    Returns, per gene, the seed indices this rank runs (ascending; empty for genes it does not take)."""
     n_genes = len(seeds_per_gene)
     out = [np.zeros(0, dtype=np.int64) for _ in range(n_genes)]
     if n_genes == 0:
         return out
     if world < n_genes:
-        for g in range(rank, n_genes, world):
-            out[g] = np.arange(seeds_per_gene[g], dtype=np.int64)
+        load = [0] * world
+        for g in sorted(range(n_genes), key=lambda x: (-seeds_per_gene[x], x)):
+            r = min(range(world), key=lambda x: (load[x], x))
+            load[r] += seeds_per_gene[g]
+            if r == rank:
+                out[g] = np.arange(seeds_per_gene[g], dtype=np.int64)
         return out
     total = max(1, sum(seeds_per_gene))
     size = [1] * n_genes                                             # ranks per gene: one each, the rest by share of the seeds
@@ -87,24 +78,47 @@ def gene_seed_share(seeds_per_gene: list[int], rank: int, world: int) -> list[np
     return out
 
 
-def all_gather_contigs(n_seeds: int, mine: np.ndarray, contigs: list[str], group=None) -> list[str]:
-    """mine[i] = global seed index of contigs[i]; returns all contigs in seed order on every rank.  The path's one exchange: ONE
-    all-gather of a length-prefixed byte buffer per rank ([n][seed index, length]*n[bytes]), padded to the longest (a second, 8-byte
-    all-gather tells the sizes)."""
+def all_gather_packed_contigs(n_seeds: int, mine: np.ndarray, contigs: np.ndarray, offsets: np.ndarray, group=None) -> tuple[np.ndarray, np.ndarray]:
+    """mine[i] = global seed index of this rank's contig i = contigs[offsets[i]:offsets[i+1]] (uint8).  Returns (contigs, offsets) of
+    ALL seeds in seed order on every rank.  The path's one exchange: ONE all-gather of a length-prefixed byte buffer per rank
+    ([n][seed index, length] * n [bytes]), padded to the longest (an 8-byte all-gather tells the sizes).  No Python work per seed:
+    the merge is numpy gathers over pieces of at most 64 MB."""
     mine = np.asarray(mine, dtype=np.int64)
-    enc = [c.encode() for c in contigs]
+    offsets = np.asarray(offsets, dtype=np.int64)
     head = np.empty(1 + 2 * mine.size, dtype=np.int64)
     head[0] = mine.size
     head[1::2] = mine
-    head[2::2] = [len(b) for b in enc]
-    blob = np.concatenate([head.view(np.uint8), np.frombuffer(b"".join(enc), dtype=np.uint8)])
-    out = [""] * n_seeds
-    for b in _all_gather_var(blob, group):
+    head[2::2] = np.diff(offsets)
+    blob = np.concatenate([head.view(np.uint8), np.ascontiguousarray(contigs, dtype=np.uint8)[: int(offsets[-1]) if offsets.size else 0]])
+    parts = [p.cpu().numpy() for p in all_gather_bytes(torch.from_numpy(blob).to(_dev()), group)]
+    lens = np.zeros(n_seeds, dtype=np.int64)
+    heads = []
+    for b in parts:
         n = int(b[:8].view(np.int64)[0])
         h = b[8:8 + 16 * n].view(np.int64)
-        pos = 8 + 16 * n
-        for j in range(n):
-            ln = int(h[2 * j + 1])
-            out[int(h[2 * j])] = b[pos:pos + ln].tobytes().decode()
-            pos += ln
-    return out
+        heads.append((n, h[0::2], h[1::2]))
+        lens[h[0::2]] = h[1::2]
+    out_off = np.zeros(n_seeds + 1, dtype=np.int64)
+    np.cumsum(lens, out=out_off[1:])
+    out = np.empty(int(out_off[-1]), dtype=np.uint8)
+    for b, (n, idx, ln) in zip(parts, heads):
+        if n == 0:
+            continue
+        src = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(ln, out=src[1:])
+        src += 8 + 16 * n
+        i = 0
+        while i < n:                                                 # pieces of <= 64 MB of contig bytes
+            j = int(np.searchsorted(src, src[i] + (64 << 20), side="right")) - 1
+            j = min(n, max(j, i + 1))
+            shift = np.repeat(out_off[idx[i:j]] - src[i:j], ln[i:j])
+            pos = np.arange(src[i], src[j], dtype=np.int64)
+            out[pos + shift] = b[pos]
+            i = j
+    return out, out_off
+
+
+def contig_list(contigs: np.ndarray, offsets: np.ndarray) -> list[str]:
+    """(tests, small batches) the packed form as Python strings"""
+    raw = contigs.tobytes()
+    return [raw[int(a):int(b)].decode() for a, b in zip(offsets[:-1], offsets[1:])]

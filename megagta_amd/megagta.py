@@ -32,8 +32,9 @@ USAGE = """Usage:
     -m/--memory 0.9        -t/--num-cpu-threads N   --min-contig-len 450   --max-tip-len 150
     --no-mercy  --mem-flag 1  --gpu-mem BYTES  --keep-tmp-files  --continue  --verbose
     --bin PATH       the multi-call `megagta` executable (default: this package's bin/megagta)
-    --gpus N         GPUs of this node for the search step: one process per GPU (torch.distributed over RCCL), seeds sharded by gene
-                     first, one all-gather of contigs (megagta_amd/search_dist.py); every other step runs on GPU 0
+    --gpus N         GPUs of this node.  `search`: one process per GPU (torch.distributed over RCCL), seeds sharded by gene first, one
+                     all-gather of contigs (megagta_amd/search_dist.py).  `buildgraph`: one process per GPU, each builds its share of the
+                     65536 prefix buckets and writes it as <prefix>.sdbg.<rank> (no exchange at all).  denovo / findstart run on GPU 0
     --one-process-per-step   start every step as its own process, as the reference driver does (default: one worker process,
                      `megagta serve`, runs all steps and keeps the device context, the read library and the last graph between them)"""
 
@@ -240,12 +241,21 @@ class Worker:
         try:
             self.p.stdin.write(("\t".join(fields) + "\n").encode())
             self.p.stdin.flush()
-            reply = self.p.stdout.readline().decode().split()
+            while True:                          # anything that is not the reply (there should be nothing: the worker keeps its steps'
+                raw = self.p.stdout.readline()   # stdout off this pipe) is logged and skipped; an empty read = the worker is gone
+                reply = raw.decode(errors="replace").split()
+                if not raw or (len(reply) == 2 and reply[0] == "DONE"):
+                    break
+                logging.debug("worker: " + raw.decode(errors="replace").rstrip())
         except (BrokenPipeError, OSError):
             reply = []
         if len(reply) == 2 and reply[0] == "DONE":
             return int(reply[1])
-        ret = self.p.wait()                      # the worker died in the step (a fatal error prints its reason and exits)
+        try:                                     # the worker died in the step (a fatal error prints its reason and exits)
+            ret = self.p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            self.p.kill()
+            ret = self.p.wait()
         return ret if ret != 0 else 1
 
     def close(self):
@@ -339,8 +349,54 @@ def build_graph(k, assist):
             cmd.append("--need_mercy")
         if assist:
             cmd += ["--assist_seq", assist]
-        run_step(cmd, "Building sdbg for k = %d" % k)
+        if opt.gpus > 1:
+            run_multi_gpu_build(cmd, k)
+        else:
+            run_step(cmd, "Building sdbg for k = %d" % k)
     write_cp()
+
+
+def fail_step(what, ret):
+    logging.error("Error occurs when %s, please refer to %s for detail" % (what, log_file()))
+    logging.error("[Exit code %d]" % ret)
+    if worker is not None:
+        worker.close()
+    sys.exit(ret)
+
+
+def release_worker_memory():
+    """the worker hands its device memory back before other processes use GPU 0; a worker that cannot answer is dropped"""
+    global worker
+    if worker is not None and worker.request(["release"]) != 0:
+        logging.debug("the worker did not release its memory: it is stopped, the remaining steps run one process each")
+        worker.close()
+        worker = None
+
+
+def run_multi_gpu_build(cmd, k):
+    """`buildgraph` over opt.gpus GPUs: the same command line once per GPU (MEGAGTA_RANK / MEGAGTA_WORLD / MEGAGTA_DEVICE), every rank
+    builds its share of the prefix buckets into <prefix>.sdbg.<rank>; `sdbgmerge` then writes the index that names the files"""
+    what = "Building sdbg for k = %d on %d GPUs" % (k, opt.gpus)
+    logging.info("--- [%s] %s ---" % (datetime.now().strftime("%c"), what))
+    release_worker_memory()
+    logging.debug("cmd (x%d ranks): %s" % (opt.gpus, " ".join(cmd)))
+    procs = []
+    for r in range(opt.gpus):
+        # rank r on GPU r (MEGAGTA_DEVICE in the environment: every rank on that device -- tests on a one-GPU box)
+        env = dict(os.environ, MEGAGTA_RANK=str(r), MEGAGTA_WORLD=str(opt.gpus), MEGAGTA_DEVICE=os.environ.get("MEGAGTA_DEVICE", str(r)))
+        procs.append(subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL))
+    relays = [threading.Thread(target=lambda p=p: [logging.debug(l.decode(errors="replace").rstrip()) for l in p.stderr], daemon=True) for p in procs]
+    for t in relays:
+        t.start()
+    rets = [p.wait() for p in procs]
+    for t in relays:
+        t.join(timeout=5)
+    bad = [r for r in rets if r != 0]
+    if bad:
+        fail_step("running %s" % what, bad[0])
+    ret = subprocess.call([opt.bin, "sdbgmerge", graph_prefix(k), str(opt.gpus)])
+    if ret != 0:
+        fail_step("merging the index of the %d graph files" % opt.gpus, ret)
 
 
 def assemble(k):
@@ -366,26 +422,17 @@ def find_seed(k, gene):
 def run_multi_gpu_search(par, k):
     """the search step on opt.gpus GPUs: its own processes (one per GPU), same arguments and files as `megagta search`"""
     logging.info("--- [%s] Searching contigs for k = %d on %d GPUs ---" % (datetime.now().strftime("%c"), k, opt.gpus))
-    if worker is not None:
-        worker.request(["release"])                      # the worker gives its device memory back while the ranks run
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opt.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "search_dist.py")] + par
+    release_worker_memory()                              # the worker gives its device memory back while the ranks run
+    # torchrun picks the rendezvous port itself (--standalone = c10d on a free port of this host): nothing to race for
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(opt.gpus),
+           os.path.join(os.path.dirname(os.path.abspath(__file__)), "search_dist.py")] + par
     logging.debug("cmd: " + " ".join(cmd))
     p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
     for line in p.stderr:
         logging.debug(line.decode(errors="replace").rstrip())
     ret = p.wait()
     if ret != 0:
-        logging.error("Error occurs when searching contigs for k = %d on %d GPUs, please refer to %s for detail" % (k, opt.gpus, log_file()))
-        logging.error("[Exit code %d]" % ret)
-        if worker is not None:
-            worker.close()
-        sys.exit(ret)
+        fail_step("searching contigs for k = %d on %d GPUs" % (k, opt.gpus), ret)
 
 
 def search_contigs(k):

@@ -8,10 +8,12 @@ Same positional arguments, inputs and outputs as `megagta search` (search.cpp:72
 
 (the driver does this for `megagta.py --gpus N`; with N = 1 it keeps the plain `megagta search`).  What replaces the reference's OpenMP
 loop over seeds (search.cpp:184-189) across GPUs:
-  * the graph (`<sdbg_prefix>.sdbg.*`) and the gene's two HMMs are replicated: every rank loads them onto its own GPU;
+  * the graph (`<sdbg_prefix>.sdbg.*`) and the gene's two HMMs are replicated: every rank copies the files to its own GPU and parses the
+    records there (`mgta_sdbg_load_files`; seconds for a graph of 630 M edges, no Python work per record);
   * seeds shard by GENE first, then round-robin inside a gene (`dist.gene_seed_share`): with N >= #genes every rank works on one gene;
   * every rank runs its seeds with the ordered-commit window over ITS sub-sequence of the seeds (MEGAGTA_CACHE_WINDOW /
-    MEGAGTA_CACHE_COST_RATE; defaults as `megagta search`: window 1024 .. 8192 and cost term 4 or 2 by the number of the rank's seeds):
+    MEGAGTA_CACHE_COST_RATE, read exactly as `megagta search` reads them; defaults: window 1024 .. 8192 and cost term 4 or 2 by the number
+    of the rank's seeds):
     seed j of a rank sees the paths of that rank's seeds <= j - B.  The result is a function of (seed order, N, B), never of timing;
     N = 1 is exactly `megagta search`;
   * ONE all-gather of the contig bytes per gene (RCCL over xGMI; gloo in the CPU tests), then rank 0 writes
@@ -23,6 +25,8 @@ from __future__ import annotations
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -54,8 +58,24 @@ def read_seeds(path: str) -> tuple[list[str], list[int]] | None:
     return kmers, states
 
 
-def fasta_text(gene: str, kmers: list[str], contigs: list[str]) -> str:
-    return "".join(f">{gene}_contig_{2 * i}_contig_{2 * i + 1}\n{c}\n" for i, c in enumerate(contigs))
+def write_fasta(path: str, gene: str, contigs, offsets) -> None:
+    """`<output_prefix>_raw_contigs_<gene>.fasta` with the reference's record names (hmm_graph_search.h:79), contigs in seed order"""
+    mv = memoryview(contigs)
+    g = gene.encode()
+    with open(path, "wb", buffering=1 << 22) as f:
+        for i in range(len(offsets) - 1):
+            f.write(b">%s_contig_%d_contig_%d\n" % (g, 2 * i, 2 * i + 1))
+            f.write(mv[offsets[i]:offsets[i + 1]])
+            f.write(b"\n")
+
+
+def window_and_rate(n_seeds: int) -> tuple[int, int]:
+    """as `megagta search` (csrc/host/megagta_main.cpp): the ordered-commit window and the cost term by the number of seeds the batch
+    holds; MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE override (any integer >= -64 for the rate: < 0 = seeds per expansion)"""
+    w, r = os.environ.get("MEGAGTA_CACHE_WINDOW"), os.environ.get("MEGAGTA_CACHE_COST_RATE")
+    window = int(w) if w not in (None, "", "-2") else 1024 if n_seeds < 32768 else 2048 if n_seeds < 65536 else 4096 if n_seeds < 196608 else 8192
+    rate = int(r) if r not in (None, "") else (4 if n_seeds < 65536 else 2)
+    return window, rate
 
 
 def main(argv: list[str]) -> int:
@@ -66,7 +86,6 @@ def main(argv: list[str]) -> int:
     sdbg_prefix, gene_list, seeds_prefix, out_prefix = argv[1:5]
     prune, pen = int(argv[5]), float(argv[6])
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    window_env = os.environ.get("MEGAGTA_CACHE_WINDOW")
     import torch
     import torch.distributed as dist
     from megagta_amd import api, dist as mdist, hmm as hmmlib
@@ -83,7 +102,7 @@ def main(argv: list[str]) -> int:
             dist.init_process_group(backend, rank=rank, world_size=world)
     t0 = time.time()
     ctx = api.Context(device)
-    graph = api.Graph(ctx, api.read_sdbg(sdbg_prefix))
+    graph = api.Graph.from_files(ctx, sdbg_prefix)
     if rank == 0:
         print(f"    [megagta_amd] rank 0 of {world}: graph of {graph.size} edges on the device ({time.time() - t0:.2f} s)", file=sys.stderr, flush=True)
     genes = read_gene_list(gene_list)
@@ -98,22 +117,18 @@ def main(argv: list[str]) -> int:
         kmers, states = seeds[gi]
         mine = share[gi]
         tg = time.time()
-        contigs, nexp = [], 0
+        contigs, offsets, nexp = np.zeros(0, np.uint8), np.zeros(1, np.int64), 0
         if mine.size:
             fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fwd)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rev))
-            # as `megagta search` (megagta_main.cpp: window and cost term by the number of seeds); per rank: over its own seeds
-            ns = int(mine.size)
-            window = int(window_env) if window_env is not None else 1024 if ns < 32768 else 2048 if ns < 65536 else 4096 if ns < 196608 else 8192
-            rate = int(os.environ["MEGAGTA_CACHE_COST_RATE"]) if "MEGAGTA_CACHE_COST_RATE" in os.environ else (4 if ns < 65536 else 2)
-            res, st = api.astar_search(graph, fw, rv, [kmers[i] for i in mine], [states[i] for i in mine], prune, pen, cache_mode=window,
-                                       cost_rate=rate)
-            contigs = [r.contig(kmers[i]) for r, i in zip(res, mine.tolist())]
+            window, rate = window_and_rate(int(mine.size))            # per rank: over its own sub-sequence of the seeds
+            contigs, offsets, st = api.astar_search_packed(graph, fw, rv, [kmers[i] for i in mine], [states[i] for i in mine], prune, pen,
+                                                           cache_mode=window, cost_rate=rate)
             nexp = st["n_expansions"]
             fw.free(); rv.free()
-        every = mdist.all_gather_contigs(len(kmers), mine, contigs) if world > 1 else contigs
+        if world > 1:
+            contigs, offsets = mdist.all_gather_packed_contigs(len(kmers), mine, contigs, offsets)
         if rank == 0:
-            with open(f"{out_prefix}_raw_contigs_{name}.fasta", "w") as f:
-                f.write(fasta_text(name, kmers, every))
+            write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
             print(f"    [megagta_amd] Done {name}: {len(kmers)} seeds over {world} rank(s), rank 0: {mine.size} seeds, {nexp} expansions, "
                   f"{time.time() - tg:.2f} s", file=sys.stderr, flush=True)
     graph.free()

@@ -79,7 +79,8 @@ def main():
     json.dump(streams, open(f"{toy}/sdbg_streams.json", "w"), indent=0)
     # stage 1 (solid-edge counting, -m >= 2) with and without mercy edges (cx1_read2sdbg_s1.cpp, s2.cpp:106-250)
     solid = {}
-    for k, m, mercy in ((29, 2, False), (29, 2, True), (44, 2, False), (44, 2, True), (44, 3, True), (35, 4, True)):
+    for k, m, mercy in ((29, 2, False), (29, 2, True), (44, 2, False), (44, 2, True), (44, 3, True), (35, 4, True),
+                        (111, 2, True), (120, 2, False), (127, 2, True)):      # 10- / 11-word sort records, up to kMaxK (definitions.h:56)
         tag = f"k{k}_m{m}_{'mercy' if mercy else 'nomercy'}"
         buildgraph(f"{tmp}/reads.lib", f"{tmp}/s1_{tag}/{k}", k, extra=(("--need_mercy",) if mercy else ()), m=m)
         fx = stream_fixture(f"{tmp}/s1_{tag}/{k}")

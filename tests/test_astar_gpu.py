@@ -218,6 +218,40 @@ def test_window_mode_grows_in_place_instead_of_failing(ctx):
             assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
 
 
+def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
+    """ordered-commit window + a pool far too small for the searches in flight: a starved search gives its memory back and starts again
+    IN PLACE (its slot keeps holding the window), the lowest running seed is never the one to yield -- the contigs, scores and
+    expansion counts are those of the run with all the room, whatever starved when (advisor r2: re-runs after the pass saw other paths)"""
+    from megagta_amd import api
+    import tempfile
+    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_gene_models(mg.genes, td)
+        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
+        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
+        g = api.Graph(ctx, stream)
+        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+        seen_yield, sizes = False, []
+        for window, rate in ((8, 0), (64, 4)):
+            want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
+            assert st0["n_retries"] == 0
+            try:
+                for kb in (256, 1024, 4096, 16384):
+                    ctx.set_search_arena(7, kb << 10)
+                    got, st = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)
+                    sizes.append((window, kb, st["n_retries"]))
+                    seen_yield |= st["n_retries"] > 0
+                    assert st["n_expansions"] == st0["n_expansions"], sizes
+                    for a, b, km in zip(got, want, kmers):
+                        assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side, sizes
+            finally:
+                ctx.set_search_arena(0, 0)
+        assert seen_yield, sizes
+
+
 @pytest.mark.parametrize("M,k1,prune,pen,seed", [(60, 30, 20, 0.5, 1), (90, 36, 0, 0.5, 2), (150, 45, 20, 0.0, 3), (75, 45, 5, 2.0, 4),
                                                    (200, 36, 20, 0.5, 5), (48, 30, 3, 0.25, 6)])
 def test_fuzz_genes_k_and_search_options_vs_oracle(ctx, oracle, tmp_path, M, k1, prune, pen, seed):
