@@ -15,8 +15,9 @@ One JSON line on rank 0: metric / value / unit per BASELINE.json;
   `roofline`     the dominant kernel of the build (algorithmic bytes / HIP-event duration measured inside the library on its own stream);
   `search`       the A* leg on the graph of that build (graph + HMMs replicated; seeds shard by gene, then round-robin; one all-gather
                  of contigs): expansions/s, achieved bytes/s against the measured random-line ceiling;
-  `e2e`          reads.fa -> contigs through the driver (`megagta.py -k 30,36,45`, rplB + nirK) on a bounded sample, next to the
-                 reference binary on the same files;
+  `e2e`          reads.fa -> contigs through the driver (`megagta.py -k 30,36,45`, rplB + nirK) on a bounded sample (2 M reads), next to the
+                 reference binary behind the same driver on the SAME files (`speedup_same_sample`);
+  `parity_1M`    the device's edge stream of the CPU-baseline sample against the reference binary's .sdbg files of it (bit-exact or not);
   `cpu_baseline` the reference `buildgraph` (kind "reference") or the oracle port on this box's host cores, bounded sample.
 """
 from __future__ import annotations
@@ -47,7 +48,24 @@ def b_build(k: int, L: int, edges_per_kmer: float) -> float:
     return 2 * 2 * 4 * W + 0.25 * L / (L - k) + 2 * edges_per_kmer
 
 
-def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int) -> dict:
+def parity_vs_reference_graph(ctx, sample: np.ndarray, k: int, ref_prefix: str) -> dict:
+    """the reference's `buildgraph` output of the CPU-baseline sample (its .sdbg files, decoded by the oracle's reader --
+    the checker, outside every timed region) against the edge stream the device builds from the same reads: bit-exact or not."""
+    from megagta_amd import synth
+    from oracle import oracle as O
+    packed, start = synth.pack_reads_for_build(sample)
+    rd = ctx.upload_reads(packed, start)
+    t = time.time()
+    ours = ctx.build_sdbg(rd, k)
+    dt = time.time() - t
+    rd.free()
+    ref = O.Stream.read(ref_prefix).edges()
+    return {"reads": int(sample.shape[0]), "edges": int(ours.records.size), "edges_reference": int(ref.records.size), "tips": int(ours.tips.size // max(1, ours.words_per_tip)),
+            "md5_equal": ours.md5() == ref.md5(), "md5": ours.md5(), "device_build_ms": ours.stats["ms_total"], "device_build_and_copy_s": dt,
+            "note": "edge stream (bucket sizes, records, large multiplicities, tip labels) of the CPU-baseline sample: device vs the reference binary's .sdbg files"}
+
+
+def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int, ctx=None) -> dict:
     from megagta_amd import synth
     n = min(sample_reads, reads.shape[0])
     sample = reads[:n]
@@ -68,9 +86,15 @@ def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int) -> dict:
                 if best is None or dt < best[0]:
                     best = (dt, threads)
             dt, threads = best
-            return {"value": n_kmers / dt / 1e9, "unit": "Gk-mer/s", "cores": threads, "kind": "reference",
-                    "sample": f"first {n} reads x {reads.shape[1]} bp of the same set, graph k={k}, `megagta buildgraph` "
-                              f"(reads.lib.bin -> .sdbg files, {dt:.2f} s wall incl. file I/O; best of 16 / 64 threads)"}
+            out = {"value": n_kmers / dt / 1e9, "unit": "Gk-mer/s", "cores": threads, "kind": "reference",
+                   "sample": f"first {n} reads x {reads.shape[1]} bp of the same set, graph k={k}, `megagta buildgraph` "
+                             f"(reads.lib.bin -> .sdbg files, {dt:.2f} s wall incl. file I/O; best of 16 / 64 threads)"}
+            if ctx is not None:
+                try:
+                    out["_parity"] = parity_vs_reference_graph(ctx, sample, k, os.path.join(tmp, f"g{threads}"))
+                except Exception as e:                                   # the baseline number must not die with the check
+                    out["_parity"] = {"error": str(e)[-400:]}
+            return out
         from oracle import oracle as O
         packed, start = synth.pack_reads_for_build(sample)
         threads = min(cores, 32)
@@ -148,22 +172,72 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                                            "note": "MEGAGTA_CACHE_WINDOW=-1: every search sees whatever paths are in the cache when it looks, as the "
                                                    "reference's multi-thread `search` does; which of several equally scored paths a seed takes depends on timing"}
         if n_ref > 0 and os.path.exists(REF):
-            best = None
-            for threads in sorted({min(cores, 32), cores}):
-                dtr, ncr = run(n_ref, f"ref_t{threads}", ["--bin", REF, "-t", str(threads)])
+            # the reference binary behind the same driver.  Its best thread count is found on the small set (16 / 32 / 64; every core was
+            # 3.7x slower than 32 in round 2), then it runs ONCE on the SAME files as ours above: one equal-work ratio, nothing else
+            sweep = {}
+            for threads in sorted({min(cores, 16), min(cores, 32), min(cores, 64)}):
+                dtr, _ = run(n_ref, f"ref_small_t{threads}", ["--bin", REF, "-t", str(threads)])
+                sweep[threads] = dtr
                 note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
-                if best is None or dtr < best[0]:
-                    best = (dtr, threads, ncr)
-            dto, nco = run(n_ref, "ours_small", ["-t", str(min(cores, 16))])
-            out["reference"] = {"reads": n_ref, "seconds": best[0], "threads": best[1], "reads_per_s": n_ref / best[0], "contigs": best[2],
-                                "note": "the reference binary behind the same driver on the same files; best of 32 / all threads "
-                                        "(8 threads were slower in every run kept under profiles/)"}
-            out["ours_same_sample"] = {"reads": n_ref, "seconds": dto, "contigs": nco}
-            out["speedup_same_sample"] = best[0] / dto
-            out["speedup_reads_per_s"] = (n_ours / dt) / (n_ref / best[0])
+            best_t = min(sweep, key=sweep.get)
+            out["reference_thread_sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
+            dtr, ncr = run(n_ours, f"ref_t{best_t}", ["--bin", REF, "-t", str(best_t)])
+            note(f"e2e reference, {best_t} threads: {n_ours} reads in {dtr:.1f} s")
+            out["reference"] = {"reads": n_ours, "seconds": dtr, "threads": best_t, "reads_per_s": n_ours / dtr, "contigs": ncr,
+                                "note": "the reference binary behind the same driver on the SAME files as `ours`; thread count = the best of "
+                                        "16 / 32 / 64 on the small set"}
+            out["speedup_same_sample"] = dtr / dt
+            if "ours_unordered_cache" in out:
+                out["speedup_same_sample_unordered_cache"] = dtr / out["ours_unordered_cache"]["seconds"]
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def product_seed_list(hits: np.ndarray, sample: np.ndarray, words, model_pos, k: int) -> list[tuple[str, int]]:
+    """(k-mer, 1-based model position) of the hits that fall into the reads of `sample` (uint8 codes [n, L], as sequenced): unique by
+    k-mer, sorted -- the lines `megagta findstart` would write for those reads (fast_kmer_filter.cpp:181-188), built with numpy"""
+    n, L = sample.shape
+    h = hits[hits["read"] < n]
+    if h.size == 0:
+        return []
+    pos, strand = (h["pos_strand"] >> 1).astype(np.int64), (h["pos_strand"] & 1).astype(bool)
+    ar = np.arange(k, dtype=np.int64)
+    col = pos[:, None] + ar[None, :]
+    col = np.where(strand[:, None], L - 1 - col, col)
+    km = sample[h["read"].astype(np.int64)[:, None], col]
+    km = np.where(strand[:, None], 3 - km, km).astype(np.uint8)
+    uniq, first = np.unique(km, axis=0, return_index=True)             # lexicographic row order = the sorted file
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[uniq]
+    refs = h["ref"][first]
+    return [(text[i].tobytes().decode(), int(model_pos[int(refs[i])])) for i in range(uniq.shape[0])]
+
+
+def contig_membership(graph, last_contigs: dict, k: int, n_sample: int = 200_000) -> dict:
+    """Every contig the search returns is a walk in the graph: a sample of the (k+1)-mers of the returned contigs (seed-only contigs
+    left out: a seed no read covers is returned as it is) looked up with IndexBinarySearchEdge on the device.  At 100 M reads most edge
+    ids lie beyond 2^32: the check that catches what only shows at that size (a launch of more than 2^32 work-items, 32-bit ids)."""
+    rng = np.random.default_rng(5)
+    rows = []
+    for cont, offs in last_contigs.values():
+        lens = np.diff(offs)
+        ok = np.nonzero(lens > k + 1)[0]
+        if ok.size == 0:
+            continue
+        c = rng.choice(ok, size=min(n_sample // max(1, len(last_contigs)), ok.size * 4))
+        p = (rng.random(c.size) * (lens[c] - k)).astype(np.int64)
+        rows.append(cont[(offs[c] + p)[:, None] + np.arange(k + 1)[None, :]])
+    if not rows:
+        return {"sampled": 0}
+    km = np.concatenate(rows)
+    code = np.zeros(256, np.uint8)
+    for ch, v in ((b"a", 1), (b"c", 2), (b"g", 3), (b"t", 4), (b"A", 1), (b"C", 2), (b"G", 3), (b"T", 4)):
+        code[ch[0]] = v
+    seqs = np.ascontiguousarray(code[km])
+    ids = np.empty(seqs.shape[0], dtype=np.int64)
+    from megagta_amd._lib import check
+    check(graph.ctx._L.mgta_sdbg_index_edges(graph.h, seqs.ctypes.data, seqs.shape[0], ids.ctypes.data), "mgta_sdbg_index_edges")
+    return {"sampled": int(ids.size), "found": int((ids >= 0).sum()), "ids_above_2^32": int((ids >= 2 ** 32).sum()), "max_edge_id": int(ids.max())}
 
 
 def random_line_ceiling(torch, n_lines: int = 1 << 26, probes: int = 1 << 26) -> float:
@@ -203,7 +277,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--seeds", type=int, default=60000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
-    ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="sample the reference binary is timed on in that leg (0 = skip)")
+    ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="small set on which the reference's thread count is chosen before it runs on the e2e set (0 = no reference run)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -297,22 +371,27 @@ def main():
         ctx.release_scratch()                           # the build's key buffers make room for the searches' pool
         td = tempfile.mkdtemp(prefix="mgta_bench_")
         synth.write_gene_models(mg.genes, td)
-        hm, seeds = [], []
+        hm, seeds, product_seeds = [], [], []
         fs_ms, fs_hits = 0.0, 0
         for gi, gene in enumerate(mg.genes):
             d = os.path.join(td, gene.name)
             hm.append((api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "for_enone.hmm"))), api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "rev_enone.hmm")))))
             seeds.append(synth.synthetic_seeds(gene, args.k, args.seeds, seed=4 + gi))
             # seed finder (row f-2) on the reads already resident for the build: kernel time of one scan per gene
-            fwords, _ = fsm.reference_words(os.path.join(d, "ref_aligned.faa"), args.k // 3)
+            fwords, _fpos = fsm.reference_words(os.path.join(d, "ref_aligned.faa"), args.k // 3)
             fhits, fms = fsm.find_hits(ctx, rd, True, args.k, fsm.pack_words(fwords, args.k // 3))
             fs_ms += fms
             fs_hits += int(fhits.size)
+            # the product's seeds of the reads the host holds a copy of (the CPU-baseline sample): unique k-mers in sorted order, as
+            # `megagta findstart` writes them, for the product-mode search leg below
+            product_seeds.append(product_seed_list(fhits, mg.sample_reads, fwords, _fpos, args.k) if rank == 0 and world == 1 else [])
+            del fhits
         findstart_leg = {"ms_kernel": fs_ms, "windows_per_s": len(mg.genes) * args.reads * (L - args.k + 1) * 2 / (fs_ms * 1e-3), "hits": fs_hits,
                          "note": "mgta_findstart, both strands, k=%d, one scan per gene (%d genes)" % (args.k, len(mg.genes))}
         shutil.rmtree(td, ignore_errors=True)
         note(f"seed scans: {fs_ms:.1f} ms, {fs_hits} hits; {sum(len(x) for x in seeds)} synthetic seeds")
         share = mdist.gene_seed_share([len(s) for s in seeds], rank, world)
+        last_contigs = {}
 
         def sstep(genes=None):
             tot = {"n_expansions": 0, "ms_kernel": 0.0, "n_retries": 0, "n_grown": 0, "pool_used": 0}
@@ -327,6 +406,8 @@ def main():
                     tot["pool_used"] = max(tot["pool_used"], st["pool_used"])
                 if world > 1:
                     mdist.all_gather_packed_contigs(len(seeds[gi]), mine, cont, offs)
+                elif len(mine):
+                    last_contigs[gi] = (cont, offs)
             return tot
 
         # warm-up: the first gene alone at 100 M reads (it obtains the pool at its full size and loads the kernels; a whole step takes
@@ -363,6 +444,30 @@ def main():
                                   "achieved": rate * 510 / 1e9, "peak": ceiling, "unit": "GB/s", "frac": rate * 510 / 1e9 / ceiling,
                                   "peak_note": "measured in this run: 2^26 independent random 128-byte line reads over an 8 GB table",
                                   "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
+        if rank == 0 and world == 1 and last_contigs:
+            search["membership"] = contig_membership(graph, last_contigs, k)
+            note(f"membership of the returned contigs' (k+1)-mers in the graph: {search['membership']}")
+        if rank == 0 and world == 1 and sum(len(x) for x in product_seeds) > 0:
+            # the mode `megagta search` runs in: findstart's seeds in its order, shared term_nodes caches under the ordered-commit window
+            # (window and cost term chosen by the number of seeds, as the binary chooses them), on the same resident graph
+            from megagta_amd import search_dist as sdm
+            tot_e, tot_ms, per_gene = 0, 0.0, {}
+            t = time.time()
+            for gi, gene in enumerate(mg.genes):
+                ps = product_seeds[gi]
+                if not ps:
+                    continue
+                window, rate = sdm.window_and_rate(len(ps))
+                _, _, st = api.astar_search_packed(graph, hm[gi][0], hm[gi][1], [x[0] for x in ps], [x[1] - 1 for x in ps], 20, 0.5, cache_mode=window, cost_rate=rate)
+                tot_e += st["n_expansions"]; tot_ms += st["ms_total"]
+                per_gene[gene.name] = {"seeds": len(ps), "window": window, "cost_rate": rate, "expansions": st["n_expansions"], "ms": st["ms_total"],
+                                       "restarted_in_place": st["n_retries"]}
+            pdt = time.time() - t
+            search["product_mode"] = {"value": tot_e / max(1e-9, tot_ms * 1e-3), "unit": "HMM-scored node expansions/s", "seeds_per_s": sum(len(x) for x in product_seeds) / pdt,
+                                      "seconds": pdt, "genes": per_gene,
+                                      "note": "findstart's seeds of the first %d reads (sorted, unique), default mode of `megagta search` (ordered-commit window + cost "
+                                              "term) on the %d-edge graph; `value` above is the cold mode on synthetic seeds" % (mg.sample_reads.shape[0], graph.size)}
+            note(f"search, product mode: {sum(len(x) for x in product_seeds)} seeds in {pdt:.1f} s, {tot_e / max(1e-9, tot_ms * 1e-3) / 1e6:.1f} M expansions/s")
         if world == 1 and (args.reads <= 20_000_000 or args.denovo):
             # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits)
             _, dst = graph.denovo(150, False, k + 2)
@@ -447,7 +552,11 @@ def main():
                     out["e2e"] = {"error": str(e)[-600:]}
             if not args.no_cpu_baseline:
                 note("cpu baseline ...")
-                out["cpu_baseline"] = cpu_baseline(mg.sample_reads, k, args.cpu_sample)
+                cb = cpu_baseline(mg.sample_reads, k, args.cpu_sample, ctx)
+                if "_parity" in cb:
+                    out["parity_1M"] = cb.pop("_parity")
+                    note(f"parity vs the reference's graph of the sample: {out['parity_1M']}")
+                out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -7,7 +7,8 @@
 // here is the ONE-thread run, byte for byte, and it is computed in parallel:
 //  * Trim marks on a snapshot and deletes afterwards, so every start node is an independent thread.
 //  * PopBubbles is order dependent (a pop changes what the next search sees).  Pending candidates are taken in windows of ascending edge
-//    id.  Every candidate of the window stamps, by 64-bit atomicMax of (round, ~rank), every edge its search could EVER read or write
+//    id.  Every candidate of the window stamps, by 64-bit atomicMax of (round, ~rank) in a hash table keyed by edge id (a few GB whatever
+//    the size of the graph: only the edges a window reaches carry a stamp), every edge its search could EVER read or write
 //    while the graph only loses edges: all edges within max_bubble_len forward steps of its begin edge plus the edges into them (its
 //    "reach").  Then it runs its search on the current graph and commits (pops) iff every still-valid edge the search read carries its
 //    own stamp: no lower pending candidate can reach what it read or writes, now or after any later change, and its own writes stay
@@ -16,15 +17,17 @@
 //  * Unitigs: the reference walks every maximal simple path back from its end edge in ascending order, locking edges in a bit
 //    vector, then locks the path of the reverse complement forwards from RC(end).  With one thread the locks held inside a path are
 //    always a suffix of it that reaches its end edge, so the whole protocol collapses to: path P (end e) is skipped iff an earlier
-//    processed (q < e), not skipped path Q has RC(q) inside P.  One serial walk per path notes (path, distance to the end) on every
-//    edge; RC(end) looked up in that table is the claim; the recursion over ascending ids is resolved by a few data-parallel
-//    sweeps; the rarely taken "RC(end) already locked" branch (:243-252) is evaluated from the same claims; labels are written by one
-//    thread per edge.
+//    processed (q < e), not skipped path Q has RC(q) inside P.  One walk per path back from its end edge (start, length, depth), one
+//    walk forwards from RC(end) to the end edge of the path it lies on (the reference's own locking walk: the claim = that path and
+//    the distance); the recursion over ascending ids is resolved by a few data-parallel sweeps; the rarely taken "RC(end) already
+//    locked" branch (:243-252) is evaluated from the same claims; the labels are written by a second walk of the paths that are
+//    emitted.  Nothing is kept per edge (round 2 kept 8 bytes per edge twice: stamps and a path table), path ids are 64-bit.
 //    (PopBubbles keeps the LAST branch on equal multiplicities, which is a different allele on the two strands: the graph is not
 //    strand-symmetric afterwards, so none of this may assume that RC(path) is a path.)
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <thread>
 
 #include "graph.hpp"
 #include "scan.hpp"
@@ -246,16 +249,59 @@ __global__ __launch_bounds__(256) void trim_delete_kernel(Dn d, const unsigned l
 }
 
 // ---- bubbles --------------------------------------------------------------------------------------------------------------------
+// Stamps of one round, keyed by edge id: open addressing, linear probing.  A key word = tag << 40 | edge id with tag = the round (1 ..
+// 2^24 - 1): whatever an earlier round left behind reads as an empty slot and is claimed by CAS, so nothing is ever cleared; the value
+// keeps (round << 32 | ~rank) by atomicMax exactly as the per-edge array of round 2 did.  Inserts (reach kernel) and look-ups (check
+// kernel) are separated by a kernel boundary, slots only ever turn from stale to current inside a round, so a probe sequence that
+// found a key keeps finding it.  An insert that sees kStampProbes occupied slots gives up: the caller treats its candidate as one
+// whose region does not fit (it and everything above it waits for the next round, whose window the host then shrinks).
+constexpr int kStampProbes = 128;
+struct StampTab {
+    unsigned long long *key, *val;
+    uint64_t mask;
+    unsigned long long tag;       // round tag << 40
+    __device__ __forceinline__ uint64_t slot(int64_t e) const { return (((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 20) & mask; }
+    __device__ bool stamp(int64_t e, unsigned long long v) const {
+        const unsigned long long mine = tag | (unsigned long long)e;
+        uint64_t h = slot(e);
+        for (int probes = 0; probes < kStampProbes;) {
+            unsigned long long cur = __hip_atomic_load(&key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur != mine && (cur & ~0xFFFFFFFFFFull) != tag) {
+                if (!__hip_atomic_compare_exchange_strong(&key[h], &cur, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && cur != mine)
+                    continue;                                      // another edge took the slot: look at it again
+                cur = mine;
+            }
+            if (cur == mine) { atomicMax(&val[h], v); return true; }
+            h = (h + 1) & mask;
+            ++probes;
+        }
+        return false;
+    }
+    __device__ unsigned long long lookup(int64_t e) const {       // 0 = no stamp this round
+        const unsigned long long mine = tag | (unsigned long long)e;
+        uint64_t h = slot(e);
+        for (int probes = 0; probes < kStampProbes; ++probes) {
+            const unsigned long long cur = key[h];
+            if (cur == mine) return val[h];
+            if ((cur & ~0xFFFFFFFFFFull) != tag) return 0ull;
+            h = (h + 1) & mask;
+        }
+        return 0ull;
+    }
+};
+
 struct SinkNone { __device__ void operator()(int64_t) {} };
 struct SinkStamp {
-    unsigned long long *owner, key;
-    __device__ void operator()(int64_t e) { atomicMax(&owner[e], key); }
-};
-struct SinkCheck {
-    const unsigned long long *owner;
+    StampTab tab;
     unsigned long long key;
     bool ok;
-    __device__ void operator()(int64_t e) { if (owner[e] != key) ok = false; }
+    __device__ void operator()(int64_t e) { if (!tab.stamp(e, key)) ok = false; }
+};
+struct SinkCheck {
+    StampTab tab;
+    unsigned long long key;
+    bool ok;
+    __device__ void operator()(int64_t e) { if (tab.lookup(e) != key) ok = false; }
 };
 
 // BranchGroup::Search (branch_group.cpp:22-103).  br[b * max_len + j] = j-th edge of branch b; every still-valid edge whose validity
@@ -356,7 +402,7 @@ __global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64
 // One WAVE per candidate: the lanes take the edges of a level side by side (a region of thousands of edges in a repeat would
 // otherwise keep one lane busy for milliseconds while the round waits for it).  Which edges end up stamped, and whether the region
 // fits, depends on the region alone (counts per level and in all), not on the order the lanes find them in.
-__device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, unsigned long long *owner, unsigned long long key,
+__device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, const StampTab &owner, unsigned long long key,
                                    unsigned long long round, int reach_max, int *s_cnt /* LDS: [0] edges of the next level, [1] edges seen, [2] overflow */) {
     if (!g_valid(g, begin)) return true;
     const int lane = threadIdx.x;
@@ -383,7 +429,7 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
         s_cnt[0] = 0; s_cnt[1] = 1; s_cnt[2] = 0;
         insert(begin);
         __hip_atomic_store(&cur[0], begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicMax(&owner[begin], key);
+        if (!owner.stamp(begin, key)) s_cnt[2] = 1;
     }
     __syncthreads();
     int n_cur = 1;
@@ -398,10 +444,11 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
                     const int seen = atomicAdd(&s_cnt[1], 1) + 1, at = atomicAdd(&s_cnt[0], 1);
                     if (seen > reach_max || at >= kReachFrontier) { s_cnt[2] = 1; continue; }
                     __hip_atomic_store(&nxt[at], out[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicMax(&owner[out[x]], key);
+                    bool fits = owner.stamp(out[x], key);
                     int64_t in[8];
                     const int id = d_incoming(g, out[x], in);
-                    for (int y = 0; y < id; ++y) atomicMax(&owner[in[y]], key);
+                    for (int y = 0; y < id; ++y) fits = owner.stamp(in[y], key) && fits;
+                    if (!fits) s_cnt[2] = 1;                            // the stamp table is crowded: treated like a region that does not fit
                 }
             }
         }
@@ -417,7 +464,7 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
 }
 
 __global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
-                                                          unsigned long long *owner, unsigned long long round, int reach_max, uint32_t *barrier) {
+                                                          StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier) {
     __shared__ int s_cnt[4];
     const uint32_t i = blockIdx.x;                                     // one wave per candidate
     if (i >= n) return;
@@ -428,11 +475,12 @@ __global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int6
     if (threadIdx.x != 0) return;
     atomicMin(barrier, i);
     int mult[kMaxBranches], nb = 0, len = 0;
-    SinkStamp s{owner, key};
+    SinkStamp s{owner, key, true};
     bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
+    if (!s.ok) atomicAdd(barrier + 2, 1u);                             // not even that fitted the table: the host shrinks the next window
 }
 __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
-                                                          const unsigned long long *owner, unsigned long long round, uint32_t *ok) {
+                                                          StampTab owner, unsigned long long round, uint32_t *ok) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     int mult[kMaxBranches], nb = 0, len = 0;
@@ -442,7 +490,7 @@ __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int6
 }
 // status (by position in the candidate list): 0 = the search fails now, 1 = popped, 2 = Pop undid itself (goes to the second list,
 // assembly_algorithms.cpp:273-277).  keep[i] = 1: still pending after this round.
-__global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *cand, const uint32_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
+__global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *cand, const uint64_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
                                                            const uint32_t *ok, const uint32_t *barrier, unsigned long long *marked, uint32_t *status,
                                                            uint32_t *keep, uint32_t *n_done) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -457,14 +505,18 @@ __global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *
     keep[i] = 0;
     atomicAdd(n_done, 1u);
 }
-__global__ __launch_bounds__(256) void window_fill_kernel(const int64_t *cand, uint64_t from, uint32_t take, uint32_t at, int64_t *win, uint32_t *pos) {
+__global__ __launch_bounds__(256) void window_fill_kernel(const int64_t *cand, uint64_t from, uint32_t take, uint32_t at, int64_t *win, uint64_t *pos) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < take) { win[at + i] = cand[from + i]; pos[at + i] = (uint32_t)(from + i); }
+    if (i < take) { win[at + i] = cand[from + i]; pos[at + i] = from + i; }
 }
-__global__ __launch_bounds__(256) void window_keep_kernel(const int64_t *win, const uint32_t *pos, const uint32_t *keep, const uint64_t *base, uint32_t n,
-                                                          int64_t *win2, uint32_t *pos2) {
+__global__ __launch_bounds__(256) void window_keep_kernel(const int64_t *win, const uint64_t *pos, const uint32_t *keep, const uint64_t *base, uint32_t n,
+                                                          int64_t *win2, uint64_t *pos2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n && keep[i]) { win2[base[i]] = win[i]; pos2[base[i]] = pos[i]; }
+}
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t n, uint32_t v) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 __global__ __launch_bounds__(256) void flag_equals_kernel(const uint32_t *status, uint64_t n, uint32_t want, uint32_t *flag, unsigned long long *count) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -475,131 +527,151 @@ __global__ __launch_bounds__(256) void flag_equals_kernel(const uint32_t *status
 }
 
 // ---- unitigs --------------------------------------------------------------------------------------------------------------------
-struct PathRec {
-    int64_t end, start, rc_start, depth;
+struct PathRec {          // (the end edge of path p is ends[p])
+    int64_t start, rc_start;
+    int64_t target;       // path whose suffix the walk from RC(end) locks (-1: RC(end) is not on a path that ends)
+    int64_t next;         // next claim on the same target
     uint32_t length;      // edges
-    int32_t target;       // path whose suffix the walk from RC(end) locks (-1: RC(end) is not on a path that ends)
+    uint32_t extra_depth; // sum of the edge multiplicities (1 or 2 each) minus length
     uint32_t dist;        // edges from RC(end) to that path's end
-    int32_t next;         // next claim on the same target
+    uint32_t pad;
 };
+static_assert(sizeof(PathRec) == 48, "path record");
 
-// The one serial walk per path: back from its end edge, noting on every edge which path it is on and how far from the end
-// (uint2: path id, edges to the end).  Everything after this is a look-up in that table.
-__global__ __launch_bounds__(64) void unitig_walk_kernel(GraphDev g, const int64_t *ends, uint32_t n, PathRec *rec, uint2 *on_path) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+// path id of an end edge: its rank among the end edges (the mask and its prefix sums are what built the ascending list)
+__device__ __forceinline__ int64_t path_of_end(const unsigned long long *end_mask, const uint64_t *end_base, int64_t e) {
+    const unsigned long long m = end_mask[e >> 6];
+    return (int64_t)end_base[e >> 6] + __popcll(m & ((1ull << (e & 63)) - 1ull));
+}
+
+// The walk back from the end edge (unitig_graph.cpp:229-239): start, length, depth.  Nothing is written per edge.
+__global__ __launch_bounds__(64) void unitig_walk_kernel(GraphDev g, const int64_t *ends, uint64_t n, PathRec *rec) {
+    const uint64_t pid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (pid >= n) return;
     const int64_t e = ends[pid];
     int64_t cur = e, p;
-    int64_t depth = multiplicity(g, e);
-    uint32_t length = 1;
-    on_path[e] = make_uint2(pid, 0u);
-    while ((p = prev_simple(g, cur)) != -1) {       // unitig_graph.cpp:229-239 (never a cycle: e has no simple successor)
+    uint64_t depth = (uint64_t)multiplicity(g, e), length = 1;
+    while ((p = prev_simple(g, cur)) != -1) {       // never a cycle: e has no simple successor
         cur = p;
-        on_path[cur] = make_uint2(pid, length);
-        depth += multiplicity(g, cur);
+        depth += (uint64_t)multiplicity(g, cur);
         ++length;
     }
     PathRec r;
-    r.end = e; r.start = cur; r.depth = depth; r.length = length;
-    r.rc_start = -1; r.target = -1; r.dist = 0; r.next = -1;
+    r.start = cur; r.length = (uint32_t)length; r.extra_depth = (uint32_t)(depth - length);
+    r.rc_start = -1; r.target = -1; r.dist = 0; r.next = -1; r.pad = length > 0xFFFFFFFFull ? 1u : 0u;   // (pad != 0: a path of 2^32 edges, reported by the host)
     rec[pid] = r;
 }
-// unitig_graph.cpp:241-273: the walk that locks forwards from RC(end) ends at the end edge of the path RC(end) lies on (an edge of a
-// pure cycle lies on no path that ends: nothing to claim)
-__global__ __launch_bounds__(64) void unitig_claim_kernel(GraphDev g, uint32_t n, PathRec *rec, const uint2 *on_path, int32_t *head) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+// unitig_graph.cpp:241-273: the walk that locks forwards from RC(end) ends at the end edge of the path RC(end) lies on -- walked here
+// the same way (an edge of a pure cycle lies on no path that ends: nothing to claim; the walk is cut when it comes round)
+__global__ __launch_bounds__(64) void unitig_claim_kernel(GraphDev g, const int64_t *ends, uint64_t n, PathRec *rec, const unsigned long long *end_mask,
+                                                          const uint64_t *end_base, int64_t *head) {
+    const uint64_t pid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (pid >= n) return;
-    const int64_t r = edge_reverse_complement(g, rec[pid].end);
+    const int64_t r = edge_reverse_complement(g, ends[pid]);
     rec[pid].rc_start = r;
     if (r < 0 || !g_valid(g, r)) return;
-    const uint2 at = on_path[r];
-    if (at.x == 0xFFFFFFFFu) return;
-    rec[pid].target = (int32_t)at.x;
-    rec[pid].dist = at.y;
-    rec[pid].next = atomicExch(&head[at.x], (int32_t)pid);
+    int64_t cur = r, nx;
+    uint32_t dist = 0;
+    while ((nx = next_simple(g, cur)) != -1) {
+        cur = nx;
+        ++dist;
+        if (cur == r) return;                        // a cycle of simple edges
+    }
+    const int64_t t = path_of_end(end_mask, end_base, cur);
+    rec[pid].target = t;
+    rec[pid].dist = dist;
+    rec[pid].next = (int64_t)atomicExch((unsigned long long *)&head[t], (unsigned long long)pid);
 }
 
 // state: 0 = not known yet, 1 = processed (its edges get locked by its own walk), 2 = skipped at `marked.try_lock(edge_idx)`
-__global__ __launch_bounds__(256) void unitig_resolve_kernel(const PathRec *rec, const int32_t *head, uint32_t n, uint32_t *state, uint32_t *undecided) {
-    const uint32_t pid = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void unitig_resolve_kernel(const int64_t *ends, const PathRec *rec, const int64_t *head, uint64_t n, uint32_t *state,
+                                                             unsigned long long *undecided) {
+    const uint64_t pid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (pid >= n || __hip_atomic_load(&state[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    const int64_t e = rec[pid].end;
     bool pending = false, skipped = false;
-    for (int32_t q = head[pid]; q >= 0; q = rec[q].next) {
-        if ((uint32_t)q == pid || rec[q].end >= e) continue;
+    for (int64_t q = head[pid]; q >= 0; q = rec[q].next) {
+        if ((uint64_t)q >= pid) continue;            // (ends ascend with the path id: an earlier end edge = a lower id)
         const uint32_t s = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s == 1) { skipped = true; break; }
         if (s == 0) pending = true;
     }
     if (skipped) __hip_atomic_store(&state[pid], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (!pending) __hip_atomic_store(&state[pid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else atomicAdd(undecided, 1u);
+    else atomicAdd(undecided, 1ull);
 }
 
-__global__ __launch_bounds__(64) void unitig_decide_kernel(GraphDev g, const PathRec *rec, const int32_t *head, const uint32_t *state, uint32_t n,
-                                                           int min_contig, uint32_t *emit, uint32_t *emit_len) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64) void unitig_decide_kernel(GraphDev g, const int64_t *ends, const PathRec *rec, const int64_t *head, const uint32_t *state, uint64_t n,
+                                                           int min_contig, uint32_t *emit_len) {
+    const uint64_t pid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (pid >= n) return;
-    emit[pid] = 0; emit_len[pid] = 0;
+    emit_len[pid] = 0;
     if (state[pid] != 1) return;
     const PathRec r = rec[pid];
+    const int64_t end = ends[pid];
     bool add = true;
     if (r.target >= 0) {       // was RC(end) locked when this path was processed? (unitig_graph.cpp:245)
-        const int32_t t = r.target;
-        bool locked = (uint32_t)t == pid || (state[t] == 1 && rec[t].end < r.end);
-        for (int32_t q = head[t]; q >= 0 && !locked; q = rec[q].next)
-            locked = (uint32_t)q != pid && state[q] == 1 && rec[q].end < r.end && rec[q].dist > r.dist;
+        const int64_t t = r.target;
+        bool locked = (uint64_t)t == pid || (state[t] == 1 && (uint64_t)t < pid);
+        for (int64_t q = head[t]; q >= 0 && !locked; q = rec[q].next)
+            locked = (uint64_t)q != pid && state[q] == 1 && (uint64_t)q < pid && rec[q].dist > r.dist;
         if (locked) {
             const int64_t rc_end = edge_reverse_complement(g, r.start);
-            const int64_t a = r.end > r.start ? r.end : r.start, b = r.rc_start > rc_end ? r.rc_start : rc_end;
+            const int64_t a = end > r.start ? end : r.start, b = r.rc_start > rc_end ? r.rc_start : rc_end;
             if (a < b) add = false;                                                  // :248-252
         }
     }
     const uint32_t len = r.length + (uint32_t)g.k;
-    if (add && (int)len >= min_contig) { emit[pid] = 1; emit_len[pid] = len; }
+    if (add && (int)len >= min_contig) emit_len[pid] = len;          // (a contig is at least k + 1 characters: 0 = not emitted)
 }
 
 struct ContigMeta { int64_t depth; uint32_t length, len; int32_t flag; uint32_t pad; uint64_t offset; };
 
-// VertexToDNAString (unitig_graph.cpp:80-112), one thread per EDGE: the label is the start node's k symbols followed by the W symbol
-// of every edge of the path
-__global__ __launch_bounds__(256) void unitig_chars_kernel(GraphDev g, const PathRec *rec, const uint2 *on_path, const uint32_t *emit, const uint64_t *off,
-                                                           char *text) {
-    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < g.size; x += (int64_t)gridDim.x * 256) {
-        const uint2 at = on_path[x];
-        if (at.x == 0xFFFFFFFFu || !emit[at.x]) continue;
-        const int w = g_W(g, x);
-        text[off[at.x] + (uint64_t)g.k + (rec[at.x].length - 1 - at.y)] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
-    }
-}
-__global__ __launch_bounds__(64) void unitig_finish_kernel(GraphDev g, const PathRec *rec, const uint32_t *emit, const uint64_t *idx, const uint64_t *off,
-                                                           uint32_t n, ContigMeta *meta, char *text) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
-    if (pid >= n || !emit[pid]) return;
+// VertexToDNAString (unitig_graph.cpp:80-112) for the paths [p0, p0 + n) that are emitted: the start node's k symbols, then the W symbol
+// of every edge of the path -- a second walk back from the end edge, writing from the end of the string; then the smaller of the label
+// and its reverse complement (WriteContig, :134-150) and the record of the contig.  off / idx: exclusive sums of emit_len / of
+// (emit_len > 0) over the chunk.
+__global__ __launch_bounds__(64) void unitig_write_kernel(GraphDev g, const int64_t *ends, const PathRec *rec, const uint32_t *emit_len, const uint64_t *idx,
+                                                          const uint64_t *off, uint64_t p0, uint64_t n, ContigMeta *meta, char *text) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n || !emit_len[p0 + i]) return;
+    const uint64_t pid = p0 + i;
     const PathRec r = rec[pid];
     const int k = g.k;
     const uint32_t len = r.length + (uint32_t)k;
-    char *s = text + off[pid];
+    char *s = text + off[i];
+    int64_t cur = ends[pid];
+    for (uint32_t at = len; at > (uint32_t)k;) {                      // the edge `dist` steps before the end is character len - 1 - dist
+        const int w = g_W(g, cur);
+        s[--at] = "ACGT"[(w > 4 ? w - 4 : w) - 1];
+        if (at > (uint32_t)k) cur = prev_simple(g, cur);
+    }
     uint8_t lab[kMaxK + 1];
     d_label(g, r.start, lab);
-    for (int i = 0; i < k; ++i) s[i] = "ACGT"[lab[i] - 1];
-    // the smaller of the label and its reverse complement (WriteContig, :134-150)
+    for (int j = 0; j < k; ++j) s[j] = "ACGT"[lab[j] - 1];
     auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
     int cmp = 0;
-    for (uint32_t i = 0; i < len && cmp == 0; ++i) {
-        const char a = s[i], b = comp(s[len - 1 - i]);
+    for (uint32_t j = 0; j < len && cmp == 0; ++j) {
+        const char a = s[j], b = comp(s[len - 1 - j]);
         cmp = a < b ? -1 : a > b ? 1 : 0;
     }
     if (cmp > 0)
-        for (uint32_t i = 0, j = len - 1; i <= j && j != 0xFFFFFFFFu; ++i, --j) {
-            const char a = comp(s[i]), b = comp(s[j]);
-            s[i] = b; s[j] = a;
+        for (uint32_t a = 0, b = len - 1; a <= b && b != 0xFFFFFFFFu; ++a, --b) {
+            const char x = comp(s[a]), y = comp(s[b]);
+            s[a] = y; s[b] = x;
         }
     int64_t t[8];
     ContigMeta m;
-    m.depth = r.depth; m.length = r.length; m.len = len; m.pad = 0; m.offset = off[pid];
-    m.flag = (d_incoming(g, r.start, t) == 0 && d_outgoing(g, r.end, t) == 0) ? 1 : 0;   // contig_flag::kIsolated
-    meta[idx[pid]] = m;
+    m.depth = (int64_t)r.length + (int64_t)r.extra_depth; m.length = r.length; m.len = len; m.pad = 0; m.offset = off[i];
+    m.flag = (d_incoming(g, r.start, t) == 0 && d_outgoing(g, ends[pid], t) == 0) ? 1 : 0;   // contig_flag::kIsolated
+    meta[idx[i]] = m;
+}
+__global__ __launch_bounds__(256) void nonzero_flag_kernel(const uint32_t *v, uint64_t n, uint32_t *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flag[i] = v[i] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void any_pad_kernel(const PathRec *rec, uint64_t n, unsigned long long *count) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && rec[i].pad) atomicAdd(count, 1ull);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -689,7 +761,8 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
 }
 
 struct BubbleWork {
-    DevBuf scratch, owner, marked, status, win[2], pos[2], ok, keep, base, tmp, small;
+    DevBuf scratch, stamp_key, stamp_val, marked, status, win[2], pos[2], ok, keep, base, tmp, small;
+    uint64_t stamp_mask = 0;
     size_t per = 0;          // int64 of scratch per candidate
     uint32_t window = 0;
     int reach_max = kReachMax;
@@ -704,29 +777,42 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
     int cur = 0;
     uint32_t want = std::min<uint32_t>(4096, b.window);
     uint32_t *barrier = b.small.as<uint32_t>(), *n_done = b.small.as<uint32_t>() + 1;
+    uint32_t cap = b.window;      // windows shrink while the stamp table overflows (a crowded table holds back what it could not stamp)
     while (carry > 0 || p < n) {
-        const uint32_t m = (uint32_t)std::min<uint64_t>(std::max(want, carry), carry + (n - p)), take = m - carry;
+        // (a carry larger than the cap is cut: the candidates beyond it stay in the list for the next rounds, in order)
+        const uint32_t m = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(std::max(want, carry), std::max(cap, 1u)), carry + (n - p));
+        const uint32_t take = m > carry ? m - carry : 0, shed = carry > m ? carry - m : 0;
         if (take) hipLaunchKernelGGL(window_fill_kernel, dim3((take + 255) / 256), dim3(256), 0, w.st, cand.as<int64_t>(), p, take, carry, b.win[cur].as<int64_t>(),
-                                     b.pos[cur].as<uint32_t>());
+                                     b.pos[cur].as<uint64_t>());
         p += take;
         ++b.round; ++n_rounds;
+        if (b.round >= 0xFFFFFEull) { set_error("mgta_denovo: more than 2^24 bubble rounds"); throw HipError{MGTA_EUNSUPPORTED}; }
         const int64_t *c = b.win[cur].as<int64_t>();
-        const uint32_t init[2] = {0xFFFFFFFFu, 0u};
-        MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 8, hipMemcpyHostToDevice, w.st));
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
-                           b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.reach_max, barrier);
-        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per,
-                           b.owner.as<unsigned long long>(), (unsigned long long)b.round, b.ok.as<uint32_t>());
-        hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint32_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
+        const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+        MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 16, hipMemcpyHostToDevice, w.st));
+        const StampTab tab{b.stamp_key.as<unsigned long long>(), b.stamp_val.as<unsigned long long>(), b.stamp_mask, (unsigned long long)(b.round + 1) << 40};
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
+                           (unsigned long long)b.round, b.reach_max, barrier);
+        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
+                           (unsigned long long)b.round, b.ok.as<uint32_t>());
+        hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
                            b.ok.as<uint32_t>(), barrier, b.marked.as<unsigned long long>(), b.status.as<uint32_t>(), b.keep.as<uint32_t>(), n_done);
-        exclusive_scan_u32(w.st, b.keep.as<uint32_t>(), m, b.base.as<uint64_t>(), b.tmp.as<uint64_t>(), w.total.as<uint64_t>());
-        hipLaunchKernelGGL(window_keep_kernel, dim3((m + 255) / 256), dim3(256), 0, w.st, c, b.pos[cur].as<uint32_t>(), b.keep.as<uint32_t>(), b.base.as<uint64_t>(), m,
-                           b.win[cur ^ 1].as<int64_t>(), b.pos[cur ^ 1].as<uint32_t>());
+        if (shed) {      // the candidates beyond the cut stay pending, behind the ones this round keeps
+            hipLaunchKernelGGL(fill_u32_kernel, dim3((shed + 255) / 256), dim3(256), 0, w.st, b.keep.as<uint32_t>() + m, shed, 1u);
+        }
+        const uint32_t mm = m + shed;
+        exclusive_scan_u32(w.st, b.keep.as<uint32_t>(), mm, b.base.as<uint64_t>(), b.tmp.as<uint64_t>(), w.total.as<uint64_t>());
+        hipLaunchKernelGGL(window_keep_kernel, dim3((mm + 255) / 256), dim3(256), 0, w.st, c, b.pos[cur].as<uint64_t>(), b.keep.as<uint32_t>(), b.base.as<uint64_t>(), mm,
+                           b.win[cur ^ 1].as<int64_t>(), b.pos[cur ^ 1].as<uint64_t>());
+        uint32_t flags[4];
+        MGTA_HIP_CHECK(hipMemcpyAsync(flags, b.small.p, 16, hipMemcpyDeviceToHost, w.st));
         carry = (uint32_t)read_u64(w, w.total.p);
         cur ^= 1;
-        const uint32_t done = m - carry;
-        if (done == 0) { set_error("mgta_denovo: a bubble round committed nothing"); throw HipError{MGTA_EINTERNAL}; }   // the lowest always commits
-        want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * done));
+        const uint32_t done = mm - carry;
+        if (flags[2]) cap = std::max<uint32_t>(1, m / 4);              // some candidate could not stamp even what it reads: fewer candidates share the table next time
+        else if (cap < b.window) cap = std::min<uint32_t>(b.window, cap * 2);
+        if (done == 0 && !(flags[2] && m > 1)) { set_error("mgta_denovo: a bubble round committed nothing"); throw HipError{MGTA_EINTERNAL}; }   // the lowest always commits
+        want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * std::max(done, 1u)));
         if ((n_rounds & 15) == 1) note(w, "bubble round %lld: window %u, committed %u, %llu of %llu taken", (long long)n_rounds, m, done, (unsigned long long)p, (unsigned long long)n);     // a round that commits few (a region that does not fit the reach scratch) shrinks the next
     }
 }
@@ -756,11 +842,17 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     n_candidates = (int64_t)nc;
     note(w, "bubbles: %llu branching edges, %llu candidates, window %u", (unsigned long long)nb, (unsigned long long)nc, b.window);
     if (nc == 0) return 0;
-    if (nc >= 0xFFFFFFFFull) { set_error("mgta_denovo: %llu bubble candidates exceed 32-bit positions", (unsigned long long)nc); throw HipError{MGTA_EUNSUPPORTED}; }
-    b.owner.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
+    // the stamp table: 2^25 .. 2^28 slots of 16 bytes (0.5 .. 4 GB) -- a window of 29 k candidates stamps a few hundred edges each; what
+    // does not fit is held back and the next window is smaller.  MGTA_DENOVO_STAMP_LOG2 (tests): a tiny table exercises that path.
+    int stamp_log = 25;
+    while (stamp_log < 28 && (1ull << stamp_log) < (uint64_t)g.size / 8) ++stamp_log;
+    if (const char *e = getenv("MGTA_DENOVO_STAMP_LOG2")) stamp_log = std::min(30, std::max(8, atoi(e)));
+    b.stamp_mask = (1ull << stamp_log) - 1;
+    b.stamp_key.alloc((b.stamp_mask + 1) * 8, w.live(), w.peak());
+    b.stamp_val.alloc((b.stamp_mask + 1) * 8, w.live(), w.peak());
     b.marked.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
     b.status.alloc(nc * 4 + 64, w.live(), w.peak());
-    for (int i = 0; i < 2; ++i) { b.win[i].alloc((size_t)b.window * 8, w.live(), w.peak()); b.pos[i].alloc((size_t)b.window * 4, w.live(), w.peak()); }
+    for (int i = 0; i < 2; ++i) { b.win[i].alloc((size_t)b.window * 8, w.live(), w.peak()); b.pos[i].alloc((size_t)b.window * 8, w.live(), w.peak()); }
     b.ok.alloc((size_t)b.window * 4, w.live(), w.peak());
     b.keep.alloc((size_t)b.window * 4, w.live(), w.peak());
     b.base.alloc((size_t)b.window * 8, w.live(), w.peak());
@@ -768,7 +860,8 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     b.small.alloc(64, w.live(), w.peak());
     flag.alloc(nc * 4 + 64, w.live(), w.peak());
     counter.alloc(64, w.live(), w.peak());
-    MGTA_HIP_CHECK(hipMemsetAsync(b.owner.p, 0, (size_t)g.size * 8 + 64, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(b.stamp_key.p, 0, (b.stamp_mask + 1) * 8, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(b.stamp_val.p, 0, (b.stamp_mask + 1) * 8, w.st));
     MGTA_HIP_CHECK(hipMemsetAsync(b.marked.p, 0, (g.n_lines + 1) * 8, w.st));
     MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 64, w.st));
     pop_in_order(w, b, cand, nc, max_len, n_rounds);
@@ -793,69 +886,83 @@ struct Contigs {
 
 static void unitigs(Work &w, int min_contig, Contigs &out) {
     const GraphDev &g = w.d.g;
-    DevBuf ends, rec, head, state, undecided, emit, emit_len, idx, off, tmp, meta, text, on_path;
-    const uint64_t n64 = edges_where(w, PredPathEnd{}, ends);
-    if (n64 >= 0x7FFFFFFFull) { set_error("mgta_denovo: %llu paths exceed 31-bit path ids", (unsigned long long)n64); throw HipError{MGTA_EUNSUPPORTED}; }
-    const uint32_t n = (uint32_t)n64;
-    out.n_paths = n;
+    DevBuf ends, rec, head, state, counter, emit_len;
+    const uint64_t n = edges_where(w, PredPathEnd{}, ends);         // w.mask / w.base keep the mask and its prefix sums: the rank of an end edge is its path id
+    out.n_paths = (int64_t)n;
     if (n == 0) return;
-    rec.alloc((size_t)n * sizeof(PathRec), w.live(), w.peak());
-    head.alloc((size_t)n * 4, w.live(), w.peak());
-    state.alloc((size_t)n * 4, w.live(), w.peak());
-    undecided.alloc(64, w.live(), w.peak());
-    MGTA_HIP_CHECK(hipMemsetAsync(head.p, 0xFF, (size_t)n * 4, w.st));
-    MGTA_HIP_CHECK(hipMemsetAsync(state.p, 0, (size_t)n * 4, w.st));
-    on_path.alloc((size_t)g.size * 8 + 64, w.live(), w.peak());
-    MGTA_HIP_CHECK(hipMemsetAsync(on_path.p, 0xFF, (size_t)g.size * 8 + 64, w.st));
-    hipLaunchKernelGGL(unitig_walk_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), on_path.as<uint2>());
-    note(w, "unitigs: %u paths walked", n);
-    hipLaunchKernelGGL(unitig_claim_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, n, rec.as<PathRec>(), on_path.as<uint2>(), head.as<int32_t>());
+    rec.alloc(n * sizeof(PathRec), w.live(), w.peak());
+    head.alloc(n * 8, w.live(), w.peak());
+    state.alloc(n * 4, w.live(), w.peak());
+    counter.alloc(64, w.live(), w.peak());
+    MGTA_HIP_CHECK(hipMemsetAsync(head.p, 0xFF, n * 8, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(state.p, 0, n * 4, w.st));
+    MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 64, w.st));
+    const unsigned grid64 = (unsigned)((n + 63) / 64), grid256 = (unsigned)((n + 255) / 256);
+    if ((n + 63) / 64 >= (1ull << 31)) { set_error("mgta_denovo: %llu paths exceed one launch", (unsigned long long)n); throw HipError{MGTA_EUNSUPPORTED}; }
+    hipLaunchKernelGGL(unitig_walk_kernel, dim3(grid64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>());
+    hipLaunchKernelGGL(any_pad_kernel, dim3(grid256), dim3(256), 0, w.st, rec.as<PathRec>(), n, counter.as<unsigned long long>());
+    if (read_u64(w, counter.p)) { set_error("mgta_denovo: a simple path of 2^32 edges or more"); throw HipError{MGTA_EUNSUPPORTED}; }
+    note(w, "unitigs: %llu paths walked", (unsigned long long)n);
+    hipLaunchKernelGGL(unitig_claim_kernel, dim3(grid64), dim3(64), 0, w.st, g, ends.as<int64_t>(), n, rec.as<PathRec>(), w.mask.as<unsigned long long>(),
+                       w.base.as<uint64_t>(), head.as<int64_t>());
     for (;;) {
-        MGTA_HIP_CHECK(hipMemsetAsync(undecided.p, 0, 4, w.st));
-        hipLaunchKernelGGL(unitig_resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, w.st, rec.as<PathRec>(), head.as<int32_t>(), n, state.as<uint32_t>(),
-                           undecided.as<uint32_t>());
+        MGTA_HIP_CHECK(hipMemsetAsync(counter.p, 0, 8, w.st));
+        hipLaunchKernelGGL(unitig_resolve_kernel, dim3(grid256), dim3(256), 0, w.st, ends.as<int64_t>(), rec.as<PathRec>(), head.as<int64_t>(), n, state.as<uint32_t>(),
+                           counter.as<unsigned long long>());
         ++out.n_sweeps;
-        uint32_t left = 0;
-        MGTA_HIP_CHECK(hipMemcpyAsync(&left, undecided.p, 4, hipMemcpyDeviceToHost, w.st));
-        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
-        if (left == 0) break;
+        if (read_u64(w, counter.p) == 0) break;
     }
     note(w, "unitigs: claims resolved in %lld sweeps", (long long)out.n_sweeps);
-    emit.alloc((size_t)n * 4, w.live(), w.peak());
-    emit_len.alloc((size_t)n * 4, w.live(), w.peak());
-    idx.alloc((size_t)n * 8, w.live(), w.peak());
-    off.alloc((size_t)n * 8, w.live(), w.peak());
-    tmp.alloc(scan_tmp_elems(n) * 8, w.live(), w.peak());
-    hipLaunchKernelGGL(unitig_decide_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), head.as<int32_t>(), state.as<uint32_t>(), n, min_contig,
-                       emit.as<uint32_t>(), emit_len.as<uint32_t>());
+    emit_len.alloc(n * 4, w.live(), w.peak());
+    hipLaunchKernelGGL(unitig_decide_kernel, dim3(grid64), dim3(64), 0, w.st, g, ends.as<int64_t>(), rec.as<PathRec>(), head.as<int64_t>(), state.as<uint32_t>(), n, min_contig,
+                       emit_len.as<uint32_t>());
     if (getenv("MGTA_DENOVO_DEBUG")) {      // the path table, for comparing with the oracle's model of this step
         std::vector<PathRec> h(n);
         std::vector<uint32_t> hs(n), he(n);
-        MGTA_HIP_CHECK(hipMemcpy(h.data(), rec.p, (size_t)n * sizeof(PathRec), hipMemcpyDeviceToHost));
-        MGTA_HIP_CHECK(hipMemcpy(hs.data(), state.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        MGTA_HIP_CHECK(hipMemcpy(he.data(), emit.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "device: %u paths\n", n);
-        for (uint32_t i = 0; i < n; ++i)
-            fprintf(stderr, "device p=%u end=%lld start=%lld len=%u rc=%lld target=%d dist=%u state=%u emit=%u\n", i, (long long)h[i].end, (long long)h[i].start,
-                    h[i].length, (long long)h[i].rc_start, h[i].target, h[i].dist, hs[i], he[i]);
+        std::vector<int64_t> hend(n);
+        MGTA_HIP_CHECK(hipMemcpy(h.data(), rec.p, n * sizeof(PathRec), hipMemcpyDeviceToHost));
+        MGTA_HIP_CHECK(hipMemcpy(hs.data(), state.p, n * 4, hipMemcpyDeviceToHost));
+        MGTA_HIP_CHECK(hipMemcpy(he.data(), emit_len.p, n * 4, hipMemcpyDeviceToHost));
+        MGTA_HIP_CHECK(hipMemcpy(hend.data(), ends.p, n * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "device: %llu paths\n", (unsigned long long)n);
+        for (uint64_t i = 0; i < n; ++i)
+            fprintf(stderr, "device p=%llu end=%lld start=%lld len=%u rc=%lld target=%lld dist=%u state=%u emit=%u\n", (unsigned long long)i, (long long)hend[i],
+                    (long long)h[i].start, h[i].length, (long long)h[i].rc_start, (long long)h[i].target, h[i].dist, hs[i], he[i] ? 1u : 0u);
     }
-    exclusive_scan_u32(w.st, emit.as<uint32_t>(), n, idx.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
-    const uint64_t n_contigs = read_u64(w, w.total.p);
-    exclusive_scan_u32(w.st, emit_len.as<uint32_t>(), n, off.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
-    const uint64_t n_chars = read_u64(w, w.total.p);
-    if (n_contigs == 0) return;
-    meta.alloc(n_contigs * sizeof(ContigMeta), w.live(), w.peak());
-    text.alloc(n_chars + 64, w.live(), w.peak());
-    hipLaunchKernelGGL(unitig_chars_kernel, dim3((unsigned)std::min<int64_t>((g.size + 255) / 256, 1 << 22)), dim3(256), 0, w.st, g, rec.as<PathRec>(), on_path.as<uint2>(), emit.as<uint32_t>(),
-                       off.as<uint64_t>(), text.as<char>());
-    hipLaunchKernelGGL(unitig_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, w.st, g, rec.as<PathRec>(), emit.as<uint32_t>(), idx.as<uint64_t>(), off.as<uint64_t>(), n,
-                       meta.as<ContigMeta>(), text.as<char>());
-    note(w, "unitigs: %llu contigs, %llu characters written", (unsigned long long)n_contigs, (unsigned long long)n_chars);
-    out.meta.resize(n_contigs);
-    out.text.resize(n_chars);
-    MGTA_HIP_CHECK(hipMemcpyAsync(out.meta.data(), meta.p, n_contigs * sizeof(ContigMeta), hipMemcpyDeviceToHost, w.st));
-    MGTA_HIP_CHECK(hipMemcpyAsync(out.text.data(), text.p, n_chars, hipMemcpyDeviceToHost, w.st));
     MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+    head.release(); state.release();                                   // (only the records, the end edges and the verdicts are needed from here on)
+    // the contigs leave in pieces of 2^25 paths: offsets, characters and records of one piece at a time
+    const uint64_t kPiece = 1ull << 25;
+    DevBuf flag, idx, off, tmp, meta, text;
+    const uint64_t pn_max = std::min(n, kPiece);
+    flag.alloc(pn_max * 4, w.live(), w.peak());
+    idx.alloc(pn_max * 8, w.live(), w.peak());
+    off.alloc(pn_max * 8, w.live(), w.peak());
+    tmp.alloc(scan_tmp_elems(pn_max) * 8, w.live(), w.peak());
+    uint64_t char_base = 0;
+    for (uint64_t p0 = 0; p0 < n; p0 += kPiece) {
+        const uint64_t pn = std::min(kPiece, n - p0);
+        hipLaunchKernelGGL(nonzero_flag_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, w.st, emit_len.as<uint32_t>() + p0, pn, flag.as<uint32_t>());
+        exclusive_scan_u32(w.st, flag.as<uint32_t>(), pn, idx.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
+        const uint64_t n_contigs = read_u64(w, w.total.p);
+        exclusive_scan_u32(w.st, emit_len.as<uint32_t>() + p0, pn, off.as<uint64_t>(), tmp.as<uint64_t>(), w.total.as<uint64_t>());
+        const uint64_t n_chars = read_u64(w, w.total.p);
+        if (n_contigs == 0) continue;
+        if (meta.bytes < n_contigs * sizeof(ContigMeta)) meta.alloc(n_contigs * sizeof(ContigMeta), w.live(), w.peak());
+        if (text.bytes < n_chars + 64) text.alloc(n_chars + 64, w.live(), w.peak());
+        hipLaunchKernelGGL(unitig_write_kernel, dim3((unsigned)((pn + 63) / 64)), dim3(64), 0, w.st, g, ends.as<int64_t>(), rec.as<PathRec>(), emit_len.as<uint32_t>(),
+                           idx.as<uint64_t>(), off.as<uint64_t>(), p0, pn, meta.as<ContigMeta>(), text.as<char>());
+        MGTA_HIP_CHECK(hipGetLastError());
+        const size_t m0 = out.meta.size(), t0 = out.text.size();
+        out.meta.resize(m0 + n_contigs);
+        out.text.resize(t0 + n_chars);
+        MGTA_HIP_CHECK(hipMemcpyAsync(out.meta.data() + m0, meta.p, n_contigs * sizeof(ContigMeta), hipMemcpyDeviceToHost, w.st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(out.text.data() + t0, text.p, n_chars, hipMemcpyDeviceToHost, w.st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(w.st));
+        for (size_t i = m0; i < out.meta.size(); ++i) out.meta[i].offset += char_base;
+        char_base += n_chars;
+    }
+    note(w, "unitigs: %zu contigs, %zu characters written", out.meta.size(), out.text.size());
 }
 
 }  // namespace
@@ -879,7 +986,6 @@ int mgta_denovo(mgta_sdbg *graph, int max_tip_len, int no_bubble, int min_contig
         w.d.g = graph->dev;
         w.d.rw = graph->lines.as<GLine>();
         const GraphDev &g = w.d.g;
-        std::string text;
         if (g.size > 0) {
             w.mask.alloc((g.n_lines + 1) * 8, w.live(), w.peak());
             w.count.alloc((g.n_lines + 1) * 4, w.live(), w.peak());
@@ -906,25 +1012,50 @@ int mgta_denovo(mgta_sdbg *graph, int max_tip_len, int no_bubble, int min_contig
             s.n_paths = c.n_paths;
             s.n_unitig_sweeps = c.n_sweeps;
             s.n_contigs = (int64_t)c.meta.size();
-            text.reserve(c.text.size() + c.meta.size() * 64);
-            char head[160];
-            long long id = 0;
-            for (const ContigMeta &m : c.meta) {                                      // WriteContig, unitig_graph.cpp:134-150
-                ++id;
-                const double multi = std::min(65535.0, (double)m.depth / (double)m.length);
-                int hl = snprintf(head, sizeof head, ">k%d_%lld flag=%d multi=%.4lf len=%d\n", g.k, id, m.flag, multi, (int)m.len);
-                text.append(head, (size_t)hl);
-                text.append(c.text.data() + m.offset, m.len);
-                text.push_back('\n');
-                s.total_len += m.len;
-            }
+            // WriteContig, unitig_graph.cpp:134-150: ">k{K}_{id} flag={f} multi={%.4lf} len={L}\n{seq}\n", ids in emission order.  The
+            // headers are formatted by several host threads (57.8 M of them took 16 s on one), each into its own piece of the text.
+            const size_t nc = c.meta.size();
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)16, nc / 4096 + 1}));
+            std::vector<std::string> piece(nt);
+            std::vector<std::thread> th;
+            auto fmt = [&](unsigned t) {
+                const size_t i0 = nc * t / nt, i1 = nc * (t + 1) / nt;
+                std::string &o = piece[t];
+                size_t chars = 0;
+                for (size_t i = i0; i < i1; ++i) chars += c.meta[i].len;
+                o.reserve(chars + (i1 - i0) * 56);
+                char head[160];
+                for (size_t i = i0; i < i1; ++i) {
+                    const ContigMeta &m = c.meta[i];
+                    const double multi = std::min(65535.0, (double)m.depth / (double)m.length);
+                    const int hl = snprintf(head, sizeof head, ">k%d_%lld flag=%d multi=%.4lf len=%d\n", g.k, (long long)(i + 1), m.flag, multi, (int)m.len);
+                    o.append(head, (size_t)hl);
+                    o.append(c.text.data() + m.offset, m.len);
+                    o.push_back('\n');
+                }
+            };
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(fmt, t);
+            fmt(0);
+            for (auto &x : th) x.join();
+            for (const ContigMeta &m : c.meta) s.total_len += m.len;
+            std::vector<char>().swap(c.text);
+            size_t total = 0;
+            for (const std::string &o : piece) total += o.size();
+            char *buf = (char *)malloc(total + 1);
+            if (!buf) { set_error("mgta_denovo: out of host memory"); return MGTA_ENOMEM; }
+            size_t at = 0;
+            for (std::string &o : piece) { memcpy(buf + at, o.data(), o.size()); at += o.size(); std::string().swap(o); }
+            buf[total] = 0;
+            *fasta = buf;
+            *fasta_len = total;
+            if (stats) *stats = s;
+            return MGTA_OK;
         }
-        char *buf = (char *)malloc(text.size() + 1);
+        char *buf = (char *)malloc(1);
         if (!buf) { set_error("mgta_denovo: out of host memory"); return MGTA_ENOMEM; }
-        memcpy(buf, text.data(), text.size());
-        buf[text.size()] = 0;
+        buf[0] = 0;
         *fasta = buf;
-        *fasta_len = text.size();
+        *fasta_len = 0;
         if (stats) *stats = s;
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }

@@ -239,9 +239,14 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
             want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
             assert st0["n_retries"] == 0
             try:
-                for kb in (256, 1024, 4096, 16384):
+                for kb in (256, 1024, 4096, 16384, 65536):
                     ctx.set_search_arena(7, kb << 10)
-                    got, st = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)
+                    try:
+                        got, st = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)
+                    except api.MegaGtaError as e:         # a pool that cannot hold even the lowest running search alone: a loud error
+                        assert "do not fit" in str(e)
+                        sizes.append((window, kb, "error"))
+                        continue
                     sizes.append((window, kb, st["n_retries"]))
                     seen_yield |= st["n_retries"] > 0
                     assert st["n_expansions"] == st0["n_expansions"], sizes

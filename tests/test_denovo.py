@@ -111,13 +111,15 @@ def test_device_ordered_rounds(ctx, oracle):
     assert gst["n_bubble_rounds"] >= 2 and gst["n_bubble_candidates"] >= gst["n_bubbles"]
     # tiny windows (pending candidates carried from window to window) and a reach limit that no region fits (every candidate holds back
     # all higher ones: one commit per round at worst) must give the same contigs
-    for knob, value in (("MGTA_DENOVO_WINDOW", "64"), ("MGTA_DENOVO_REACH_MAX", "8")):
+    # ... and so must a stamp table (the hash of (edge -> round, rank) that replaced round 2's 8 bytes per edge) of 256 slots: most
+    # candidates cannot stamp their reach, they and everything above them wait, the next window is a quarter of the size
+    for knob, value in (("MGTA_DENOVO_WINDOW", "64"), ("MGTA_DENOVO_REACH_MAX", "8"), ("MGTA_DENOVO_STAMP_LOG2", "8"), ("MGTA_DENOVO_STAMP_LOG2", "11")):
         os.environ[knob] = value
         try:
             got2, gst2 = api.Graph(ctx, st.edges()).denovo(150, False, 0)
         finally:
             del os.environ[knob]
-        assert got2 == want and gst2["n_bubble_rounds"] > gst["n_bubble_rounds"], knob
+        assert got2 == want and gst2["n_bubbles"] == wst["n_bubbles"] and gst2["n_bubble_rounds"] > gst["n_bubble_rounds"], (knob, value)
 
 
 @pytest.mark.gpu

@@ -147,34 +147,42 @@ def test_config4_five_genes_two_ranks_every_artefact_equals_the_one_gpu_run(five
     assert "on 2 GPUs" in log and "rank 1 of 2" in log
 
 
-def test_split_gene_agreement_fraction(five_gene_inputs):
+def test_split_gene_agreement_fraction(tmp_path):
     """more ranks than genes: the seeds of ONE gene are dealt round-robin to two ranks, each windows over its own half.  The result is
-    deterministic for a given (seed order, N, B) but not the one-rank result: how far apart they are is measured and bounded here, on the
-    raw contigs of a two-gene list searched by 4 ranks (2 + 2) against `megagta search` on the same files"""
+    deterministic for a given (seed order, N, B) but NOT the one-rank result.  Input chosen (scripts/explore_window_effects.py) so that
+    sharing really matters: 4x coverage, 2 % errors, prune 10 -- cold and sequential runs differ on 166 of 9427 seeds there, and the
+    two-rank run differs from the one-rank run on about 1 % of the seeds.  How far apart they are is measured, printed and bounded."""
     assert os.path.exists(BIN)
-    d = five_gene_inputs
-    out = d / "out1"
-    if not (out / "k44" / "44.sdbg_info").exists():
-        pytest.skip("needs the driver run of test_config4_five_genes_two_ranks_every_artefact_equals_the_one_gpu_run")
-    gl2 = d / "gene_list_2.txt"
-    gl2.write_text("".join(open(d / "models" / "gene_list.txt").readlines()[:2]))
-    pre = str(out / "k44" / "44")
-    env = {**os.environ, "MEGAGTA_CACHE_WINDOW": "4", "MEGAGTA_CACHE_COST_RATE": "0"}
-    subprocess.run([BIN, "search", pre, str(gl2), pre, str(d / "s1"), "20", "0.5", "4"], check=True, capture_output=True, env=env)
+    d = tmp_path
+    mg = synth.make_metagenome(20000, 150, (("g", 277),), seed=6, reads_per_genome=300, genome_len=12000, aa_sub=0.03, err=0.02)
+    synth.write_lib_bin(mg.reads, str(d / "reads.lib"))
+    gl = synth.write_gene_models(mg.genes, str(d / "models"))
+    run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
+    run([BIN, "buildgraph", "-k", "44", "-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4",
+         "--num_output_threads", "1", "--read_lib_file", str(d / "reads.lib"), "--output_prefix", str(d / "44")])
+    faa = open(gl).readline().split()[3]
+    with open(d / "44_g_starting_kmers.txt", "wb") as f:
+        f.write(run([BIN, "findstart", faa, str(d / "reads.lib.bin"), "45", "4"]).stdout)
+    pre = str(d / "44")
+    env = {**os.environ, "MEGAGTA_CACHE_WINDOW": "8", "MEGAGTA_CACHE_COST_RATE": "0"}
+    run([BIN, "search", pre, gl, pre, str(d / "s1"), "10", "0.5", "4"], env=env)
+    run([BIN, "search", pre, gl, pre, str(d / "cold"), "10", "0.5", "4"], env={**env, "MEGAGTA_CACHE_WINDOW": "0"})
     script = os.path.join(ROOT, "megagta_amd", "search_dist.py")
     runs = []
-    for rep in range(2):                                              # twice: the four-rank result is the same on every run
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "4",
-                            script, pre, str(gl2), pre, str(d / f"s4_{rep}"), "20", "0.5", "4"], capture_output=True, text=True, env={**env, **ONE_GPU})
+    for rep in range(2):                                              # twice: the two-rank result is the same on every run
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
+                            script, pre, gl, pre, str(d / f"s2_{rep}"), "10", "0.5", "4"], capture_output=True, text=True, env={**env, **ONE_GPU})
         assert r.returncode == 0, r.stderr[-3000:]
-        runs.append({g: (d / f"s4_{rep}_raw_contigs_{g}.fasta").read_bytes() for g in ("rplB", "nirK")})
+        runs.append((d / f"s2_{rep}_raw_contigs_g.fasta").read_bytes())
     assert runs[0] == runs[1]
-    for g in ("rplB", "nirK"):
-        a, b = _seqs(d / f"s4_0_raw_contigs_{g}.fasta"), _seqs(d / f"s1_raw_contigs_{g}.fasta")
-        assert len(a) == len(b) > 64
-        same_pos = sum(1 for x, y in zip(a, b) if x == y)
-        common = sum((Counter(a) & Counter(b)).values())
-        print(f"split gene {g}: {len(a)} seeds over 2 ranks, window 4: {same_pos} contigs equal the one-rank run seed by seed, {common} as a multiset")
-        assert common >= 0.9 * len(b), (g, common, len(b))
-        names = [l for l in open(d / f"s4_0_raw_contigs_{g}.fasta") if l.startswith(">")]
-        assert names == [l for l in open(d / f"s1_raw_contigs_{g}.fasta") if l.startswith(">")]
+    a, b, c = _seqs(d / "s2_0_raw_contigs_g.fasta"), _seqs(d / "s1_raw_contigs_g.fasta"), _seqs(d / "cold_raw_contigs_g.fasta")
+    assert len(a) == len(b) == len(c) > 5000
+    differ = sum(1 for x, y in zip(a, b) if x != y)
+    common = sum((Counter(a) & Counter(b)).values())
+    cold_differ = sum(1 for x, y in zip(c, b) if x != y)
+    print(f"split gene: {len(a)} seeds over 2 ranks, window 8: {differ} contigs differ from the one-rank run seed by seed ({100.0 * differ / len(a):.2f} %), "
+          f"{common} equal as a multiset ({100.0 * common / len(a):.2f} %); no sharing at all differs on {cold_differ}")
+    assert cold_differ > 0 and differ > 0, "the input was chosen because sharing changes contigs on it"
+    assert common >= 0.97 * len(b), (common, len(b))
+    names = [l for l in open(d / "s2_0_raw_contigs_g.fasta") if l.startswith(">")]
+    assert names == [l for l in open(d / "s1_raw_contigs_g.fasta") if l.startswith(">")]

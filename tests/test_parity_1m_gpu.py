@@ -1,0 +1,106 @@
+"""Parity above toy size: 1 M reads x 150 bp (rplB + nirK, 500 genomes, 53 M edges), every stage of the hot path against the REFERENCE
+BINARY run on the same box on the same files (oracle/_ref/megagta; about a minute and a half of its time):
+  buildgraph  edge stream bit-exact (and the .sdbg file itself byte-identical)
+  denovo      contigs byte-identical to the reference's one-thread run
+  findstart   the same seed lines
+  search      the default mode of `megagta search` (ordered-commit window + cost term) against the reference's sequential `search ... 1`
+              on 6000 seeds: equal as multisets up to a measured, asserted fraction; window 1 on a prefix byte-identical
+The size-only class of bug (a dispatch of more than 2^32 work-items, 32-bit edge ids) needs 100 M reads and is covered by bench.py's
+sampled membership leg; this test is the largest reference-compared input."""
+import hashlib
+import os
+import subprocess
+import time
+from collections import Counter
+
+import pytest
+
+from megagta_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
+BIN = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
+N_READS = 1_000_000
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/megagta (the prebuilt reference) is not present")
+    assert os.path.exists(BIN), "megagta_amd/bin/megagta missing: run __graft_entry__.build()"
+    d = tmp_path_factory.mktemp("parity1m")
+    mg = synth.make_metagenome(N_READS, 150, (("rplB", 277), ("nirK", 360)), seed=77)
+    synth.write_lib_bin(mg.reads, str(d / "reads.lib"))
+    synth.write_gene_models(mg.genes, str(d / "models"))
+    return d
+
+
+def _run(cmd, **kw):
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, **kw)
+    assert r.returncode == 0, (cmd[:3], r.stderr.decode(errors="replace")[-2000:])
+    return r, time.time() - t
+
+
+def test_buildgraph_1m_reads_vs_reference(big, oracle):
+    d = big
+    common = ["-k", "44", "-m", "1", "--host_mem", "32000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_output_threads", "1",
+              "--read_lib_file", str(d / "reads.lib")]
+    _, t_ref = _run([REF, "buildgraph", "--output_prefix", str(d / "ref"), "--num_cpu_threads", str(min(64, os.cpu_count() or 8))] + common)
+    _, t_ours = _run([BIN, "buildgraph", "--output_prefix", str(d / "ours"), "--num_cpu_threads", "4"] + common)
+    a, b = oracle.Stream.read(str(d / "ours")).edges(), oracle.Stream.read(str(d / "ref")).edges()
+    assert a.records.size == b.records.size > 50_000_000
+    assert a.md5() == b.md5()
+    same_file = hashlib.md5(open(d / "ours.sdbg.0", "rb").read()).hexdigest() == hashlib.md5(open(d / "ref.sdbg.0", "rb").read()).hexdigest()
+    print(f"parity 1M buildgraph: {a.records.size} edges, {a.tips.size // a.words_per_tip} tips, stream md5 equal; .sdbg.0 byte-identical: {same_file}; "
+          f"reference {t_ref:.1f} s, ours {t_ours:.1f} s (process wall, files included)")
+    assert same_file and open(d / "ours.sdbg_info").read() == open(d / "ref.sdbg_info").read()
+
+
+def test_denovo_1m_reads_vs_reference_one_thread(big):
+    d = big
+    if not os.path.exists(d / "ours.sdbg_info"):
+        pytest.skip("needs test_buildgraph_1m_reads_vs_reference")
+    args = ["--min_standalone", "400", "--max_tip_len", "150", "--min_contig", "46"]
+    _, t_ref = _run([REF, "denovo", "-s", str(d / "ref"), "-o", str(d / "ref"), "-t", "1"] + args)
+    _, t_ours = _run([BIN, "denovo", "-s", str(d / "ours"), "-o", str(d / "ours"), "-t", "4"] + args)
+    a, b = open(d / "ours.contigs.fa", "rb").read(), open(d / "ref.contigs.fa", "rb").read()
+    print(f"parity 1M denovo: {a.count(b'>')} contigs, {len(a)} bytes; reference -t 1 {t_ref:.1f} s, ours {t_ours:.1f} s")
+    assert a == b and a.count(b">") > 100_000
+    assert open(d / "ours.contigs.fa.info").read() == open(d / "ref.contigs.fa.info").read()
+
+
+def test_findstart_and_search_1m_reads_vs_reference(big):
+    d = big
+    if not os.path.exists(d / "ours.sdbg_info"):
+        pytest.skip("needs test_buildgraph_1m_reads_vs_reference")
+    genes = {l.split()[0]: l.split() for l in open(d / "models" / "gene_list.txt")}
+    n_take = {"rplB": 6000, "nirK": 2000}
+    for g, a in genes.items():
+        r_ref, t_ref = _run([REF, "findstart", a[3], str(d / "reads.lib.bin"), "45", "16"])
+        r_ours, t_ours = _run([BIN, "findstart", a[3], str(d / "reads.lib.bin"), "45", "4"])
+        ref_lines, ours_lines = sorted(r_ref.stdout.decode().splitlines()), r_ours.stdout.decode().splitlines()
+        print(f"parity 1M findstart {g}: {len(ours_lines)} seeds; reference {t_ref:.1f} s, ours {t_ours:.1f} s")
+        assert ours_lines == ref_lines and len(ours_lines) > n_take[g]
+        # every n-th seed: the sample spans all genomes (the sorted file groups similar k-mers)
+        step = len(ours_lines) // n_take[g]
+        open(d / f"s_{g}_starting_kmers.txt", "w").write("\n".join(ours_lines[::step][: n_take[g]]) + "\n")
+    gl = str(d / "models" / "gene_list.txt")
+    _, t_ref = _run([REF, "search", str(d / "ref"), gl, str(d / "s"), str(d / "ref1"), "20", "0.5", "1"])
+    _, t_ours = _run([BIN, "search", str(d / "ours"), gl, str(d / "s"), str(d / "dflt"), "20", "0.5", "4"])
+    _, t_w1 = _run([BIN, "search", str(d / "ours"), gl, str(d / "s"), str(d / "w1"), "20", "0.5", "4"], env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
+    _, t_cold = _run([BIN, "search", str(d / "ours"), gl, str(d / "s"), str(d / "cold"), "20", "0.5", "4"], env={**os.environ, "MEGAGTA_CACHE_WINDOW": "0"})
+    seqs = lambda p: [l for l in open(p).read().splitlines() if l and l[0] != ">"]
+    for g in genes:
+        ref = seqs(d / f"ref1_raw_contigs_{g}.fasta")
+        assert open(d / f"w1_raw_contigs_{g}.fasta", "rb").read() == open(d / f"ref1_raw_contigs_{g}.fasta", "rb").read(), g   # window 1 == `search ... 1`
+        dflt, cold = seqs(d / f"dflt_raw_contigs_{g}.fasta"), seqs(d / f"cold_raw_contigs_{g}.fasta")
+        assert len(dflt) == len(ref) == n_take[g]
+        common = sum((Counter(dflt) & Counter(ref)).values())
+        same_pos = sum(1 for x, y in zip(dflt, ref) if x == y)
+        cold_pos = sum(1 for x, y in zip(cold, ref) if x == y)
+        print(f"parity 1M search {g}: {len(ref)} seeds; default mode (window 1024 + cost term) vs reference `search ... 1`: {same_pos} equal seed by seed, "
+              f"{common} as a multiset ({100.0 * common / len(ref):.2f} %); cold (no sharing) equal seed by seed: {cold_pos}; "
+              f"reference 1 thread {t_ref:.1f} s, ours default {t_ours:.1f} s, window 1 {t_w1:.1f} s, cold {t_cold:.1f} s (both genes)")
+        assert common >= 0.97 * len(ref), (g, common, len(ref))
