@@ -47,7 +47,7 @@ void launch_astar(const mgta::AstarArgs &a, int blocks, size_t lds_bytes, bool u
     MGTA_HIP_CHECK(hipGetLastError());
 }
 template <int G> size_t lds_fixed() {
-    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::kLdsHeapSlots * sizeof(mgta::HeapEnt) + 2 * mgta::kMaxLevels * sizeof(uint32_t));
+    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::Grp<G>::kLdsHeap * sizeof(mgta::HeapEnt) + 2 * mgta::kMaxLevels * sizeof(uint32_t));
 }
 }  // namespace
 
@@ -173,7 +173,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         // wide; with the small windows + cost term `megagta search` uses now 16 lanes win at every size measured (7.4 k / 9.7 k seeds:
         // 2.0 / 3.0 s vs 2.6 / 4.6 s; 18 k / 24 k: 3.0 / 3.9 s vs 5.0 / 10.0 s, profiles/r02/e2e_window_sweep.log).  MGTA_ASTAR_GROUP=16|32|64 overrides.
         int G = 16;
-        if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) G = v; }
+        if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
 
@@ -198,7 +198,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         d_prof.alloc(128);
         MGTA_HIP_CHECK(hipMemsetAsync(d_prof.p, 0, 128, st));
         a.prof = d_prof.as<unsigned long long>();
-        const size_t lds_fix = G == 16 ? lds_fixed<16>() : G == 32 ? lds_fixed<32>() : lds_fixed<64>();
+        const size_t lds_fix = G == 8 ? lds_fixed<8>() : G == 16 ? lds_fixed<16>() : G == 32 ? lds_fixed<32>() : lds_fixed<64>();
         const bool use_lds = lds_fix + tab_bytes + 1024 <= 160 * 1024;             // heap tops + level tables + HMM tables
         const size_t lds_bytes = lds_fix + (use_lds ? tab_bytes : 0);
 
@@ -319,7 +319,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 a.todo[d] = d_todo[d].as<int64_t>(); a.n_todo[d] = (int64_t)todo[d].size();
             }
             MGTA_HIP_CHECK(hipEventRecord(ev.e[2], st));
-            if (G == 16) launch_astar<16>(a, (int)blocks, lds_bytes, use_lds, st);
+            if (G == 8) launch_astar<8>(a, (int)blocks, lds_bytes, use_lds, st);
+            else if (G == 16) launch_astar<16>(a, (int)blocks, lds_bytes, use_lds, st);
             else if (G == 32) launch_astar<32>(a, (int)blocks, lds_bytes, use_lds, st);
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));

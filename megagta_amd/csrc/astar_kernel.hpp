@@ -25,7 +25,9 @@ constexpr int kAstarThreads = kAstarWaves * 64;
 constexpr uint32_t kNone = 0x7FFFFFFFu;
 constexpr int kMaxKmer = 160;
 constexpr int kMaxLevels = 20;                 // levels of a growable array (level l >= 1 doubles the capacity)
-constexpr uint32_t kLdsHeapSlots = 72;         // heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels)
+// heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels); with 8 lanes per search (twice the
+// searches per workgroup) the root block and four child blocks, so that the HMM tables of a 360-column model still fit beside them
+constexpr uint32_t lds_heap_slots(int G) { return G >= 16 ? 72u : 40u; }
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
@@ -317,7 +319,12 @@ __device__ __forceinline__ void store_ent(HeapEnt *p, const HeapEnt &e) {
 // ---- group (= one search) primitives: G consecutive lanes ---------------------------------------------------------------------
 template <int G> struct Grp {
     static constexpr int kGroups = 64 / G;
-    static constexpr int kLog = G == 64 ? 6 : G == 32 ? 5 : 4;
+    static constexpr int kLog = G == 64 ? 6 : G == 32 ? 5 : G == 16 ? 4 : 3;
+    static constexpr uint32_t kLdsHeap = lds_heap_slots(G);
+    // the <= 16 (first edge, second edge) pairs of an expansion are walked by min(G, 16) lanes at a time: G = 8 takes the first edges
+    // 0 and 1 in one pass and comes back for 2 and 3 only when the node has them (one node in a few hundred)
+    static constexpr int kWalkLanes = G >= 16 ? 16 : G;
+    static constexpr int kPasses = 16 / kWalkLanes;
     static constexpr uint64_t kMask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
     __device__ static __forceinline__ uint64_t ballot(bool p, int gbase) { return (__ballot(p) >> gbase) & kMask; }
     template <class T> __device__ static __forceinline__ T bcast(T v, int src, int gbase) { return __shfl(v, gbase + src, 64); }
@@ -346,16 +353,16 @@ __device__ __forceinline__ uint32_t heap_slots_needed(uint32_t n) {
 }
 
 template <int G> struct Heap {
-    HeapEnt *lds;                 // this search's first kLdsHeapSlots slots
+    HeapEnt *lds;                 // this search's first Grp<G>::kLdsHeap slots
     HeapArr ar;
     int gl, gbase;
     __device__ __forceinline__ HeapEnt get(uint64_t i) const {
         const uint32_t s = heap_slot((uint32_t)i);
-        return s < kLdsHeapSlots ? lds[s] : load_ent(reinterpret_cast<const HeapEnt *>(ar.at(s)));
+        return s < Grp<G>::kLdsHeap ? lds[s] : load_ent(reinterpret_cast<const HeapEnt *>(ar.at(s)));
     }
     __device__ __forceinline__ void set(uint64_t i, const HeapEnt &e) const {
         const uint32_t s = heap_slot((uint32_t)i);
-        if (s < kLdsHeapSlots) lds[s] = e; else store_ent(reinterpret_cast<HeapEnt *>(ar.at(s)), e);
+        if (s < Grp<G>::kLdsHeap) lds[s] = e; else store_ent(reinterpret_cast<HeapEnt *>(ar.at(s)), e);
     }
     // __push_heap(first, hole, 0, v) (bits/stl_heap.h): every lane of the group calls it with the same arguments
     __device__ __forceinline__ void sift_up(uint64_t hole, const HeapEnt &v) const {
@@ -579,6 +586,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     constexpr uint32_t SPB = kAstarWaves * GROUPS;
     extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][level tables: nodes, heap][HMM tables]
     HeapEnt *const s_heap = reinterpret_cast<HeapEnt *>(s_mem);
+    constexpr uint32_t kLdsHeapSlots = GX::kLdsHeap;
     uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * kLdsHeapSlots * sizeof(HeapEnt));
     double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + 2 * kMaxLevels * sizeof(uint32_t)));
 
@@ -988,28 +996,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 const int cached_st = cached >= 0 ? (cached >> 9) : -1;
 
-                // ---- enumeration of the <= 64 codon paths (node_enumerator.h:98-128): lane (i, j) walks two edges and owns the <= 4
-                // third edges that continue from there
-                int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-                const int ci = (gl >> 2) & 3, cj = gl & 3;
-                int64_t e1 = 0, e2 = 0;
-                bool valid = gl < 16 && ci < g_out_nth(g, curr.node_id, ci, e1);
-                int od3 = 0, c12 = 0, low12 = 0;
-                if (valid) {
-                    valid = cj < g_out_nth(g, e1 >> 4, cj, e2);
-                    if (valid) {
-                        od3 = g_out_all(g, e2 >> 4, p0, p1, p2, p3);
-                        if (od3 < 0) od3 = 0;
-                        c12 = (((int)(e1 & 7) - 1) << 6) | (((int)(e2 & 7) - 1) << 3);
-                        low12 = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1);
-                    }
-                }
-                if (!valid) od3 = 0;
                 n_expanded++;
                 if (a.gate && a.cost_rate != 0 && (n_expanded & 63) == 0 && gl == 0 && n_expanded > prog_floor)
                     __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-                PROF(5)
                 // ---- children (node_enumerator.h:131-244)
                 double mt, it, dt;
                 if (cst == ST_M) { mt = tsc[T_MM * M1 + curr.state_no]; it = tsc[T_MI * M1 + curr.state_no]; dt = tsc[T_MD * M1 + curr.state_no]; }
@@ -1017,24 +1007,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 else { mt = tsc[T_IM * M1 + curr.state_no]; it = tsc[T_II * M1 + curr.state_no]; dt = NEG_INF; }
                 const double max_match = maxm[next_state];
                 const double h_m = hc[next_state], h_i = hc[M1 + curr.state_no], h_d = hc[2 * M1 + next_state];
-
-                // which of this lane's codons pass (stop codons :142-144; a cached child keeps only its own codon :146-148)
-                int use_bits = 0, cols = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
-                    if (k < od3) {
-                        const int codon = c12 | ((int)(e3 & 7) - 1);
-                        const int col = hv.col_enum[((codon >> 6) & 7) * 16 + ((codon >> 3) & 7) * 4 + (codon & 7)];
-                        bool use = col >= 0;
-                        if (use && cached >= 0) use = cached_st == ST_D ? ((e3 >> 4) == curr.node_id) : (codon == (cached & 511));
-                        if (use) { use_bits |= 1 << k; cols |= col << (8 * k); }
-                    }
-                }
-                const bool any_pass = GX::ballot(use_bits != 0, gbase) != 0ull;
                 // a cached match/insert child ends the enumeration at that child (:178-181,207-210)
                 const bool ins_ok = cst != ST_D && cached_st != ST_M;
-                const bool want_del = cst != ST_I && !((cached_st == ST_M || cached_st == ST_I) && any_pass);
 
                 // ---- admission (hmm_graph_search.h:288-311): prune test + open_hash lookup, all children in parallel
                 auto admissible = [&](int length, int negative_count, double real_score) {
@@ -1061,86 +1035,18 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 cd.score = curr.score + (dt - max_match);
                 cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
                 cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
-                bool del = want_del;
+                // (whether a cached match / insert child suppresses the delete child is known once every codon has been looked at: the
+                // probe is issued now, the verdict follows the passes)
+                bool del = cst != ST_I;
                 if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score);
                 const bool probe_d = del && !first;
                 const uint64_t key_d = make_key(cd.node_id, cd.state_no, ST_D);
                 const uint32_t slot_d = (uint32_t)mix64(key_d) & hmask;
                 uint4 vd = make_uint4(0, 0, 0, 0);
                 if (probe_d) vd = ld_slot(slot_d);
-                // node indices are handed out codon rank by codon rank (k), lane by lane, match before insert: the pool order is not
-                // observable, only the order of the commits below is
-                uint32_t nbase = n_nodes;
-                uint64_t MM = 0, MI = 0;                                               // admitted match / insert children: bit 16 k + lane
-                int fm0 = 0, fm1 = 0, fm2 = 0, fm3 = 0, fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (__ballot((use_bits >> k) & 1) == 0ull) continue;               // (uniform over the active lanes)
-                    const bool use = (use_bits >> k) & 1;
-                    const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
-                    const int codon = c12 | ((int)(e3 & 7) - 1);
-                    const int low = low12 & (int)((e3 >> 3) & 1);
-                    const int col = (cols >> (8 * k)) & 255;
-                    ANode cm, cin;                                                     // this codon's match / insert child
-                    cm.parent = cur; cin.parent = cur;
-                    cm.node_id = e3 >> 4; cin.node_id = e3 >> 4;
-                    cm.length = (int16_t)(curr.length + 1); cin.length = cm.length;
-                    cm.state_no = (int16_t)next_state; cin.state_no = curr.state_no;
-                    cm.em_state = (uint16_t)(codon | (ST_M << 9)); cin.em_state = (uint16_t)(codon | (ST_I << 9));
-                    const double pen = low ? a.low_cov_penalty : 0.0;                  // :150
-                    {
-                        const double e = mt + (use ? msc[(size_t)next_state * A + col] : 0.0);
-                        cm.real_score = curr.real_score + e - pen;
-                        if (cm.real_score >= curr.max_score) { cm.max_score = cm.real_score; cm.negative_count = 0; }
-                        else { cm.max_score = curr.max_score; cm.negative_count = (int16_t)(curr.negative_count + 1); }
-                        cm.score = curr.score + (e - pen - max_match);
-                        cm.fval = to_fval(10000 * (cm.score + 2.0 * h_m));             // :173
-                        const double ei = it + (next_state == M ? NEG_INF : 0.0);      // isc == 0 except at node M
-                        cin.real_score = curr.real_score + ei - pen;
-                        cin.max_score = curr.max_score;
-                        cin.negative_count = (int16_t)(curr.negative_count + 1);
-                        cin.score = curr.score + (ei - pen);
-                        cin.fval = to_fval(10000 * (cin.score + 2.0 * h_i));
-                    }
-                    bool open_m = use, open_i = use && ins_ok;
-                    if (!first) {                                                      // :212-233: the first expansion neither prunes nor looks up
-                        open_m = open_m && admissible(cm.length, cm.negative_count, cm.real_score);
-                        open_i = open_i && admissible(cin.length, cin.negative_count, cin.real_score);
-                        const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
-                        const uint32_t slot_m = (uint32_t)mix64(key_m) & hmask, slot_i = (uint32_t)mix64(key_i) & hmask;
-                        uint4 vm = make_uint4(0, 0, 0, 0), vi = vm;
-                        if (open_m) vm = ld_slot(slot_m);
-                        if (open_i) vi = ld_slot(slot_i);
-                        uint32_t om = kNone, oi = kNone;
-                        if (open_m) om = resolve(key_m, slot_m, vm);
-                        if (open_i) oi = resolve(key_i, slot_i, vi);
-                        int old_m = 0, old_i = 0;
-                        if (om != kNone) old_m = node_at(om)->fval;
-                        if (oi != kNone) old_i = node_at(oi)->fval;
-                        if (om != kNone) open_m = old_m < cm.fval;                     // got->second < next (:299-302); equal keys => only fval differs
-                        if (oi != kNone) open_i = old_i < cin.fval;
-                    }
-                    const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
-                    const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
-                    if (open_m) store_node(node_at(idx_m), cm);
-                    if (open_i) store_node(node_at(idx_m + (open_m ? 1u : 0u)), cin);
-                    nbase += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
-                    MM |= (mm & 0xFFFFull) << (16 * k);
-                    MI |= (mi & 0xFFFFull) << (16 * k);
-                    if (k == 0) { fm0 = cm.fval; fi0 = cin.fval; } else if (k == 1) { fm1 = cm.fval; fi1 = cin.fval; }
-                    else if (k == 2) { fm2 = cm.fval; fi2 = cin.fval; } else { fm3 = cm.fval; fi3 = cin.fval; }
-                }
-                if (probe_d) {
-                    const uint32_t od = resolve(key_d, slot_d, vd);
-                    if (od != kNone) del = node_at(od)->fval < cd.fval;
-                }
-                const uint32_t idx_d = nbase;
-                if (del && gl == 0) store_node(node_at(idx_d), cd);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
-                PROF(6)
                 // ---- commit in the reference's order: open_hash[next] = next (:331) and open.push (:335), codon by codon
-                // (ascending lane, then k), match before insert, delete last
+                // (ascending (first edge, second edge), then third edge), match before insert, delete last
                 auto commit = [&](uint64_t key, int fval, uint32_t node) {
                     HeapEnt he;
                     he.key = key; he.fval = fval; he.node = node;
@@ -1154,29 +1060,153 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     H.sift_up(n_heap, he);
                     ++n_heap;
                 };
-                const uint64_t anyk = MM | MI;
-                uint32_t lanes_todo = (uint32_t)((anyk | (anyk >> 16) | (anyk >> 32) | (anyk >> 48)) & 0xFFFFull);
-                while (lanes_todo) {
-                    const int l = __builtin_ctz(lanes_todo);
-                    lanes_todo &= lanes_todo - 1;
-                    // this lane's children in k order; what they need from lane l: the third edges and the fvals
-                    const int64_t q0 = GX::bcast(p0, l, gbase), q1 = GX::bcast(p1, l, gbase), q2 = GX::bcast(p2, l, gbase), q3 = GX::bcast(p3, l, gbase);
-                    const uint32_t below = (1u << l) - 1u;
-                    uint32_t kbase = n_nodes;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t mmk = (uint32_t)(MM >> (16 * k)) & 0xFFFFu, mik = (uint32_t)(MI >> (16 * k)) & 0xFFFFu;
-                        const bool hm_ = (mmk >> l) & 1u, hi_ = (mik >> l) & 1u;
-                        if (hm_ || hi_) {
-                            const int64_t e3 = k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3;
-                            const uint32_t idx = kbase + (uint32_t)__popc(mmk & below) + (uint32_t)__popc(mik & below);
-                            if (hm_) commit(make_key(e3 >> 4, next_state, ST_M), GX::bcast(k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3, l, gbase), idx);
-                            if (hi_) commit(make_key(e3 >> 4, curr.state_no, ST_I), GX::bcast(k == 0 ? fi0 : k == 1 ? fi1 : k == 2 ? fi2 : fi3, l, gbase),
-                                            idx + (hm_ ? 1u : 0u));
+
+                // ---- enumeration of the <= 64 codon paths (node_enumerator.h:98-128): lane (i, j) walks two edges and owns the <= 4
+                // third edges that continue from there.  kWalkLanes (i, j) pairs per pass, ascending: with 8 lanes per search the first
+                // pass takes the first edges 0 and 1, a second one (rare: a node with three or four out-edges) the first edges 2 and 3.
+                // The children of a pass are admitted, stored and committed before the next pass walks: their keys are distinct (distinct
+                // end nodes), so a later child's look-up never meets an earlier child of the same expansion, as in the reference's loop.
+                bool any_pass = false;
+                bool more = true;
+                uint32_t nbase = n_nodes;
+#pragma unroll 1
+                for (int pass = 0; pass < GX::kPasses; ++pass) {
+                    if (more) {
+                        int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+                        const int vl = gl + GX::kWalkLanes * pass;
+                        const int ci = (vl >> 2) & 3, cj = vl & 3;
+                        int64_t e1 = 0, e2 = 0;
+                        int od1 = 0;
+                        bool valid = gl < GX::kWalkLanes;
+                        if (valid) { od1 = g_out_nth(g, curr.node_id, ci, e1); valid = ci < od1; }
+                        if (GX::kPasses > 1) od1 = GX::bcast(od1, 0, gbase);
+                        int od3 = 0, c12 = 0, low12 = 0;
+                        if (valid) {
+                            valid = cj < g_out_nth(g, e1 >> 4, cj, e2);
+                            if (valid) {
+                                od3 = g_out_all(g, e2 >> 4, p0, p1, p2, p3);
+                                if (od3 < 0) od3 = 0;
+                                c12 = (((int)(e1 & 7) - 1) << 6) | (((int)(e2 & 7) - 1) << 3);
+                                low12 = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1);
+                            }
                         }
-                        kbase += (uint32_t)__popc(mmk) + (uint32_t)__popc(mik);
+                        if (!valid) od3 = 0;
+                        PROF(5)
+                        // which of this lane's codons pass (stop codons :142-144; a cached child keeps only its own codon :146-148)
+                        int use_bits = 0, cols = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                            if (k < od3) {
+                                const int codon = c12 | ((int)(e3 & 7) - 1);
+                                const int col = hv.col_enum[((codon >> 6) & 7) * 16 + ((codon >> 3) & 7) * 4 + (codon & 7)];
+                                bool use = col >= 0;
+                                if (use && cached >= 0) use = cached_st == ST_D ? ((e3 >> 4) == curr.node_id) : (codon == (cached & 511));
+                                if (use) { use_bits |= 1 << k; cols |= col << (8 * k); }
+                            }
+                        }
+                        any_pass = any_pass || GX::ballot(use_bits != 0, gbase) != 0ull;
+                        // node indices are handed out codon rank by codon rank (k), lane by lane, match before insert: the pool order is
+                        // not observable, only the order of the commits below is
+                        const uint32_t n_before = nbase;
+                        uint64_t MM = 0, MI = 0;                                       // admitted match / insert children: bit 16 k + lane
+                        int fm0 = 0, fm1 = 0, fm2 = 0, fm3 = 0, fi0 = 0, fi1 = 0, fi2 = 0, fi3 = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (__ballot((use_bits >> k) & 1) == 0ull) continue;       // (uniform over the active lanes)
+                            const bool use = (use_bits >> k) & 1;
+                            const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                            const int codon = c12 | ((int)(e3 & 7) - 1);
+                            const int low = low12 & (int)((e3 >> 3) & 1);
+                            const int col = (cols >> (8 * k)) & 255;
+                            ANode cm, cin;                                             // this codon's match / insert child
+                            cm.parent = cur; cin.parent = cur;
+                            cm.node_id = e3 >> 4; cin.node_id = e3 >> 4;
+                            cm.length = (int16_t)(curr.length + 1); cin.length = cm.length;
+                            cm.state_no = (int16_t)next_state; cin.state_no = curr.state_no;
+                            cm.em_state = (uint16_t)(codon | (ST_M << 9)); cin.em_state = (uint16_t)(codon | (ST_I << 9));
+                            const double pen = low ? a.low_cov_penalty : 0.0;          // :150
+                            {
+                                const double e = mt + (use ? msc[(size_t)next_state * A + col] : 0.0);
+                                cm.real_score = curr.real_score + e - pen;
+                                if (cm.real_score >= curr.max_score) { cm.max_score = cm.real_score; cm.negative_count = 0; }
+                                else { cm.max_score = curr.max_score; cm.negative_count = (int16_t)(curr.negative_count + 1); }
+                                cm.score = curr.score + (e - pen - max_match);
+                                cm.fval = to_fval(10000 * (cm.score + 2.0 * h_m));     // :173
+                                const double ei = it + (next_state == M ? NEG_INF : 0.0);   // isc == 0 except at node M
+                                cin.real_score = curr.real_score + ei - pen;
+                                cin.max_score = curr.max_score;
+                                cin.negative_count = (int16_t)(curr.negative_count + 1);
+                                cin.score = curr.score + (ei - pen);
+                                cin.fval = to_fval(10000 * (cin.score + 2.0 * h_i));
+                            }
+                            bool open_m = use, open_i = use && ins_ok;
+                            if (!first) {                                              // :212-233: the first expansion neither prunes nor looks up
+                                open_m = open_m && admissible(cm.length, cm.negative_count, cm.real_score);
+                                open_i = open_i && admissible(cin.length, cin.negative_count, cin.real_score);
+                                const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
+                                const uint32_t slot_m = (uint32_t)mix64(key_m) & hmask, slot_i = (uint32_t)mix64(key_i) & hmask;
+                                uint4 vm = make_uint4(0, 0, 0, 0), vi = vm;
+                                if (open_m) vm = ld_slot(slot_m);
+                                if (open_i) vi = ld_slot(slot_i);
+                                uint32_t om = kNone, oi = kNone;
+                                if (open_m) om = resolve(key_m, slot_m, vm);
+                                if (open_i) oi = resolve(key_i, slot_i, vi);
+                                int old_m = 0, old_i = 0;
+                                if (om != kNone) old_m = node_at(om)->fval;
+                                if (oi != kNone) old_i = node_at(oi)->fval;
+                                if (om != kNone) open_m = old_m < cm.fval;             // got->second < next (:299-302); equal keys => only fval differs
+                                if (oi != kNone) open_i = old_i < cin.fval;
+                            }
+                            const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
+                            const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
+                            if (open_m) store_node(node_at(idx_m), cm);
+                            if (open_i) store_node(node_at(idx_m + (open_m ? 1u : 0u)), cin);
+                            nbase += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
+                            MM |= (mm & 0xFFFFull) << (16 * k);
+                            MI |= (mi & 0xFFFFull) << (16 * k);
+                            if (k == 0) { fm0 = cm.fval; fi0 = cin.fval; } else if (k == 1) { fm1 = cm.fval; fi1 = cin.fval; }
+                            else if (k == 2) { fm2 = cm.fval; fi2 = cin.fval; } else { fm3 = cm.fval; fi3 = cin.fval; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        PROF(6)
+                        const uint64_t anyk = MM | MI;
+                        uint32_t lanes_todo = (uint32_t)((anyk | (anyk >> 16) | (anyk >> 32) | (anyk >> 48)) & 0xFFFFull);
+                        while (lanes_todo) {
+                            const int l = __builtin_ctz(lanes_todo);
+                            lanes_todo &= lanes_todo - 1;
+                            // this lane's children in k order; what they need from lane l: the third edges and the fvals
+                            const int64_t q0 = GX::bcast(p0, l, gbase), q1 = GX::bcast(p1, l, gbase), q2 = GX::bcast(p2, l, gbase), q3 = GX::bcast(p3, l, gbase);
+                            const uint32_t below = (1u << l) - 1u;
+                            uint32_t kbase = n_before;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint32_t mmk = (uint32_t)(MM >> (16 * k)) & 0xFFFFu, mik = (uint32_t)(MI >> (16 * k)) & 0xFFFFu;
+                                const bool hm_ = (mmk >> l) & 1u, hi_ = (mik >> l) & 1u;
+                                if (hm_ || hi_) {
+                                    const int64_t e3 = k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3;
+                                    const uint32_t idx = kbase + (uint32_t)__popc(mmk & below) + (uint32_t)__popc(mik & below);
+                                    if (hm_) commit(make_key(e3 >> 4, next_state, ST_M), GX::bcast(k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3, l, gbase), idx);
+                                    if (hi_) commit(make_key(e3 >> 4, curr.state_no, ST_I), GX::bcast(k == 0 ? fi0 : k == 1 ? fi1 : k == 2 ? fi2 : fi3, l, gbase),
+                                                    idx + (hm_ ? 1u : 0u));
+                                }
+                                kbase += (uint32_t)__popc(mmk) + (uint32_t)__popc(mik);
+                            }
+                        }
+                        PROF(7)
+                        more = od1 > ((GX::kWalkLanes * (pass + 1)) >> 2);               // the node has first edges beyond this pass
                     }
+                    if (GX::kPasses == 1 || __ballot(more) == 0ull) break;
                 }
+                // the delete child, last (:218-244)
+                if (del && (cached_st == ST_M || cached_st == ST_I) && any_pass) del = false;
+                if (del && probe_d) {
+                    const uint32_t od = resolve(key_d, slot_d, vd);
+                    if (od != kNone) del = node_at(od)->fval < cd.fval;
+                }
+                const uint32_t idx_d = nbase;
+                if (del && gl == 0) store_node(node_at(idx_d), cd);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (del) commit(make_key(cd.node_id, cd.state_no, ST_D), cd.fval, idx_d);
                 n_nodes = nbase + (del ? 1u : 0u);
                 if (first) {

@@ -763,6 +763,7 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
 struct BubbleWork {
     DevBuf scratch, stamp_key, stamp_val, marked, status, win[2], pos[2], ok, keep, base, tmp, small;
     uint64_t stamp_mask = 0;
+    int64_t n_crowded = 0;   // rounds in which the stamp table turned a candidate away
     size_t per = 0;          // int64 of scratch per candidate
     uint32_t window = 0;
     int reach_max = kReachMax;
@@ -809,7 +810,7 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         carry = (uint32_t)read_u64(w, w.total.p);
         cur ^= 1;
         const uint32_t done = mm - carry;
-        if (flags[2]) cap = std::max<uint32_t>(1, m / 4);              // some candidate could not stamp even what it reads: fewer candidates share the table next time
+        if (flags[2]) { cap = std::max<uint32_t>(1, m / 2); ++b.n_crowded; }   // some candidate could not stamp even what it reads: fewer candidates share the table next time
         else if (cap < b.window) cap = std::min<uint32_t>(b.window, cap * 2);
         if (done == 0 && !(flags[2] && m > 1)) { set_error("mgta_denovo: a bubble round committed nothing"); throw HipError{MGTA_EINTERNAL}; }   // the lowest always commits
         want = std::min<uint32_t>(b.window, std::max<uint32_t>(std::min<uint32_t>(4096, b.window), 4 * std::max(done, 1u)));
@@ -842,10 +843,11 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     n_candidates = (int64_t)nc;
     note(w, "bubbles: %llu branching edges, %llu candidates, window %u", (unsigned long long)nb, (unsigned long long)nc, b.window);
     if (nc == 0) return 0;
-    // the stamp table: 2^25 .. 2^28 slots of 16 bytes (0.5 .. 4 GB) -- a window of 29 k candidates stamps a few hundred edges each; what
-    // does not fit is held back and the next window is smaller.  MGTA_DENOVO_STAMP_LOG2 (tests): a tiny table exercises that path.
-    int stamp_log = 25;
-    while (stamp_log < 28 && (1ull << stamp_log) < (uint64_t)g.size / 8) ++stamp_log;
+    // the stamp table: one slot of 16 bytes per edge up to 2^29 slots (8 GB, whatever the size of the graph beyond that) -- a window of
+    // 29 k candidates stamps up to 16 k edges each, a few hundred as a rule; what does not fit is held back and the next window is
+    // smaller.  MGTA_DENOVO_STAMP_LOG2 (tests): a tiny table exercises that path.
+    int stamp_log = 22;
+    while (stamp_log < 29 && (1ull << stamp_log) < (uint64_t)g.size) ++stamp_log;
     if (const char *e = getenv("MGTA_DENOVO_STAMP_LOG2")) stamp_log = std::min(30, std::max(8, atoi(e)));
     b.stamp_mask = (1ull << stamp_log) - 1;
     b.stamp_key.alloc((b.stamp_mask + 1) * 8, w.live(), w.peak());
@@ -875,6 +877,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
         hipLaunchKernelGGL(flag_equals_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, w.st, b.status.as<uint32_t>(), na, 1u, flag.as<uint32_t>(),
                            counter.as<unsigned long long>());
     }
+    note(w, "bubbles: %lld rounds, the stamp table (2^%d slots) was crowded in %lld of them", (long long)n_rounds, stamp_log, (long long)b.n_crowded);
     return read_u64(w, counter.p);
 }
 

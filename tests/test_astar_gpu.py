@@ -48,9 +48,10 @@ def _check_side(got, ref):
     assert got["n_closed"] == ref["closed"]
 
 
-@pytest.fixture(params=[(16, 0), (64, 0), (16, 7), (64, 7)], ids=["g16", "g64", "g16-grow", "g64-grow"])
+@pytest.fixture(params=[(16, 0), (64, 0), (16, 7), (64, 7), (8, 0), (8, 7)], ids=["g16", "g64", "g16-grow", "g64-grow", "g8", "g8-grow"])
 def search_mode(request, ctx):
-    """lanes per search (16: four searches per wavefront; 64: one) x base arena (0 = default 4096 nodes; 7 = 128 nodes: every search
+    """lanes per search (8: eight searches per wavefront, the (first edge, second edge) pairs walked in two passes; 16: four searches;
+    64: one) x base arena (0 = default 4096 nodes; 7 = 128 nodes: every search
     of the goldens then outgrows its base arena and re-hashes several times)"""
     group, log_b0 = request.param
     os.environ["MGTA_ASTAR_GROUP"] = str(group)
