@@ -57,7 +57,8 @@ struct HeapEnt {                  // 16 bytes; the priority (fval, -state_no, st
 struct HashEnt {
     uint64_t key;                 // node_id << 18 | state_no << 2 | (state + 1); 0 = empty
     uint32_t val;                 // open-list node index (kNone = none) | closed << 31
-    uint32_t pad;
+    int32_t fval;                 // fval of that node: the admission test `got->second < next` (hmm_graph_search.h:299-302) is answered by
+                                  // the probe itself, without a second dependent fetch of the node
 };
 static_assert(sizeof(HeapEnt) == 16 && sizeof(HashEnt) == 16, "entry layout");
 
@@ -401,6 +402,11 @@ template <int G> struct Heap {
             const int p = gl + 1 - (1 << (t - 1));
             const int parent_lane = t > 1 ? (1 << (t - 2)) - 1 + (p >> 1) : 0;
             int levels = 2;                                            // the root block holds two levels below the root
+            // the entry that ends up right above the final hole is the one the last step moved there: known without a load, and it is
+            // all __push_heap needs to look at when the former last entry stays below it (the usual case)
+            HeapEnt par;
+            par.key = 0; par.fval = 0; par.node = 0;
+            bool have_par = false;
             while (hole < half) {
                 const int64_t P = ((hole + 1) << (t - 1)) - 1 + p;    // the node whose two children this lane holds
                 const bool has = t <= levels && P < half;
@@ -421,14 +427,18 @@ template <int G> struct Heap {
                 if ((path >> gl) & 1ull) set((uint64_t)P, ch);                    // every node of the path moves up one level
                 const int deepest = 63 - __builtin_clzll(path);                   // path != 0: the hole has two children
                 hole = Grp<G>::bcast(pick_left ? 2 * P + 1 : 2 * P + 2, deepest, gbase);
+                par.key = Grp<G>::bcast(ch.key, deepest, gbase); par.fval = Grp<G>::bcast(ch.fval, deepest, gbase); par.node = Grp<G>::bcast(ch.node, deepest, gbase);
+                have_par = true;
                 levels = 3;
             }
             if ((len & 1) == 0 && hole == (len - 2) / 2) {             // a last, single (left) child
                 const HeapEnt ce = get((uint64_t)(2 * hole + 1));
                 if (gl == 0) set((uint64_t)hole, ce);
                 hole = 2 * hole + 1;
+                par = ce; have_par = true;
             }
-            sift_up((uint64_t)hole, v);
+            if (have_par && !(ent_prio(par) < ent_prio(v))) { if (gl == 0) set((uint64_t)hole, v); }   // __push_heap stops at once
+            else sift_up((uint64_t)hole, v);
         }
     }
 };
@@ -457,8 +467,8 @@ __device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask
         i = (i + 1) & hmask;
     }
 }
-__device__ __forceinline__ void hash_put(HashEnt *tab, uint32_t i, uint64_t key, uint32_t val) {
-    *reinterpret_cast<uint4 *>(tab + i) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), val, 0u);
+__device__ __forceinline__ void hash_put(HashEnt *tab, uint32_t i, uint64_t key, uint32_t val, int32_t fval = 0) {
+    *reinterpret_cast<uint4 *>(tab + i) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), val, (uint32_t)fval);
 }
 
 // child descriptor cached for `key` and visible to seed `seed`, or -1
@@ -860,6 +870,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 bool have = false;
                 uint32_t hs = 0, hval = kNone;
                 uint64_t hkey = 0;
+                bool hfound = false;
                 while (n_heap > 0) {
                     const HeapEnt top = H.get(0);
                     const uint32_t t0 = touch(hash + ((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node)),
@@ -873,6 +884,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     cur = (int32_t)top.node;
                     hkey = top.key;
                     if (!found) ++n_keys;                                              // (children of the first expansion are not in open_hash)
+                    hfound = found;
                     have = true;
                     break;
                 }
@@ -885,7 +897,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         if (better) inter = cur;
                         ok = 1; goal = inter; stop = true;
                     } else {
-                        if (gl == 0) hash_put(hash, hs, hkey, hval | 0x80000000u);     // closed.insert (:272)
+                        if (gl == 0) {                                                 // closed.insert (:272); the entry keeps its node and fval
+                            if (hfound) hash[hs].val = hval | 0x80000000u;
+                            else hash_put(hash, hs, hkey, hval | 0x80000000u);
+                        }
                         n_closed++;
                         if (better) { inter = cur; inter_val = cv; }                   // :274-277
                     }
@@ -947,6 +962,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                                 if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&nt[j].key), &expect, k, __ATOMIC_RELAXED,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                                     __hip_atomic_store(&nt[j].val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&nt[j].fval, (int32_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     break;
                                 }
                                 j = (j + 1) & nmask;
@@ -1017,11 +1033,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // the probes of one expansion are independent: their first loads are issued together, then resolved, then the fvals of
                 // the open-list entries they found are fetched together (three dependent round trips instead of six)
                 auto ld_slot = [&](uint32_t ii) { return *reinterpret_cast<const uint4 *>(hash + ii); };
-                auto resolve = [&](uint64_t key, uint32_t ii, uint4 v) -> uint32_t {     // open-list node recorded for `key`, kNone = none
+                auto resolve = [&](uint64_t key, uint32_t ii, uint4 v, int &old_fval) -> uint32_t {     // open-list node recorded for `key` (+ its fval), kNone = none
                     while (true) {
                         const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
                         if (k == 0) return kNone;
-                        if (k == key) return v.z & kNone;
+                        if (k == key) { old_fval = (int)v.w; return v.z & kNone; }
                         ii = (ii + 1) & hmask;
                         v = ld_slot(ii);
                     }
@@ -1053,7 +1069,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (!first) {
                         bool found; uint32_t val;
                         const uint32_t hs = hash_find(hash, hmask, key, found, val);
-                        if (gl == 0) hash_put(hash, hs, key, (found ? (val & 0x80000000u) : 0u) | node);
+                        if (gl == 0) hash_put(hash, hs, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
                         if (!found) ++n_keys;
                         n_opened++;
                     }
@@ -1150,11 +1166,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                                 if (open_m) vm = ld_slot(slot_m);
                                 if (open_i) vi = ld_slot(slot_i);
                                 uint32_t om = kNone, oi = kNone;
-                                if (open_m) om = resolve(key_m, slot_m, vm);
-                                if (open_i) oi = resolve(key_i, slot_i, vi);
                                 int old_m = 0, old_i = 0;
-                                if (om != kNone) old_m = node_at(om)->fval;
-                                if (oi != kNone) old_i = node_at(oi)->fval;
+                                if (open_m) om = resolve(key_m, slot_m, vm, old_m);
+                                if (open_i) oi = resolve(key_i, slot_i, vi, old_i);
                                 if (om != kNone) open_m = old_m < cm.fval;             // got->second < next (:299-302); equal keys => only fval differs
                                 if (oi != kNone) open_i = old_i < cin.fval;
                             }
@@ -1201,8 +1215,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // the delete child, last (:218-244)
                 if (del && (cached_st == ST_M || cached_st == ST_I) && any_pass) del = false;
                 if (del && probe_d) {
-                    const uint32_t od = resolve(key_d, slot_d, vd);
-                    if (od != kNone) del = node_at(od)->fval < cd.fval;
+                    int old_d = 0;
+                    const uint32_t od = resolve(key_d, slot_d, vd, old_d);
+                    if (od != kNone) del = old_d < cd.fval;
                 }
                 const uint32_t idx_d = nbase;
                 if (del && gl == 0) store_node(node_at(idx_d), cd);

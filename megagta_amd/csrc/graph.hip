@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256) void graph_invalid_kernel(const GLine *lines, 
 extern "C" {
 
 // records / tip labels in host memory (`resident` false) or still on the device where the build left them (true: no copy of the records)
+// (`recs_owner`: a device buffer of the caller that holds `recs` and nothing else -- released as soon as the lines are packed, before
+// the rank tables are built: at 2 bytes per edge it is as large as the graph itself)
 static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
-                      int64_t n_tip_words, int words_per_tip, bool resident, mgta_sdbg **out) {
+                      int64_t n_tip_words, int words_per_tip, bool resident, mgta_sdbg **out, DevBuf *recs_owner = nullptr) {
     try {
         MGTA_HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
@@ -198,12 +200,17 @@ static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, 
                 dev_recs = d_recs.as<uint16_t>();
             }
             d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
             hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_lines + 3) / 4, 1u << 22)), dim3(256), 0, st, dev_recs, size,
                                g->lines.as<GLine>(), n_lines, d_cnt.as<uint32_t>());
             MGTA_HIP_CHECK(hipGetLastError());
+            if (!resident || recs_owner) {                                   // the records have done their part
+                MGTA_HIP_CHECK(hipStreamSynchronize(st));
+                d_recs.release();
+                if (recs_owner) recs_owner->release();
+            }
+            d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+            d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
             uint64_t tot[6];
             for (int c = 0; c < 6; ++c)
                 exclusive_scan_u32(st, d_cnt.as<uint32_t>() + c * n_lines, n_lines, d_base.as<uint64_t>() + c * n_lines, d_tmp.as<uint64_t>(),
@@ -371,7 +378,7 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
         for (auto &e : ev) (void)hipEventDestroy(e);
         d_piece[0].release(); d_piece[1].release();
         if (bad) { set_error("%s: %u buckets do not parse to the sizes the index gives", prefix.c_str(), bad); return MGTA_EINVAL; }
-        return load_graph(ctx, k, d_recs.as<uint16_t>(), (int64_t)total, items.data(), d_tips.as<uint32_t>(), (int64_t)ntips * wpt, wpt, true, out);
+        return load_graph(ctx, k, d_recs.as<uint16_t>(), (int64_t)total, items.data(), d_tips.as<uint32_t>(), (int64_t)ntips * wpt, wpt, true, out, &d_recs);
     } catch (const HipError &e) { return e.code; }
 }
 

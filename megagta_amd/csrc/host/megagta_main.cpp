@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <thread>
 #include <string>
 #include <vector>
@@ -51,8 +52,13 @@ struct Session {
     mgta_ctx *ctx2 = nullptr;     // second context of the device: the other lane of a two-gene search
     mgta_sdbg *graph = nullptr;   // graph of the last buildgraph, not used yet
     std::string graph_prefix;
+    std::thread writer;           // PREFIX.sdbg.* of the last buildgraph being written while the next step already runs on the resident graph
 };
 static Session g_sess;
+// the graph files of the last buildgraph are complete (called before anything reads them, before the next build, at the end)
+static void writer_join() {
+    if (g_sess.writer.joinable()) g_sess.writer.join();
+}
 
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
@@ -97,6 +103,7 @@ static mgta_sdbg *graph_get(mgta_ctx *ctx, const std::string &prefix, int *k_out
         return g;
     }
     graph_drop();
+    writer_join();
     mgta_sdbg *g = nullptr;                                              // the files are copied to the device as they are and parsed there
     if (mgta_sdbg_load_files(ctx, prefix.c_str(), &g) != MGTA_OK) die("mgta_sdbg_load_files: %s", mgta_last_error());
     *k_out = mgta_sdbg_k(g); *n_edges = (size_t)mgta_sdbg_size(g);
@@ -180,6 +187,7 @@ static int main_buildgraph(int argc, char **argv) {
     const int share = (65536 + world - 1) / world, b_lo = std::min(65536, rank * share), b_hi = std::min(65536, (rank + 1) * share);
 
     double t0 = now_s();
+    writer_join();
     PackedReads local;
     PackedReads::Mark mk;
     PackedReads &pr = lib_get(lib_file + ".bin", lib_file, local, mk);
@@ -197,7 +205,8 @@ static int main_buildgraph(int argc, char **argv) {
     // (measured: 194 GB cost 5.3 s before the first kernel ran), which outweighs the few extra bucket-range passes of a tighter budget
     // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  A resident caller (bench, multi-k API) keeps the pool.
     mgta_ctx_set_mem_limit(ctx, gpu_mem > 0 ? (uint64_t)gpu_mem : (64ull << 30));
-    EdgeStream s;
+    std::shared_ptr<EdgeStream> sp = std::make_shared<EdgeStream>();
+    EdgeStream &s = *sp;
     s.k = k; s.words_per_tip = (2 * k + 31) / 32;
     mgta_build_stats st;
     mgta_reads *rd = nullptr;
@@ -223,18 +232,25 @@ static int main_buildgraph(int argc, char **argv) {
     ctx_put(ctx);
     logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
          (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);
-    double t1 = now_s();
-    if (world == 1) write_sdbg(out_prefix, s);
-    else {
-        write_sdbg(out_prefix, s, rank, b_lo, b_hi, true);
-        logf("rank %d of %d: buckets [%d, %d) -> %s.sdbg.%d", rank, world, b_lo, b_hi, out_prefix.c_str(), rank);
-    }
-    long long nw[9] = {0};
-    for (uint16_t r : s.recs) nw[r & 15]++;
-    logf("Number of $ A C G T A- C- G- T-:");                           // s2_post_proc, cx1_read2sdbg_s2.cpp:899-915
-    logf("%lld %lld %lld %lld %lld %lld %lld %lld %lld", nw[0], nw[1], nw[2], nw[3], nw[4], nw[5], nw[6], nw[7], nw[8]);
-    logf("Total number of edges: %zu", s.recs.size());
-    logf("Total number of $v edges: %zu (write %.3f s)", s.words_per_tip ? s.tips.size() / s.words_per_tip : 0, now_s() - t1);
+    // the files: the run's artefacts, what `--continue` resumes from and what a one-shot process reads.  In the worker the step that
+    // follows works on the resident graph, so they are written by a host thread behind it (joined before anything reads them)
+    auto write_files = [sp, out_prefix, world, rank, b_lo, b_hi]() {
+        const EdgeStream &s = *sp;
+        double t1 = now_s();
+        if (world == 1) write_sdbg(out_prefix, s);
+        else {
+            write_sdbg(out_prefix, s, rank, b_lo, b_hi, true);
+            logf("rank %d of %d: buckets [%d, %d) -> %s.sdbg.%d", rank, world, b_lo, b_hi, out_prefix.c_str(), rank);
+        }
+        long long nw[9] = {0};
+        for (uint16_t r : s.recs) nw[r & 15]++;
+        logf("Number of $ A C G T A- C- G- T-:");                           // s2_post_proc, cx1_read2sdbg_s2.cpp:899-915
+        logf("%lld %lld %lld %lld %lld %lld %lld %lld %lld", nw[0], nw[1], nw[2], nw[3], nw[4], nw[5], nw[6], nw[7], nw[8]);
+        logf("Total number of edges: %zu", s.recs.size());
+        logf("Total number of $v edges: %zu (write %.3f s)", s.words_per_tip ? s.tips.size() / s.words_per_tip : 0, now_s() - t1);
+    };
+    if (hand_over && !getenv("MEGAGTA_SYNC_WRITES")) g_sess.writer = std::thread(write_files);
+    else write_files();
     return 0;
 }
 
@@ -674,6 +690,7 @@ static int main_serve() {
         fflush(rep);
     }
     graph_drop();
+    writer_join();
     if (g_sess.ctx2) mgta_ctx_destroy(g_sess.ctx2);
     if (g_sess.ctx) mgta_ctx_destroy(g_sess.ctx);
     return 0;
