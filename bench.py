@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=60000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
     ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="small set on which the reference's thread count is chosen before it runs on the e2e set (0 = no reference run)")
+    ap.add_argument("--product-seeds", type=int, default=100_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -308,7 +309,7 @@ def main():
     gene_specs = tuple((g.split(":")[0], int(g.split(":")[1])) for g in args.genes.split(","))
     # identical synthetic read set on every rank (seeded), generated and packed on the device
     t0 = time.time()
-    host_sample = max(args.cpu_sample if not args.no_cpu_baseline else 0, 1) if rank == 0 and world == 1 else 1
+    host_sample = max(args.cpu_sample, 1) if rank == 0 and world == 1 else 1      # (the CPU baseline's sample; also the reads the product-mode seeds come from)
     mg = synth.make_metagenome_device(args.reads, L, gene_specs, seed=1, device=f"cuda:{local_rank}", host_sample=host_sample)
     t_gen = time.time() - t0
     note(f"{args.reads} reads generated and packed on the device in {t_gen:.1f} s")
@@ -384,7 +385,11 @@ def main():
             fs_hits += int(fhits.size)
             # the product's seeds of the reads the host holds a copy of (the CPU-baseline sample): unique k-mers in sorted order, as
             # `megagta findstart` writes them, for the product-mode search leg below
-            product_seeds.append(product_seed_list(fhits, mg.sample_reads, fwords, _fpos, args.k) if rank == 0 and world == 1 else [])
+            ps_all = product_seed_list(fhits, mg.sample_reads, fwords, _fpos, args.k) if rank == 0 and world == 1 else []
+            # (a contiguous block of the sorted list, at most --product-seeds per gene: neighbours in that order share their paths, which
+            # is what the ordered window lives on; the whole list of the sample is a quarter of a million seeds per gene at 100 M reads)
+            lo_ = max(0, (len(ps_all) - args.product_seeds) // 2)
+            product_seeds.append(ps_all[lo_:lo_ + args.product_seeds])
             del fhits
         findstart_leg = {"ms_kernel": fs_ms, "windows_per_s": len(mg.genes) * args.reads * (L - args.k + 1) * 2 / (fs_ms * 1e-3), "hits": fs_hits,
                          "note": "mgta_findstart, both strands, k=%d, one scan per gene (%d genes)" % (args.k, len(mg.genes))}
@@ -465,8 +470,9 @@ def main():
             pdt = time.time() - t
             search["product_mode"] = {"value": tot_e / max(1e-9, tot_ms * 1e-3), "unit": "HMM-scored node expansions/s", "seeds_per_s": sum(len(x) for x in product_seeds) / pdt,
                                       "seconds": pdt, "genes": per_gene,
-                                      "note": "findstart's seeds of the first %d reads (sorted, unique), default mode of `megagta search` (ordered-commit window + cost "
-                                              "term) on the %d-edge graph; `value` above is the cold mode on synthetic seeds" % (mg.sample_reads.shape[0], graph.size)}
+                                      "note": "findstart's seeds of the first %d reads (sorted, unique; a contiguous block of at most %d per gene), default mode of "
+                                              "`megagta search` (ordered-commit window + cost term) on the %d-edge graph; `value` above is the cold mode on "
+                                              "synthetic seeds" % (mg.sample_reads.shape[0], args.product_seeds, graph.size)}
             note(f"search, product mode: {sum(len(x) for x in product_seeds)} seeds in {pdt:.1f} s, {tot_e / max(1e-9, tot_ms * 1e-3) / 1e6:.1f} M expansions/s")
         if world == 1 and (args.reads <= 20_000_000 or args.denovo):
             # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits)

@@ -257,7 +257,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             // hundred; 16 MB for batches of a million searches and more (20 M reads: 68 GB in use at most, 93 GB handed out).  No new search starts while half
             // of it is in use, so a small pool costs searches in flight, not failures.
             const uint64_t n_search = (uint64_t)work * 2;
-            const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : n_search >= (1ull << 20) ? (16ull << 20) : (8ull << 20);
+            // (graphs of billions of edges: the searches run longer, the 8 MB that serve a 2 M-read graph starved nirK's at 100 M reads)
+            const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : (n_search >= (1ull << 20) || g->dev.size > (3ll << 30)) ? (16ull << 20) : (8ull << 20);
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
                                                  : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);

@@ -130,7 +130,8 @@ struct AstarArgs {
     long long *run_seed;          // [slots] seed a search slot is working on (a lower bound while it is taking one from the queue), -1 = none
     unsigned long long *run_progress;   // [slots] expansions of that search so far (lags; only ever too small)
     unsigned long long *start_limit;    // [0..1] highest seed index known to be allowed to start (monotone cache of the gate), [2..3] time of the last
-                                        // refresh by a waiting wave, [4] the pass has given up (no further seed is taken)
+                                        // refresh by a waiting wave, [4] the pass has given up (no further seed is taken), [5] the call
+                                        // for memory (call_for_memory)
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
@@ -551,6 +552,24 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
     return bound;
 }
 
+// start_limit[5]: the call for memory of a search nobody may overtake (the lowest running one when it starves, or one that waits to start
+// again): first28 << 28 | last28, times in units of 1024 ticks of the 100 MHz clock (~10 us) of the first and the latest call of the
+// episode (calls less than 50 ms apart).  The LEVEL of the call is its age in 10 ms steps: starved searches with fewer than
+// 256 << 2 level expansions give their memory back, so the ones with the least work to lose go first and everybody after 100 ms.
+__device__ __forceinline__ void call_for_memory(const AstarArgs &a) {
+    const unsigned long long now = (__builtin_amdgcn_s_memrealtime() >> 10) & 0xFFFFFFFull, word = ld_agent(&a.start_limit[5]);
+    const unsigned long long last = word & 0xFFFFFFFull, first = (word >> 28) & 0xFFFFFFFull;
+    const bool going = word != 0ull && ((now - last) & 0xFFFFFFFull) < 5000ull;
+    st_agent(&a.start_limit[5], ((going ? first : now) << 28) | now);
+}
+__device__ __forceinline__ int memory_call_level(const AstarArgs &a) {          // -1: nobody is calling
+    const unsigned long long now = (__builtin_amdgcn_s_memrealtime() >> 10) & 0xFFFFFFFull, word = ld_agent(&a.start_limit[5]);
+    const unsigned long long last = word & 0xFFFFFFFull, first = (word >> 28) & 0xFFFFFFFull;
+    if (word == 0ull || ((now - last) & 0xFFFFFFFull) >= 5000ull) return -1;
+    const unsigned long long age = ((last - first) & 0xFFFFFFFull) / 1000ull;
+    return age > 12ull ? 12 : (int)age;
+}
+
 // Lowest search (2 * seed + direction) any slot of the launch is working on (-1: none).  Every lane of the WAVE calls it and returns the
 // same value.  Under the gate seeds are taken in order, so this is the one search nobody is ahead of: the one that never yields its memory.
 template <int G>
@@ -649,6 +668,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     int st = S_IDLE;
     bool need_scan = false;
     uint32_t spins = 0;
+    long long last_lim = -1;                                          // the start limit when this wave last looked (gate progress)
     long long seed = -1;
     int64_t sid = 0;
     uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0, cap_heap = 2 * B0;
@@ -680,7 +700,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             used = GX::bcast(used, 0, gbase);
             quit = GX::bcast(quit, 0, gbase);
             if (quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }       // (status stays 0: the pass is run again)
-            else if (used <= a.pool.soft_limit) st = S_START;
+            else if (used <= a.pool.soft_limit) { st = S_START; starved = 0; }
+            else if ((++starved & 255u) == 0u && gl == 0) call_for_memory(a);   // waiting for room is calling for room too (this may be the
+                                                                                 // lowest search of all: the running ones must not sit on what it waits for)
         }
         if (__ballot(st == S_BACKOFF) != 0ull && __ballot(st == S_START || st == S_RUN || st == S_DONE) == 0ull) {
 #pragma unroll
@@ -748,6 +770,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     lim = __shfl(lim, 0, 64);
                     quit = __shfl(quit, 0, 64);
                     if (st == S_WAIT && quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }   // the pass has given up and is run again
+                    if (lim != last_lim) { last_lim = lim; spins = 0; }     // the searches ahead are getting on: a long queue is not a hang
                     if (st == S_WAIT && lim >= seed) st = S_START;
                     if (__ballot(st == S_WAIT) != 0ull) {
                         int refresh = 0;
@@ -766,7 +789,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (st == S_WAIT && b >= seed) st = S_START;
                     need_scan = false;
                 }
-                if (st == S_WAIT && ++spins > (1u << 22)) {          // bounded wait: the host reports the seed
+                if (st == S_WAIT && ++spins > (1u << 22)) {          // bounded wait (counted while the limit stands still): the host reports the seed
                     if (gl == 0) { a.status[sid] = 4; st_agent(&a.run_seed[slot], -1ll); }
                     st = S_EXIT;
                 }
@@ -785,6 +808,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             const long long lo = lowest_running<G>(a, lane);
             if (st == S_RUN && yield_check) {
                 yield_check = false;
+                int level = -1;
+                if (gl == 0) { if (sid == lo) call_for_memory(a); else level = memory_call_level(a); }
+                level = GX::bcast(level, 0, gbase);
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
                     // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
@@ -795,11 +821,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     unsigned long long used = 0;
                     if (gl == 0) used = ld_agent(&a.pool.stat[4]);
                     used = GX::bcast(used, 0, gbase);
-                    if (used <= own) {
+                    if (used <= own || starved > (1u << 18)) {                       // (the second: a backstop -- no room for ten seconds of calling)
                         status = 2; st = S_DONE;
                         if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
                     }
-                } else {
+                } else if (level >= 0 && (uint64_t)n_expanded < (256ull << (2 * level))) {
                     if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
                         pool_release_fence();
                         if (gl == 0) {
@@ -991,10 +1017,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (++starved > patience) {
                     if (a.gate) {                                                      // ordered launch: yield in place (above), never a host re-run
                         if (((starved - patience) & 255u) == 1u) yield_check = true;
-                        if (starved > (1u << 18)) {                                    // (backstop) no room for seconds: the host starts the batch again
-                            status = 2; stop = true;
-                            if (gl == 0) st_agent(&a.start_limit[4], 1ull);
-                        }
                     } else { status = 2; stop = true; }
                 }
             } else {

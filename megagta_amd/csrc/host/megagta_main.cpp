@@ -336,7 +336,8 @@ static int main_search(int argc, char **argv) {
         //  200 k / 270 k: 8192 + 2  9.0 / 15.8  (8192 + 4: 10.3 / 16.7;  4096 + 4: 11.8 / 18.2);  414 k: 8192 + 2 14.4 (4096 + 2: 15.4)
         const size_t ns = kmers.size();
         const int window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
-        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
+        // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
+        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : window == 1 ? 0 : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);

@@ -1599,7 +1599,8 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     MGTA_HIP_CHECK(hipMemcpyAsync(d_plan, low.data(), low.size() * sizeof(Digit), hipMemcpyHostToDevice, stream));
     // room behind the stride for the last segment of a tile: ~2.5 average segments, an eighth of the tile at least, half at most
     const double avg_seg = avg_segment_len(n_items, P, tp.frac);
-    uint32_t margin = (uint32_t)std::min<double>(LocalCfg<WT>::kTile / 2, std::max<double>(LocalCfg<WT>::kTile / 8, 2.5 * avg_seg));
+    static const double margin_factor = getenv("MGTA_SORT_MARGIN") ? atof(getenv("MGTA_SORT_MARGIN")) : 2.5;      // (measurement knob)
+    uint32_t margin = (uint32_t)std::min<double>(LocalCfg<WT>::kTile / 2, std::max<double>(LocalCfg<WT>::kTile / 8, margin_factor * avg_seg));
     margin = (margin + 63u) & ~63u;
     const uint32_t stride = (uint32_t)LocalCfg<WT>::kTile - margin;
     const uint64_t l_blocks = (n_items + stride - 1) / stride;
