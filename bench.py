@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=60000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
     ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="small set on which the reference's thread count is chosen before it runs on the e2e set (0 = no reference run)")
-    ap.add_argument("--product-seeds", type=int, default=100_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
+    ap.add_argument("--product-seeds", type=int, default=60_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -391,6 +391,12 @@ int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
     }
     try {
         MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        if (ctx->acc_valid) {    // the build's key buffers (grow-only pool) are scratch; a graph of tens of billions of edges needs their room
+            size_t free_b = 0, total_b = 0;
+            MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t need = (uint64_t)((double)ctx->last_n_rec * 3.3) + (1ull << 30);      // lines 2.0 + line counts 0.4 + their prefix sums 0.75 bytes per edge
+            if ((uint64_t)free_b < need) { MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream)); ctx->pool.clear(); }
+        }
         if (ctx->acc_valid)      // a multi-pass build that kept its whole stream (mgta_ctx_keep_stream): records per bucket are on the host
             return load_graph(ctx, ctx->last_k, static_cast<const uint16_t *>(ctx->last_rec), (int64_t)ctx->last_n_rec, ctx->acc_items.data(),
                               static_cast<const uint32_t *>(ctx->last_tips), (int64_t)ctx->last_n_tips * ctx->last_words_per_tip,

@@ -35,6 +35,7 @@ T0 = time.time()
 threading.Thread(target=poll, daemon=True).start()
 t = time.time()
 mg = synth.make_metagenome_device(n, 150, genes, seed=1, device="cuda:0", host_sample=1)
+torch.cuda.empty_cache()
 phase(f"{n} reads generated and packed on the device", t)
 ctx = api.Context(0)
 rd = ctx.adopt_reads(mg.packed.data_ptr(), mg.n_words, mg.start.data_ptr(), mg.n_reads, keepalive=(mg.packed, mg.start))

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
 BIN = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
 N_READS = 1_000_000
-N_SEQ = 400          # seeds per gene of the strictly sequential (window 1) comparison
+N_SEQ = 100          # seeds per gene of the strictly sequential (window 1) comparison
 
 
 @pytest.fixture(scope="module")
