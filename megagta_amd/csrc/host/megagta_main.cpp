@@ -12,6 +12,7 @@
 #include <fcntl.h>
 #include <getopt.h>
 #include <sys/resource.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <sys/time.h>
 
@@ -47,8 +48,11 @@ struct Session {
     bool active = false;
     mgta_ctx *ctx = nullptr;
     std::string lib_key;          // path of the .bin the library was read from
-    PackedReads lib;              // reversed, NOT finished (sequences of one step are appended behind it and taken off again)
+    PackedReads lib;              // reversed; the contigs one step appended behind it stay for the next step that wants the same file
     bool lib_loaded = false;
+    PackedReads::Mark lib_mark{}; // end of the library proper
+    std::string extra_key;        // the contigs file behind it (path | size | mtime)
+    bool have_extra = false;
     mgta_ctx *ctx2 = nullptr;     // second context of the device: the other lane of a two-gene search
     mgta_sdbg *graph = nullptr;   // graph of the last buildgraph, not used yet
     std::string graph_prefix;
@@ -75,20 +79,39 @@ static mgta_ctx *ctx_get() {
 static void ctx_put(mgta_ctx *ctx) {
     if (!g_sess.active) mgta_ctx_destroy(ctx);
 }
-// the library of `bin_path` (reads.lib.bin), reversed; `mk` = its end (rewind to it when the step is over)
-static PackedReads &lib_get(const std::string &bin_path, const std::string &lib_prefix, PackedReads &local, PackedReads::Mark &mk) {
+// The library of `bin_path` (reads.lib.bin), reversed, with the sequences of `extra` (a FASTA of contigs: the assist sequences of
+// buildgraph, the contigs findstart scans with the reads) appended behind it, finished for upload.  `mk` = the end of the library
+// proper.  The worker keeps both between steps: a multi-k run reads the contigs of a k once for the buildgraph and the findstart calls
+// that use them (at 20 M reads: 0.8 GB of text, 1.5 s per parse), and never re-reads the library.
+static std::string file_key(const std::string &path) {
+    struct stat sb;
+    if (path.empty() || stat(path.c_str(), &sb) != 0) return path;
+    return path + "|" + std::to_string((long long)sb.st_size) + "|" + std::to_string((long long)sb.st_mtime) + "|" + std::to_string((long long)sb.st_mtim.tv_nsec);
+}
+static PackedReads &lib_get(const std::string &bin_path, const std::string &lib_prefix, const std::string &extra, bool extra_is_assist, PackedReads &local,
+                            PackedReads::Mark &mk) {
     PackedReads &pr = g_sess.active ? g_sess.lib : local;
     if (!(g_sess.active && g_sess.lib_loaded && g_sess.lib_key == bin_path)) {
         if (g_sess.active) { g_sess.lib = PackedReads(); g_sess.lib_loaded = false; }
         if (!lib_prefix.empty()) load_read_lib(lib_prefix, /*reverse=*/true, pr);       // cx1_read2sdbg_s1.cpp:97,117
         else load_read_bin(bin_path, /*reverse=*/true, pr);
-        if (g_sess.active) { g_sess.lib_loaded = true; g_sess.lib_key = bin_path; }
+        if (g_sess.active) { g_sess.lib_loaded = true; g_sess.lib_key = bin_path; g_sess.lib_mark = pr.mark(); g_sess.extra_key.clear(); g_sess.have_extra = false; }
+        else g_sess.lib_mark = pr.mark();
     }
-    mk = pr.mark();
+    mk = g_sess.lib_mark;
+    const std::string key = extra.empty() ? std::string() : file_key(extra);
+    if (g_sess.active && g_sess.have_extra && g_sess.extra_key == key) {
+        logf("library%s: still in memory", extra.empty() ? "" : " + contigs");
+        return pr;
+    }
+    pr.rewind(mk);
+    if (!extra.empty()) {
+        if (extra_is_assist) load_assist_fasta(extra, /*reverse=*/true, pr);            // :121-134
+        else load_fastx(extra, true, pr);
+    }
+    pr.finish();
+    if (g_sess.active) { g_sess.extra_key = key; g_sess.have_extra = true; }
     return pr;
-}
-static void lib_put(PackedReads &pr, const PackedReads::Mark &mk) {
-    if (g_sess.active) pr.rewind(mk);
 }
 static void graph_drop() {
     if (g_sess.graph) { mgta_sdbg_free(g_sess.graph); g_sess.graph = nullptr; g_sess.graph_prefix.clear(); }
@@ -190,10 +213,8 @@ static int main_buildgraph(int argc, char **argv) {
     writer_join();
     PackedReads local;
     PackedReads::Mark mk;
-    PackedReads &pr = lib_get(lib_file + ".bin", lib_file, local, mk);
+    PackedReads &pr = lib_get(lib_file + ".bin", lib_file, assist, true, local, mk);
     pr.n_short = mk.n_start ? mk.n_start - 1 : 0;                        // the library's reads; assist sequences follow
-    if (!assist.empty()) load_assist_fasta(assist, /*reverse=*/true, pr); // :121-134
-    pr.finish();
     logf("%zu reads, %d max read length, %llu total bases (load %.3f s)", pr.start.size() - 1, pr.max_len,
          (unsigned long long)pr.start.back(), now_s() - t0);
 
@@ -214,7 +235,6 @@ static int main_buildgraph(int argc, char **argv) {
     int rc = mgta_sdbg_build_resident(ctx, rd, pr.n_short, k, min_count, min_count > 1 ? need_mercy : 0, b_lo, b_hi, sink_collect, &s, &st);
     if (rc != MGTA_OK) die("mgta_sdbg_build: %s", mgta_last_error());
     mgta_reads_free(rd);
-    lib_put(pr, mk);
     if (hand_over) {                                                     // the graph stays on the device for the step that uses it
         if (mgta_sdbg_load_resident(ctx, &g_sess.graph) != MGTA_OK) die("mgta_sdbg_load_resident: %s", mgta_last_error());
         g_sess.graph_prefix = out_prefix;
@@ -487,10 +507,8 @@ static int main_findstart(int argc, char **argv) {
     logf("reference kmer set size: %lld\n", (long long)ref.model_pos.size());
     PackedReads local;
     PackedReads::Mark mk;
-    PackedReads &pr = lib_get(argv[2], "", local, mk);                   // stored as buildgraph wants them: the scan handles both orders
-    const uint64_t n_lib = pr.start.empty() ? 0 : pr.start.size() - 1;
-    if (argc > 5) load_fastx(argv[5], true, pr);
-    pr.finish();
+    PackedReads &pr = lib_get(argv[2], "", argc > 5 ? argv[5] : "", false, local, mk);   // stored as buildgraph wants them: the scan handles both orders
+    const uint64_t n_lib = mk.n_start ? mk.n_start - 1 : 0;
     const uint64_t n_reads = pr.start.size() - 1;
     logf("Processing %llu reads, %llu contigs\n", (unsigned long long)n_lib, (unsigned long long)(n_reads - n_lib));
     mgta_ctx *ctx = ctx_get();
@@ -565,7 +583,6 @@ static int main_findstart(int argc, char **argv) {
     }
     if (cf_out) fclose(cf_out);
     mgta_reads_free(rd);
-    lib_put(pr, mk);
     ctx_put(ctx);
     return 0;
 }
