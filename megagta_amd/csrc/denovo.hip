@@ -480,9 +480,10 @@ __global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int6
     if (!s.ok) atomicAdd(barrier + 2, 1u);                             // not even that fitted the table: the host shrinks the next window
 }
 __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
-                                                          StampTab owner, unsigned long long round, uint32_t *ok) {
+                                                          StampTab owner, unsigned long long round, uint32_t *ok, const uint32_t *barrier) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
+    if (i > *barrier) { ok[i] = 0; return; }                            // held back this round whatever its stamps say: no search
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkCheck s{owner, (round << 32) | (0xFFFFFFFFull - i), true};
     bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
@@ -795,7 +796,7 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
                            (unsigned long long)b.round, b.reach_max, barrier);
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
-                           (unsigned long long)b.round, b.ok.as<uint32_t>());
+                           (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier);
         hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
                            b.ok.as<uint32_t>(), barrier, b.marked.as<unsigned long long>(), b.status.as<uint32_t>(), b.keep.as<uint32_t>(), n_done);
         if (shed) {      // the candidates beyond the cut stay pending, behind the ones this round keeps
@@ -825,7 +826,12 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     DevBuf branching, found, cand, flag, again, counter;
     uint64_t nb = edges_where(w, PredBranching{}, branching);
     b.per = std::max<size_t>((size_t)kMaxBranches * max_len, (size_t)kReachHash + 2 * kReachFrontier);
-    b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, (8ull << 30) / (b.per * 8)));
+    // candidates per round: as many as an eighth of the free device memory (2 .. 32 GB) holds scratch for -- a round costs ~24 ms of
+    // launches and look-ups whatever it commits, 100 M reads took 513 rounds with 8 GB
+    size_t free_b = 0, total_b = 0;
+    MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t scratch_budget = std::min<uint64_t>(32ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t)free_b / 8));
+    b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, scratch_budget / (b.per * 8)));
     // test knobs: tiny windows exercise the carry of pending candidates, a tiny reach limit the hold-back of a region that does not fit
     if (const char *e = getenv("MGTA_DENOVO_WINDOW")) b.window = (uint32_t)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));

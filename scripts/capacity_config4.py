@@ -11,7 +11,8 @@ import torch
 from megagta_amd import api, synth, hmm as hmmlib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000_000
-n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4000      # 0: skip the search leg
+os.environ.setdefault("MGTA_DENOVO_VERBOSE", "1")               # one line per phase / every 16 bubble rounds on stderr: minutes of work otherwise look like a hang
 k = 44
 genes = (("rplB", 277), ("nirK", 360), ("nifH", 296), ("rpoB", 240), ("amoA", 180))
 peak = {"used": 0}
@@ -54,7 +55,7 @@ synth.write_gene_models(mg.genes, td)
 t = time.time()
 tot_e = 0
 found = sampled = above = 0
-for gi, gene in enumerate(mg.genes):
+for gi, gene in enumerate(mg.genes if n_seeds > 0 else []):
     d = os.path.join(td, gene.name)
     fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "for_enone.hmm"))), api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(d, "rev_enone.hmm")))
     seeds = synth.synthetic_seeds(gene, 45, n_seeds, seed=4 + gi)
