@@ -426,7 +426,7 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
         }
     };
     if (lane == 0) {
-        s_cnt[0] = 0; s_cnt[1] = 1; s_cnt[2] = 0;
+        s_cnt[0] = 0; s_cnt[1] = 1; s_cnt[2] = 0; s_cnt[3] = 0;
         insert(begin);
         __hip_atomic_store(&cur[0], begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!owner.stamp(begin, key)) s_cnt[2] = 1;
@@ -442,7 +442,7 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
                 for (int x = 0; x < od; ++x) {
                     if (!insert(out[x])) continue;
                     const int seen = atomicAdd(&s_cnt[1], 1) + 1, at = atomicAdd(&s_cnt[0], 1);
-                    if (seen > reach_max || at >= kReachFrontier) { s_cnt[2] = 1; continue; }
+                    if (seen > reach_max || at >= kReachFrontier) { s_cnt[2] = 1; s_cnt[3] = 1; continue; }   // [3]: the REGION is too large (not the table)
                     __hip_atomic_store(&nxt[at], out[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool fits = owner.stamp(out[x], key);
                     int64_t in[8];
@@ -463,16 +463,21 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
     return true;
 }
 
-__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
+constexpr unsigned long long kKnownBig = 1ull << 63;   // in a window's position word: the candidate's region did not fit the scratch in an earlier round
+__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
                                                           StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier) {
     __shared__ int s_cnt[4];
     const uint32_t i = blockIdx.x;                                     // one wave per candidate
     if (i >= n) return;
     const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
-    if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt)) return;
+    // a region that did not fit once is not walked again (thousands of line fetches to learn the same thing every round it waits behind
+    // another one like it): treating a candidate as one whose region does not fit is always safe
+    const bool known_big = (pos[i] & kKnownBig) != 0ull;
+    if (!known_big && bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt)) return;
     // the region does not fit: nobody above may commit this round (what this one can reach is not known), and it stamps at least what
     // its search reads today, so that it can still commit itself once nothing below reaches that
     if (threadIdx.x != 0) return;
+    if (!known_big && s_cnt[3]) pos[i] |= kKnownBig;
     atomicMin(barrier, i);
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkStamp s{owner, key, true};
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *
     SinkNone s;
     uint32_t st = 0;
     if (bubble_search(d.g, cand[i], max_len, br, mult, nb, len, s)) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
-    status[pos[i]] = st;
+    status[pos[i] & ~kKnownBig] = st;
     keep[i] = 0;
     atomicAdd(n_done, 1u);
 }
@@ -795,7 +800,7 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 16, hipMemcpyHostToDevice, w.st));
         const StampTab tab{b.stamp_key.as<unsigned long long>(), b.stamp_val.as<unsigned long long>(), b.stamp_mask, (unsigned long long)(b.round + 1) << 40};
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per, tab,
                            (unsigned long long)b.round, b.reach_max, barrier);
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
                            (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier);
