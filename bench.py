@@ -451,6 +451,20 @@ def main():
                                   "achieved": rate * 510 / 1e9, "peak": ceiling, "unit": "GB/s", "frac": rate * 510 / 1e9 / ceiling,
                                   "peak_note": "measured in this run: 2^26 independent random 128-byte line reads over an 8 GB table",
                                   "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
+            # what the kernel really moves: L2 misses per expansion from the PMC pass of the round (TCC_MISS_sum over the A* dispatches /
+            # expansions; PMC cannot be collected inline), one 128-byte line each, against the same measured ceiling
+            cp = os.path.join(ROOT, "profiles", "r03", "astar_counters_100M.json")
+            if os.path.exists(cp):
+                try:
+                    cj = json.load(open(cp))
+                    n_exp = 306951464 + 921574632                        # expansions of the profiled command (profiles/r03/astar_counters_100M.md)
+                    mpe = cj["astar_tcc"]["counters_sum_over_astar_dispatches"]["TCC_MISS_sum"] / n_exp
+                    search["roofline"]["traffic"] = {"l2_misses_per_expansion": mpe, "line_bytes": 128, "achieved": rate * mpe * 128 / 1e9, "unit": "GB/s",
+                                                     "frac_of_random_line_ceiling": rate * mpe * 128 / 1e9 / ceiling,
+                                                     "note": "TCC_MISS_sum per expansion on the 100 M-read graph (profiles/r03/astar_counters_100M.md) x this run's rate: "
+                                                             "priced on the lines it actually misses, the kernel runs at about the device's random-line rate"}
+                except Exception:
+                    pass
         if rank == 0 and world == 1 and last_contigs:
             search["membership"] = contig_membership(graph, last_contigs, k)
             note(f"membership of the returned contigs' (k+1)-mers in the graph: {search['membership']}")

@@ -45,7 +45,9 @@ struct ANode {                    // AStarNode, a_star_node.h:9-33
     int32_t fval;
     int16_t state_no, length, negative_count;
     uint16_t em_state;            // nucl_emission (9 bits) | state << 9
-    uint32_t pad[4];              // one node = one aligned 64-byte sector: a node access is a single request
+    int64_t fwd_r;                // forward descriptor of node_id (graph.hpp FwdDesc): the expansion of this node starts at the TARGET line of
+    uint32_t fwd_hint;            // its edge instead of loading the edge's own line first (kFdNone: not known, e.g. the seed's start edge)
+    uint32_t pad;                 // one node = one aligned 64-byte sector: a node access is a single request
 };
 static_assert(sizeof(ANode) == 64, "node layout");
 
@@ -299,14 +301,14 @@ using HeapArr = Grow<4>;
 __device__ __forceinline__ ANode load_node(const ANode *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     union { uint4 v[4]; ANode n; } u;
-    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2];
+    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
     return u.n;
 }
 __device__ __forceinline__ void store_node(ANode *p, const ANode &n) {
     union { uint4 v[4]; ANode n; } u;
     u.n = n;
     uint4 *q = reinterpret_cast<uint4 *>(p);
-    q[0] = u.v[0]; q[1] = u.v[1]; q[2] = u.v[2];
+    q[0] = u.v[0]; q[1] = u.v[1]; q[2] = u.v[2]; q[3] = u.v[3];
 }
 __device__ __forceinline__ HeapEnt load_ent(const HeapEnt *p) {
     const uint4 v = *reinterpret_cast<const uint4 *>(p);
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     bool first = true;
     ANode curr;
     curr.score = curr.real_score = curr.max_score = 0; curr.node_id = 0; curr.parent = -1; curr.fval = 0;
-    curr.state_no = curr.length = curr.negative_count = 0; curr.em_state = 0;
+    curr.state_no = curr.length = curr.negative_count = 0; curr.em_state = 0; curr.fwd_r = 0; curr.fwd_hint = kFdNone; curr.pad = 0;
 
     PROF_DECL
     while (true) {
@@ -878,6 +880,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 curr.parent = -1; curr.state_no = (int16_t)(sstate + n_aa); curr.em_state = (uint16_t)(ST_M << 9); curr.length = (int16_t)n_aa;
                 curr.fval = 0; curr.score = sc; curr.real_score = rs; curr.max_score = 0; curr.negative_count = 0;
                 curr.node_id = a.start_node[sid];
+                curr.fwd_r = 0; curr.fwd_hint = kFdNone; curr.pad = 0;                  // the start edge's own line is read once, by the first expansion
                 if (gl == 0) store_node(node_at(0), curr);
                 n_nodes = 1;
                 inter_val = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
@@ -899,10 +902,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 bool hfound = false;
                 while (n_heap > 0) {
                     const HeapEnt top = H.get(0);
-                    const uint32_t t0 = touch(hash + ((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node)),
-                                   t2 = touch(g.lines + ((top.key >> 18) >> 6));
+                    // (the node's edge needs no line of its own any more: the node carries where its Forward lands)
+                    const uint32_t t0 = touch(hash + ((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node));
                     H.remove_top(n_heap);
-                    touch_done(t0, t1, t2);
+                    touch_done(t0, t1, t1);
                     --n_heap;
                     bool found;
                     hs = hash_find(hash, hmask, top.key, found, hval);
@@ -1073,6 +1076,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 cd.score = curr.score + (dt - max_match);
                 cd.fval = to_fval(10000 * (cd.score + 2.0 * h_d));
                 cd.em_state = (uint16_t)(((4 << 6) | (4 << 3) | 4) | (ST_D << 9));
+                cd.fwd_r = curr.fwd_r; cd.fwd_hint = curr.fwd_hint; cd.pad = 0;         // the same edge
                 // (whether a cached match / insert child suppresses the delete child is known once every codon has been looked at: the
                 // probe is issued now, the verdict follows the passes)
                 bool del = cst != ST_I;
@@ -1116,13 +1120,21 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         int64_t e1 = 0, e2 = 0;
                         int od1 = 0;
                         bool valid = gl < GX::kWalkLanes;
-                        if (valid) { od1 = g_out_nth(g, curr.node_id, ci, e1); valid = ci < od1; }
+                        // one line per step: every edge comes with the place its own Forward lands (FwdDesc), the node's own edge included
+                        FwdDesc fd1, fd2, f0, f1, f2, f3;
+                        fd1.r = 0; fd1.hint = kFdNone; fd2 = fd1; f0 = fd1; f1 = fd1; f2 = fd1; f3 = fd1;
+                        if (valid) {
+                            FwdDesc fc;
+                            fc.r = curr.fwd_r; fc.hint = curr.fwd_hint;
+                            od1 = g_out_nth_fd(g, curr.node_id, fc, ci, e1, fd1);
+                            valid = ci < od1;
+                        }
                         if (GX::kPasses > 1) od1 = GX::bcast(od1, 0, gbase);
                         int od3 = 0, c12 = 0, low12 = 0;
                         if (valid) {
-                            valid = cj < g_out_nth(g, e1 >> 4, cj, e2);
+                            valid = cj < g_out_nth_fd(g, e1 >> 4, fd1, cj, e2, fd2);
                             if (valid) {
-                                od3 = g_out_all(g, e2 >> 4, p0, p1, p2, p3);
+                                od3 = g_out_all_fd(g, e2 >> 4, fd2, p0, p1, p2, p3, f0, f1, f2, f3);
                                 if (od3 < 0) od3 = 0;
                                 c12 = (((int)(e1 & 7) - 1) << 6) | (((int)(e2 & 7) - 1) << 3);
                                 low12 = (int)((e1 >> 3) & 1) & (int)((e2 >> 3) & 1);
@@ -1163,6 +1175,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                             cm.length = (int16_t)(curr.length + 1); cin.length = cm.length;
                             cm.state_no = (int16_t)next_state; cin.state_no = curr.state_no;
                             cm.em_state = (uint16_t)(codon | (ST_M << 9)); cin.em_state = (uint16_t)(codon | (ST_I << 9));
+                            cm.fwd_r = k == 0 ? f0.r : k == 1 ? f1.r : k == 2 ? f2.r : f3.r;
+                            cm.fwd_hint = k == 0 ? f0.hint : k == 1 ? f1.hint : k == 2 ? f2.hint : f3.hint;
+                            cm.pad = 0; cin.fwd_r = cm.fwd_r; cin.fwd_hint = cm.fwd_hint; cin.pad = 0;
                             const double pen = low ? a.low_cov_penalty : 0.0;          // :150
                             {
                                 const double e = mt + (use ? msc[(size_t)next_state * A + col] : 0.0);

@@ -360,6 +360,135 @@ __device__ __forceinline__ int g_out_all(const GraphDev &g, int64_t e, int64_t &
     return o.od;
 }
 
+// ---- forward descriptors --------------------------------------------------------------------------------------------------------
+// Everything OutgoingEdges(e) needs from e's own line is the rank r of the `last` bit Forward(e) selects and the hint line where the
+// look-up starts (succinct_dbg.h:155-164).  Both can be computed when e is FOUND -- e is then an out-edge in a line that sits in
+// registers -- so a walk edge -> out-edges -> their out-edges ... fetches ONE line per step (the target) instead of two (the edge's own
+// line again, then the target).  FwdDesc travels with the edge: in the A* kernel also inside the search node, so that an expansion
+// starts at the target line of its node.  hint == kFdNone: not known (an edge of the line before the target line, the seed's start
+// edge): the two-line path above.
+constexpr uint32_t kFdNone = 0xFFFFFFFFu;
+struct FwdDesc {
+    int64_t r;            // Select argument of Forward: rank_f[a] + Rank(a, e) - 1
+    uint32_t hint;        // fwd_hint[a - 1] of e's line, or kFdNone
+};
+// descriptor of the edge at bit `pos` of the line whose words are given (the edge is valid and carries a symbol 1..8)
+__device__ __forceinline__ FwdDesc g_fd_of(const GraphDev &g, int64_t x, int pos, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3, uint64_t rw0, uint64_t rw1,
+                                           uint64_t rw2, uint64_t rw3, uint64_t h01, uint64_t h23) {
+    FwdDesc f;
+    int a = (int)((sel4(w0, w1, w2, w3, (pos >> 4) & 3) >> ((pos & 15) * 4)) & 15);
+    if (a > 4) a -= 4;
+    int64_t cnt;
+    if (x >= g.size - 1) cnt = a == 1 ? g.total_w[1] : a == 2 ? g.total_w[2] : a == 3 ? g.total_w[3] : g.total_w[4];
+    else {
+        const int fw = pos >> 4, nb = (pos & 15) + 1;
+        const uint64_t m = nb == 16 ? ~0ull : ((1ull << (4 * nb)) - 1);
+        cnt = (int64_t)sel4(rw0, rw1, rw2, rw3, a - 1);
+        const uint64_t e0 = nib_eq(w0, a), e1 = nib_eq(w1, a), e2 = nib_eq(w2, a), e3 = nib_eq(w3, a);
+        cnt += __popcll(fw > 0 ? e0 : (e0 & m));
+        if (fw >= 1) cnt += __popcll(fw > 1 ? e1 : (e1 & m));
+        if (fw >= 2) cnt += __popcll(fw > 2 ? e2 : (e2 & m));
+        if (fw >= 3) cnt += __popcll(e3 & m);
+    }
+    const int64_t rf = a == 1 ? g.rank_f[1] : a == 2 ? g.rank_f[2] : a == 3 ? g.rank_f[3] : g.rank_f[4];
+    f.r = rf + cnt - 1;
+    const uint64_t hh = (a <= 2) ? h01 : h23;
+    f.hint = (uint32_t)((a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32));
+    return f;
+}
+// the out-set of the node Forward selects with rank `r`, starting at line `li` (g_outset_line from its second half on), with the whole
+// target line handed back in named scalars
+struct LineOut { uint64_t w0, w1, w2, w3, m1, rw0, rw1, rw2, rw3, h01, h23; };
+__device__ __forceinline__ OutSet g_outset_from(const GraphDev &g, int64_t r, uint64_t li, LineOut &L) {
+    OutSet o;
+    o.vm_hi = 0; o.vm_lo = 0; o.li = 0; o.od = 0;
+    if (r >= g.total_last || r < 0) return o;
+    LineR A = g_load_line(g, li);
+    const uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
+        do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
+        A = g_load_line(g, li);
+    }
+    const int xj = select64(A.last, (int)(r - (int64_t)A.rank_last));
+    const uint64_t upto = xj == 63 ? ~0ull : ((2ull << xj) - 1ull);      // bits 0 .. xj
+    const uint64_t stop = (A.last | A.tip) & (upto >> 1);                 // last | tip strictly below xj
+    o.li = li;
+    if (stop) {
+        const int y = 63 - __builtin_clzll(stop);
+        o.vm_hi = upto & ~((2ull << y) - 1ull) & ~A.invalid;
+    } else {
+        o.vm_hi = upto & ~A.invalid;
+        if (li > 0) {                                                     // the node began in the line before
+            const GLine &P = g.lines[li - 1];
+            const uint64_t pstop = P.last | P.tip;
+            const uint64_t keep = pstop ? ~((2ull << (63 - __builtin_clzll(pstop))) - 1ull) : ~0ull;
+            o.vm_lo = keep & ~P.invalid;
+            if (pstop >> 63) o.vm_lo = 0;
+        }
+    }
+    const int n = __popcll(o.vm_hi) + __popcll(o.vm_lo);
+    o.od = n > 4 ? 4 : n;
+    L.w0 = A.w0; L.w1 = A.w1; L.w2 = A.w2; L.w3 = A.w3; L.m1 = A.multi1;
+    L.rw0 = A.rw0; L.rw1 = A.rw1; L.rw2 = A.rw2; L.rw3 = A.rw3; L.h01 = A.h01; L.h23 = A.h23;
+    return o;
+}
+// descriptor of edge e from its own line (the slow start of a chain: one extra line); od < 0 when e is not a valid edge
+__device__ __forceinline__ FwdDesc g_fd_load(const GraphDev &g, int64_t e, bool &valid_edge) {
+    const LineR Le = g_load_line(g, (uint64_t)e >> 6);
+    valid_edge = !g_bit(Le.invalid, e);
+    return g_fd_of(g, e, (int)(e & 63), Le.w0, Le.w1, Le.w2, Le.w3, Le.rw0, Le.rw1, Le.rw2, Le.rw3, Le.h01, Le.h23);
+}
+// n-th out-edge of an out-set with its own descriptor (kFdNone when the edge lies in the line before the target line)
+__device__ __forceinline__ int64_t g_outset_get_fd(const GraphDev &g, const OutSet &o, const LineOut &L, int n, FwdDesc &fd) {
+    const int nh = __popcll(o.vm_hi);
+    const bool hi = n < nh;
+    uint64_t m = hi ? o.vm_hi : o.vm_lo;
+    int skip = hi ? n : n - nh;
+    if (skip >= 1) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    if (skip >= 2) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    if (skip >= 3) m &= ~(1ull << (63 - __builtin_clzll(m)));
+    const int pos = 63 - __builtin_clzll(m | 1ull);
+    int w, m1;
+    int64_t x;
+    if (hi) {
+        x = (int64_t)(o.li << 6) + pos;
+        w = (int)((sel4(L.w0, L.w1, L.w2, L.w3, (pos >> 4) & 3) >> ((pos & 15) * 4)) & 15); m1 = g_bit(L.m1, x);
+        fd = g_fd_of(g, x, pos, L.w0, L.w1, L.w2, L.w3, L.rw0, L.rw1, L.rw2, L.rw3, L.h01, L.h23);
+    } else {
+        x = (int64_t)((o.li - 1) << 6) + pos;
+        w = g_W(g, x); m1 = (int)g_multi1(g, x);
+        fd.r = 0; fd.hint = kFdNone;
+    }
+    return (x << 4) | ((int64_t)m1 << 3) | (int64_t)(w > 4 ? w - 4 : w);
+}
+// OutgoingEdges of the edge described by `in` (or of `e` itself when in.hint == kFdNone): the n-th one + its descriptor; returns the out-degree
+__device__ __forceinline__ int g_out_nth_fd(const GraphDev &g, int64_t e, FwdDesc in, int n, int64_t &edge, FwdDesc &out) {
+    if (in.hint == kFdNone) {
+        bool ok;
+        in = g_fd_load(g, e, ok);
+        if (!ok) return -1;
+    }
+    LineOut L;
+    const OutSet o = g_outset_from(g, in.r, in.hint, L);
+    if (n < o.od) edge = g_outset_get_fd(g, o, L, n, out);
+    return o.od;
+}
+__device__ __forceinline__ int g_out_all_fd(const GraphDev &g, int64_t e, FwdDesc in, int64_t &o0, int64_t &o1, int64_t &o2, int64_t &o3, FwdDesc &f0, FwdDesc &f1,
+                                            FwdDesc &f2, FwdDesc &f3) {
+    if (in.hint == kFdNone) {
+        bool ok;
+        in = g_fd_load(g, e, ok);
+        if (!ok) return -1;
+    }
+    LineOut L;
+    const OutSet o = g_outset_from(g, in.r, in.hint, L);
+    if (o.od > 0) o0 = g_outset_get_fd(g, o, L, 0, f0);
+    if (o.od > 1) o1 = g_outset_get_fd(g, o, L, 1, f1);
+    if (o.od > 2) o2 = g_outset_get_fd(g, o, L, 2, f2);
+    if (o.od > 3) o3 = g_outset_get_fd(g, o, L, 3, f3);
+    return o.od;
+}
+
 __device__ __forceinline__ int g_tip_char(const GraphDev &g, int64_t tip_rank, int j) {
     const uint32_t *t = g.tip_labels + (size_t)g.words_per_tip * tip_rank;
     return (t[j >> 4] >> (15 - (j & 15)) * 2) & 3;

@@ -236,7 +236,7 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
         fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
         kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
         seen_yield, sizes = False, []
-        for (window, rate), pools in (((8, 0), (1024, 16384, 65536)), ((64, 4), (4096,))):
+        for (window, rate), pools in (((8, 0), (2048, 4096, 8192, 16384)), ((64, 4), (8192, 16384))):
             want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
             assert st0["n_retries"] == 0
             try:
