@@ -114,7 +114,8 @@ __device__ __forceinline__ int64_t g_select_last(const GraphDev &g, int64_t r) {
     if (r >= g.total_last) return g.size;
     if (r < 0) return -1;
     uint64_t li = g.sel_last[r >> 6];
-    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r) ++li;
+    // (the ones before the next line = the ones before this line + the ones in it: the next line is only touched when the target is there)
+    while (li + 1 < g.n_lines && (int64_t)(g.lines[li].rank_last + (uint64_t)__popcll(g.lines[li].last)) <= r) ++li;
     const GLine &L = g.lines[li];
     return (int64_t)(li << 6) + select64(L.last, (int)(r - (int64_t)L.rank_last));
 }
@@ -123,7 +124,11 @@ __device__ __forceinline__ int64_t g_select_w(const GraphDev &g, int c, int64_t 
     if (r >= g.total_w[c]) return g.size;
     if (r < 0) return -1;
     uint64_t li = g.sel_w[c][r >> 6];
-    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_w[c - 1] <= r) ++li;
+    for (; li + 1 < g.n_lines; ++li) {                                   // (the next line is only touched when the target is there)
+        const GLine &C = g.lines[li];
+        const int here = __popcll(nib_eq(C.w[0], c)) + __popcll(nib_eq(C.w[1], c)) + __popcll(nib_eq(C.w[2], c)) + __popcll(nib_eq(C.w[3], c));
+        if ((int64_t)C.rank_w[c - 1] + here > r) break;
+    }
     const GLine &L = g.lines[li];
     int rem = (int)(r - (int64_t)L.rank_w[c - 1]);
 #pragma unroll
@@ -144,7 +149,7 @@ __device__ __forceinline__ int64_t g_forward(const GraphDev &g, int64_t e) {   /
     if (r >= g.total_last) return g.size;
     if (r < 0) return -1;
     uint64_t li = g.lines[e >> 6].fwd_hint[a - 1];
-    while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r) ++li;
+    while (li + 1 < g.n_lines && (int64_t)(g.lines[li].rank_last + (uint64_t)__popcll(g.lines[li].last)) <= r) ++li;
     const GLine &L = g.lines[li];
     return (int64_t)(li << 6) + select64(L.last, (int)(r - (int64_t)L.rank_last));
 }
@@ -233,7 +238,8 @@ __device__ __forceinline__ int g_outgoing_line(const GraphDev &g, const LineR &L
     uint64_t hh = (a <= 2) ? Le.h01 : Le.h23;
     uint64_t li = (a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32);           // fwd_hint[a-1]
     LineR A = g_load_line(g, li);
-    uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    // (ones of `last` before the NEXT line = before this one + in this one: no need to touch the next line to know that the target is here)
+    const uint64_t next_rank = A.rank_last + (uint64_t)__popcll(A.last);
     if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
         do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
         A = g_load_line(g, li);
@@ -292,7 +298,8 @@ __device__ __forceinline__ OutSet g_outset_line(const GraphDev &g, const LineR &
     const uint64_t hh = (a <= 2) ? Le.h01 : Le.h23;
     uint64_t li = (a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32);           // fwd_hint[a-1]
     LineR A = g_load_line(g, li);
-    const uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    // (ones of `last` before the NEXT line = before this one + in this one: no need to touch the next line to know that the target is here)
+    const uint64_t next_rank = A.rank_last + (uint64_t)__popcll(A.last);
     if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
         do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
         A = g_load_line(g, li);
@@ -404,7 +411,8 @@ __device__ __forceinline__ OutSet g_outset_from(const GraphDev &g, int64_t r, ui
     o.vm_hi = 0; o.vm_lo = 0; o.li = 0; o.od = 0;
     if (r >= g.total_last || r < 0) return o;
     LineR A = g_load_line(g, li);
-    const uint64_t next_rank = g.lines[li + 1 < g.n_lines ? li + 1 : li].rank_last;   // same burst as A
+    // (ones of `last` before the NEXT line = before this one + in this one: no need to touch the next line to know that the target is here)
+    const uint64_t next_rank = A.rank_last + (uint64_t)__popcll(A.last);
     if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
         do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
         A = g_load_line(g, li);
