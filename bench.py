@@ -491,7 +491,9 @@ def main():
                                               "synthetic seeds" % (mg.sample_reads.shape[0], args.product_seeds, graph.size)}
             note(f"search, product mode: {sum(len(x) for x in product_seeds)} seeds in {pdt:.1f} s, {tot_e / max(1e-9, tot_ms * 1e-3) / 1e6:.1f} M expansions/s")
         if world == 1 and (args.reads <= 20_000_000 or args.denovo):
-            # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits)
+            # row f-1: tips, bubbles, unitigs on the same resident graph (last: it consumes the validity bits).  The searches' pool goes
+            # first: the bubble rounds size their windows by the free memory
+            ctx.release_scratch()
             _, dst = graph.denovo(150, False, k + 2)
             denovo_leg = {"edges": int(graph.size), "ms_tips": dst["ms_tips"], "ms_bubbles": dst["ms_bubbles"], "ms_unitigs": dst["ms_unitigs"],
                           "tips": dst["n_tips"], "bubbles": dst["n_bubbles"], "bubble_rounds": dst["n_bubble_rounds"], "contigs": dst["n_contigs"],
