@@ -491,8 +491,17 @@ __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int6
     if (i > *barrier) { ok[i] = 0; return; }                            // held back this round whatever its stamps say: no search
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkCheck s{owner, (round << 32) | (0xFFFFFFFFull - i), true};
-    bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
+    int64_t *br = scratch + (size_t)i * per;
+    const bool found = bubble_search(g, cand[i], max_len, br, mult, nb, len, s);
     ok[i] = s.ok ? 1u : 0u;
+    // what the search found stays behind the branches for the commit: a candidate that passed read only edges nobody else of this round
+    // writes (the committing candidates' read and write sets are disjoint by the stamp rule), so the search it would run again there,
+    // after other candidates' pops, finds exactly this
+    if (s.ok) {
+        int64_t *res = br + (size_t)kMaxBranches * max_len;
+        res[0] = (int64_t)(found ? 1 : 0) | ((int64_t)nb << 8) | ((int64_t)len << 16);
+        for (int b = 0; b < kMaxBranches; b += 2) res[1 + b / 2] = (int64_t)(uint32_t)mult[b] | ((int64_t)(uint32_t)mult[b + 1] << 32);
+    }
 }
 // status (by position in the candidate list): 0 = the search fails now, 1 = popped, 2 = Pop undid itself (goes to the second list,
 // assembly_algorithms.cpp:273-277).  keep[i] = 1: still pending after this round.
@@ -502,11 +511,13 @@ __global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     if (!ok[i] || i > *barrier) { keep[i] = 1; return; }
-    int mult[kMaxBranches], nb = 0, len = 0;
+    int mult[kMaxBranches];
     int64_t *br = scratch + (size_t)i * per;
-    SinkNone s;
+    const int64_t *res = br + (size_t)kMaxBranches * max_len;                 // left by the check kernel (see there)
+    const int nb = (int)((res[0] >> 8) & 255), len = (int)(res[0] >> 16);
+    for (int b = 0; b < kMaxBranches; b += 2) { mult[b] = (int)(uint32_t)res[1 + b / 2]; mult[b + 1] = (int)(uint32_t)(res[1 + b / 2] >> 32); }
     uint32_t st = 0;
-    if (bubble_search(d.g, cand[i], max_len, br, mult, nb, len, s)) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
+    if (res[0] & 1) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
     status[pos[i] & ~kKnownBig] = st;
     keep[i] = 0;
     atomicAdd(n_done, 1u);
@@ -832,7 +843,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     BubbleWork b;
     DevBuf branching, found, cand, flag, again, counter;
     uint64_t nb = edges_where(w, PredBranching{}, branching);
-    b.per = std::max<size_t>((size_t)kMaxBranches * max_len, (size_t)kReachHash + 2 * kReachFrontier);
+    b.per = std::max<size_t>((size_t)kMaxBranches * max_len + 1 + kMaxBranches / 2, (size_t)kReachHash + 2 * kReachFrontier);
     // candidates per round: as many as an eighth of the free device memory (2 .. 32 GB) holds scratch for -- a round costs ~24 ms of
     // launches and look-ups whatever it commits, 100 M reads took 513 rounds with 8 GB
     size_t free_b = 0, total_b = 0;
