@@ -13,6 +13,7 @@
 #include <string>
 
 #include "astar_kernel.hpp"
+#include "scan.hpp"
 
 struct mgta_hmm {
     mgta_ctx *ctx = nullptr;
@@ -28,6 +29,19 @@ using namespace mgta;
 static const char kCodonAA[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";   // codon.h:9-106
 
 namespace {
+// the result strings of a batch, packed: side sid's `len[sid]` characters move from its fixed-size slot to packed[off[sid] ...) (a
+// million-seed batch has 5 GB of slots for 0.7 GB of text: the slots never cross the bus)
+__global__ __launch_bounds__(256) void pack_results_kernel(const char *slots, uint32_t slot_bytes, const uint32_t *len, const uint64_t *off, uint64_t n_sides,
+                                                           char *packed) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t sid = wave; sid < n_sides; sid += n_waves) {
+        const uint32_t n = len[sid];
+        const char *src = slots + sid * slot_bytes;
+        char *dst = packed + off[sid];
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
 struct Events {                  // RAII: the events also go on the early-return and throw paths
     hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
     Events() { for (auto &x : e) MGTA_HIP_CHECK(hipEventCreate(&x)); }
@@ -381,13 +395,25 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             for (int q = 0; q < 10; ++q) fprintf(stderr, "[astar-prof] %-12s %6.2f %%\n", nm[q], 100.0 * hp[q] / (tot ? tot : 1));
         }
 #endif
-        // results
+        // results: records and lengths as they are, the strings packed on the device first
         std::vector<mgta_astar_side> h_sides((size_t)n * 2);
         std::vector<uint32_t> h_len((size_t)n * 2);
-        std::vector<char> h_out((size_t)n * 2 * out_cap);
+        std::vector<uint64_t> h_off((size_t)n * 2);
+        DevBuf d_off, d_scan_tmp, d_tot, d_packed;
+        d_off.alloc((size_t)n * 2 * 8); d_scan_tmp.alloc(scan_tmp_elems((uint64_t)n * 2) * 8); d_tot.alloc(64);
+        exclusive_scan_u32(st, d_len.as<uint32_t>(), (uint64_t)n * 2, d_off.as<uint64_t>(), d_scan_tmp.as<uint64_t>(), d_tot.as<uint64_t>());
+        uint64_t n_chars = 0;
+        MGTA_HIP_CHECK(hipMemcpyAsync(&n_chars, d_tot.p, 8, hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        d_packed.alloc(n_chars + 64);
+        hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)std::min<uint64_t>(((uint64_t)n * 2 + 3) / 4, 1u << 16)), dim3(256), 0, st, d_out.as<char>(), out_cap,
+                           d_len.as<uint32_t>(), d_off.as<uint64_t>(), (uint64_t)n * 2, d_packed.as<char>());
+        MGTA_HIP_CHECK(hipGetLastError());
+        std::vector<char> h_out(n_chars + 1);
         MGTA_HIP_CHECK(hipMemcpyAsync(h_sides.data(), d_sides.p, h_sides.size() * sizeof(mgta_astar_side), hipMemcpyDeviceToHost, st));
         MGTA_HIP_CHECK(hipMemcpyAsync(h_len.data(), d_len.p, h_len.size() * 4, hipMemcpyDeviceToHost, st));
-        MGTA_HIP_CHECK(hipMemcpyAsync(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipMemcpyAsync(h_off.data(), d_off.p, h_off.size() * 8, hipMemcpyDeviceToHost, st));
+        if (n_chars) MGTA_HIP_CHECK(hipMemcpyAsync(h_out.data(), d_packed.p, n_chars, hipMemcpyDeviceToHost, st));
         MGTA_HIP_CHECK(hipEventRecord(ev.e[1], st));
         MGTA_HIP_CHECK(hipStreamSynchronize(st));
         float ms = 0;
@@ -404,8 +430,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 ST.n_opened += h_sides[(size_t)s * 2 + d].n_opened;
             }
             if (sink) {
-                const char *r = h_out.data() + (size_t)(2 * s) * out_cap;
-                const char *l = h_out.data() + (size_t)(2 * s + 1) * out_cap;
+                const char *r = h_out.data() + h_off[(size_t)2 * s];
+                const char *l = h_out.data() + h_off[(size_t)2 * s + 1];
                 uint32_t ll = h_len[(size_t)2 * s + 1];
                 left.assign(ll, ' ');
                 for (uint32_t i = 0; i < ll; ++i) {                                  // RevComp, hmm_graph_search.h:362-398
