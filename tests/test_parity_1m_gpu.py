@@ -71,6 +71,12 @@ def test_denovo_1m_reads_vs_reference_one_thread(big):
     print(f"parity 1M denovo: {a.count(b'>')} contigs, {len(a)} bytes; reference -t 1 {t_ref:.1f} s, ours {t_ours:.1f} s")
     assert a == b and a.count(b">") > 100_000
     assert open(d / "ours.contigs.fa.info").read() == open(d / "ref.contigs.fa.info").read()
+    # and from the REFERENCE's graph files (one file per writer thread of its buildgraph, buckets dealt batch by batch): what our loader
+    # (index on the host, records parsed on the device) makes of them is the same graph
+    n_files = sum(1 for f in os.listdir(d) if f.startswith("ref.sdbg.") and f[9:].isdigit())
+    _run([BIN, "denovo", "-s", str(d / "ref"), "-o", str(d / "ours_on_ref"), "-t", "4"] + args)
+    assert open(d / "ours_on_ref.contigs.fa", "rb").read() == b
+    print(f"parity 1M denovo from the reference's {n_files} graph file(s): identical contigs")
 
 
 def test_findstart_and_search_1m_reads_vs_reference(big):
