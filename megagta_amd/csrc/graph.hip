@@ -255,9 +255,10 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
     struct Fd { int fd = -1; const unsigned char *map = nullptr; size_t size = 0; };
     std::vector<Fd> files;
     struct Cleanup {
-        std::vector<Fd> &f; void *pin[2] = {nullptr, nullptr};
+        std::vector<Fd> &f; void *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
         ~Cleanup() { for (Fd &x : f) { if (x.map && x.size) munmap(const_cast<unsigned char *>(x.map), x.size); if (x.fd >= 0) close(x.fd); }
-                     for (void *q : pin) if (q) (void)hipHostFree(q); }
+                     for (void *q : pin) if (q) (void)hipHostFree(q);
+                     for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
     } cleanup{files};
     try {
         FILE *info = fopen((prefix + ".sdbg_info").c_str(), "r");
@@ -319,7 +320,7 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
         MGTA_HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 64, st));
         const size_t kPiece = 512ull << 20, kStage = 64ull << 20;
         for (auto &q : cleanup.pin) MGTA_HIP_CHECK(hipHostMalloc(&q, kStage, hipHostMallocDefault));
-        hipEvent_t ev[2];
+        hipEvent_t (&ev)[2] = cleanup.ev;
         for (auto &e : ev) MGTA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         int stage = 0;
         bool used_stage[2] = {false, false};
@@ -375,7 +376,6 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
         uint32_t bad = 0;
         MGTA_HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
         MGTA_HIP_CHECK(hipStreamSynchronize(st));
-        for (auto &e : ev) (void)hipEventDestroy(e);
         d_piece[0].release(); d_piece[1].release();
         if (bad) { set_error("%s: %u buckets do not parse to the sizes the index gives", prefix.c_str(), bad); return MGTA_EINVAL; }
         return load_graph(ctx, k, d_recs.as<uint16_t>(), (int64_t)total, items.data(), d_tips.as<uint32_t>(), (int64_t)ntips * wpt, wpt, true, out, &d_recs);
