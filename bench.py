@@ -439,7 +439,7 @@ def main():
         search = {"value": rate, "unit": "HMM-scored node expansions/s", "n_seeds": sum(len(s) for s in seeds), "genes": [g.name for g in mg.genes],
                   "graph_edges": int(graph.size), "graph_build_and_load_s": t_graph, "graph_passes": gst["n_passes"],
                   "expansions_per_step": float(nexp[0]), "ms_per_step": float(nexp[1]) * 1e3, "cache_mode": "cold (every seed independent)",
-                  "lanes_per_search": 16, "searches_in_flight_per_gpu": 8192,
+                  "lanes_per_search": 8 if max(len(x) for x in seeds) >= 32768 else 16, "searches_in_flight_per_gpu": 16384 if max(len(x) for x in seeds) >= 32768 else 8192,
                   "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"], "searches_grown_in_place": sst[-1]["n_grown"],
                   "pool_used_GB": sst[-1]["pool_used"] / 1e9}
         if rank == 0:

@@ -182,11 +182,13 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         MGTA_HIP_CHECK(hipMemcpyAsync(d_exit.p, exit_prob.data(), 3000 * 8, hipMemcpyHostToDevice, st));
         MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
 
-        // lanes per search: 16 (four searches per wavefront, 8192 in flight).  One search per wavefront (64 lanes: an iteration is ~2.5x
-        // shorter, 2048 in flight) was the choice for shared-cache batches below 32768 seeds while their window was thousands of seeds
-        // wide; with the small windows + cost term `megagta search` uses now 16 lanes win at every size measured (7.4 k / 9.7 k seeds:
-        // 2.0 / 3.0 s vs 2.6 / 4.6 s; 18 k / 24 k: 3.0 / 3.9 s vs 5.0 / 10.0 s, profiles/r02/e2e_window_sweep.log).  MGTA_ASTAR_GROUP=16|32|64 overrides.
-        int G = 16;
+        // lanes per search: 16 (four searches per wavefront, 8192 in flight).  One search per wavefront (64 lanes) was the choice for
+        // shared-cache batches while their windows were thousands of seeds wide; with the small windows + cost term `megagta search` uses
+        // 16 lanes win at every size measured (profiles/r02/e2e_window_sweep.log).  Eight lanes per search (16 384 in flight, two walk
+        // passes) pay where the batch is large and independent: cold, 120 000 seeds on the 100 M-read graph 46.6 -> 43.6 s, 40 000 seeds
+        // on the 10 M-read graph +14 %; they lose where single searches bound the run (30 000 seeds per gene at 100 M reads -5 %, the
+        // ordered window on the 100 M-read graph 38.6 -> 42.7 s): profiles/r03/astar_ab.md.  MGTA_ASTAR_GROUP=8|16|32|64 overrides.
+        int G = (cache_mode == 0 && n >= 32768) ? 8 : 16;
         if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
