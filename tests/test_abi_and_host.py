@@ -140,6 +140,46 @@ def test_host_sdbg_reader_and_writer(tmp_path, oracle, golden_dir):
     assert oracle.Stream.read(str(tmp_path / "out")).edges().md5() == s.md5()
 
 
+def test_sdbgmerge_puts_the_ranks_index_parts_together(tmp_path, oracle, golden_dir):
+    """`megagta sdbgmerge` (host only): the per-rank index parts a multi-GPU `buildgraph` leaves (PREFIX.sdbg_info.part<r>: one header line
+    "k words_per_tip b_lo b_hi records tips large", then the rank's bucket lines) become ONE PREFIX.sdbg_info naming the ranks' files; the
+    merged graph reads back as the whole stream through the C++ reader, our Python reader and the oracle's reader of the reference format.
+    Parts that do not tile the 65536 buckets are an error."""
+    import subprocess
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "ragged", "reads.lib"))
+    o = oracle.Stream.build(packed, start, 29, threads=2).edges()
+    s = api.EdgeStream(k=o.k, words_per_tip=o.words_per_tip, bucket_items=o.bucket_items, records=o.records, large=o.large, tips=o.tips)
+    ranks = 3
+    api.write_sdbg(str(tmp_path / "w"), s, num_files=ranks)           # the same layout: file r holds a contiguous bucket range
+    info = open(tmp_path / "w.sdbg_info").read().splitlines()
+    rows = [l.split() for l in info[7:]]
+    assert len(rows) == 65536
+    file_of = [int(r[1]) for r in rows]
+    cuts = [0] + [next(b for b in range(65536) if file_of[b] == f) if f in file_of else None for f in range(1, ranks)] + [65536]
+    # (empty buckets carry file -1: a part's range runs from its first bucket to the next part's first)
+    assert all(c is not None for c in cuts)
+    for r in range(ranks):
+        os.replace(tmp_path / f"w.sdbg.{r}", tmp_path / f"m.sdbg.{r}")
+        lo, hi = cuts[r], cuts[r + 1]
+        mine = rows[lo:hi]
+        n = sum(int(x[3]) for x in mine); nt = sum(int(x[4]) for x in mine); nl = sum(int(x[5]) for x in mine)
+        with open(tmp_path / f"m.sdbg_info.part{r}", "w") as f:
+            f.write(f"{s.k} {s.words_per_tip} {lo} {hi} {n} {nt} {nl}\n")
+            f.writelines(" ".join(x) + "\n" for x in mine)
+    exe = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
+    r = subprocess.run([exe, "sdbgmerge", str(tmp_path / "m"), str(ranks)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(tmp_path / "m.sdbg_info.part0")
+    assert open(tmp_path / "m.sdbg_info").read().splitlines() == info
+    assert api.read_sdbg(str(tmp_path / "m")).md5() == s.md5()
+    assert oracle.Stream.read(str(tmp_path / "m")).edges().md5() == s.md5()
+    r = subprocess.run([exe, "sdbgcopy", str(tmp_path / "m"), str(tmp_path / "c")], capture_output=True, text=True)
+    assert r.returncode == 0 and api.read_sdbg(str(tmp_path / "c")).md5() == s.md5()
+    # a missing rank is reported, not papered over
+    r = subprocess.run([exe, "sdbgmerge", str(tmp_path / "m"), str(ranks)], capture_output=True, text=True)
+    assert r.returncode != 0 and "part0" in r.stderr
+
+
 def test_driver_continue_mode_follows_the_reference(tmp_path, monkeypatch, capsys):
     """--continue (reference megagta.py:321-351): every option but -o comes from opts.txt, parsed into a FRESH option set (reads given
     next to --continue are not appended a second time); without an opts.txt the driver says so and carries on in normal mode"""
