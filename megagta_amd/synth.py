@@ -286,10 +286,11 @@ class DeviceMetagenome:
 
 def make_metagenome_device(n_reads: int, read_len: int = 150, gene_specs=(("rplB", 277),), seed: int = 1, genome_len: int = 20000,
                            aa_sub: float = 0.10, err: float = 0.005, reads_per_genome: int = 2000, device: str = "cuda",
-                           host_sample: int = 1_000_000, keep_variants: int = 4096, chunk: int = 4_000_000) -> DeviceMetagenome:
+                           host_sample: int = 1_000_000, keep_variants: int = 4096, chunk: int = 4_000_000, on_chunk=None) -> DeviceMetagenome:
     """G = n_reads / reads_per_genome random genomes, one diverged copy of every gene in each, uniform reads, random strand,
     substitution errors: the model of make_metagenome, drawn by the device's generator (so the reads differ from the
-    numpy version's; every rank of a multi-GPU run draws the same ones from the same seed)."""
+    numpy version's; every rank of a multi-GPU run draws the same ones from the same seed).  `on_chunk(first_read, codes[m, L])`, when
+    given, receives every chunk of reads on the host (to write a reads file of any size without holding it)."""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -343,6 +344,8 @@ def make_metagenome_device(n_reads: int, read_len: int = 150, gene_specs=(("rplB
         r = torch.where(errs, (r + torch.randint(1, 4, (m, L), device=device, generator=gen, dtype=torch.uint8)) & 3, r)
         if len(sample) * chunk < host_sample:
             sample.append(r[: max(0, host_sample - len(sample) * chunk)].cpu().numpy())
+        if on_chunk is not None:
+            on_chunk(s, r.cpu().numpy())
         rr = r.flip(1).reshape(-1)                                   # reversed, not complemented (cx1_read2sdbg_s1.cpp:97,117)
         pad = (-rr.numel()) % 16
         if pad:
