@@ -1653,6 +1653,22 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
         // segments that did not fit a tile next to their neighbours: alone in LDS if they fit, else (hot k-mers, or the whole array
         // when it is tiny) one workgroup each with global ping-pong passes
         hipLaunchKernelGGL((segment_end_kernel<WT>), dim3(n_big), dim3(256), 0, stream, src, n_items, T, d_big, d_big + big_cap);
+        if (getenv("MGTA_SORT_DIAG")) {                               // (measurement aid) sizes of the deferred segments of this sort
+            std::vector<uint64_t> s(n_big), e(n_big);
+            MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+            MGTA_HIP_CHECK(hipMemcpy(s.data(), d_big, n_big * 8ull, hipMemcpyDeviceToHost));
+            MGTA_HIP_CHECK(hipMemcpy(e.data(), d_big + big_cap, n_big * 8ull, hipMemcpyDeviceToHost));
+            uint64_t hist[40] = {}, keys[40] = {}, mx = 0;
+            for (uint32_t i = 0; i < n_big; ++i) {
+                const uint64_t c = e[i] - s[i];
+                const int b = c ? 64 - __builtin_clzll(c) : 0;
+                hist[b]++; keys[b] += c; mx = std::max(mx, c);
+            }
+            fprintf(stderr, "[sort diag] %u deferred segments of %llu keys, longest %llu:", n_big, (unsigned long long)n_items, (unsigned long long)mx);
+            for (int b = 0; b < 40; ++b)
+                if (hist[b]) fprintf(stderr, " <2^%d: %llu (%llu keys)", b, (unsigned long long)hist[b], (unsigned long long)keys[b]);
+            fprintf(stderr, "\n");
+        }
         hipLaunchKernelGGL((local_lsd_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, d_big, d_big + big_cap, 1, lp);
         hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
                            (int)low.size(), (uint32_t)LocalCfg<WT>::kTile);

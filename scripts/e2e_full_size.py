@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 logdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
 os.makedirs(logdir, exist_ok=True)
 d = tempfile.mkdtemp(prefix="mgta_e2e_full_")
-need = n * (162 + 40 + 3 * 12) * 1.2                                   # reads.fa + library + three graphs' files + contigs, bytes (generous)
+need = n * (163 + 40 + 3 * 80) * 1.1                                   # reads.fa + library + three graphs' files + contigs, bytes (generous)
 free = shutil.disk_usage(d).free
 print(f"scratch {d}: {free / 1e9:.0f} GB free, about {need / 1e9:.0f} GB needed", flush=True)
 if free < need:
@@ -53,6 +53,10 @@ try:
     def heartbeat():                                                    # (a line a minute: a silent call is taken to be hung)
         while not done.wait(60):
             print(f"  driver running: {time.time() - t:.0f} s", flush=True)
+            try:                                                        # the driver's detailed log so far: a run cut off at the call's limit still leaves it
+                shutil.copyfile(d + "/out/log", os.path.join(logdir, f"e2e_{n // 1_000_000}M_out_log.txt"))
+            except OSError:
+                pass
     threading.Thread(target=heartbeat, daemon=True).start()
     with open(os.path.join(logdir, f"e2e_{n // 1_000_000}M_steps.log"), "w") as lg:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "megagta_amd", "megagta.py"), "-r", d + "/reads.fa", "-g", gl, "-k", "30,36,45", "-o", d + "/out",
