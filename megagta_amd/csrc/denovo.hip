@@ -403,14 +403,15 @@ __global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64
 // otherwise keep one lane busy for milliseconds while the round waits for it).  Which edges end up stamped, and whether the region
 // fits, depends on the region alone (counts per level and in all), not on the order the lanes find them in.
 __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, const StampTab &owner, unsigned long long key,
-                                   unsigned long long round, int reach_max, int *s_cnt /* LDS: [0] edges of the next level, [1] edges seen, [2] overflow */) {
+                                   unsigned long long round, int reach_max, int *s_cnt /* LDS: [0] edges of the next level, [1] edges seen, [2] overflow */,
+                                   unsigned long long tag_flag) {
     if (!g_valid(g, begin)) return true;
     const int lane = threadIdx.x;
     unsigned long long *hash = reinterpret_cast<unsigned long long *>(scratch);
     int64_t *cur = scratch + kReachHash, *nxt = cur + kReachFrontier;
     // hash entries carry the round in their top 24 bits: whatever an earlier round or a search left in the scratch reads as empty
     // (edge ids stay below 2^40), so nothing is cleared
-    const unsigned long long tag = ((round & 0x3FFFFFull) + 1) << 40;
+    const unsigned long long tag = (((round & 0x3FFFFFull) + 1) << 40) | tag_flag;     // (tag_flag: what the narrow walk of the same round left reads as stale)
     auto insert = [&](int64_t e) -> bool {           // true = new; slots are claimed at the L2 (other lanes insert at the same time)
         uint32_t h = (uint32_t)(((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 49) & (kReachHash - 1);
         const unsigned long long mine = tag | (unsigned long long)e;
@@ -464,25 +465,123 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
 }
 
 constexpr unsigned long long kKnownBig = 1ull << 63;   // in a window's position word: the candidate's region did not fit the scratch in an earlier round
-__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
-                                                          StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier) {
-    __shared__ int s_cnt[4];
-    const uint32_t i = blockIdx.x;                                     // one wave per candidate
-    if (i >= n) return;
-    const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
-    // a region that did not fit once is not walked again (thousands of line fetches to learn the same thing every round it waits behind
-    // another one like it): treating a candidate as one whose region does not fit is always safe
-    const bool known_big = (pos[i] & kKnownBig) != 0ull;
-    if (!known_big && bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt)) return;
-    // the region does not fit: nobody above may commit this round (what this one can reach is not known), and it stamps at least what
-    // its search reads today, so that it can still commit itself once nothing below reaches that
-    if (threadIdx.x != 0) return;
-    if (!known_big && s_cnt[3]) pos[i] |= kKnownBig;
+constexpr unsigned long long kKnownWide = 1ull << 62;  // ... its region has more than kNarrowMax edges: walked by a whole wave from the start
+constexpr unsigned long long kPosMask = ~(kKnownBig | kKnownWide);
+constexpr int kNarrowLanes = 8, kNarrowMax = 512;
+
+// the tail of a candidate whose region does not fit (or is known not to): nobody above may commit this round (what this one can reach is
+// not known), and it stamps at least what its search reads today, so that it can still commit itself once nothing below reaches that
+__device__ void bubble_reach_failed(const GraphDev &g, const int64_t *cand, uint32_t i, int max_len, int64_t *scratch, size_t per, const StampTab &owner,
+                                    unsigned long long key, uint32_t *barrier) {
     atomicMin(barrier, i);
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkStamp s{owner, key, true};
     bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
     if (!s.ok) atomicAdd(barrier + 2, 1u);                             // not even that fitted the table: the host shrinks the next window
+}
+
+// Most regions are a few dozen edges in levels of one to three: a wave per candidate keeps 60 lanes idle through ~60 levels of dependent
+// line fetches and atomics (20 M reads: 17 of the 23 ms of a round).  Eight lanes per candidate, eight candidates per wave: the same walk
+// (same stamps, same verdict) with eight times the candidates in flight.  A region of more than kNarrowMax edges is left to the wave-wide
+// walk below (list), now and in later rounds (kKnownWide); what this walk stamped of it is a subset of what that one stamps.
+__global__ __launch_bounds__(64) void bubble_reach_narrow_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
+                                                                 StampTab owner, unsigned long long round, int reach_max, int narrow_max, uint32_t *barrier,
+                                                                 uint32_t *wide_list, uint32_t *wide_count) {
+    constexpr int G = kNarrowLanes, NG = 64 / G;
+    __shared__ int s_cnt[NG][4];                                       // per candidate: [0] edges of the next level, [1] edges seen, [2] stop, [3] the region is over the limit
+    const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+    const uint32_t i = blockIdx.x * NG + grp;
+    const bool have = i < n;
+    const uint64_t pw = have ? pos[i] : 0ull;
+    const bool known_big = (pw & kKnownBig) != 0ull, known_wide = (pw & kKnownWide) != 0ull;
+    const int64_t begin = have ? cand[i] : 0;
+    const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
+    const int limit = reach_max < narrow_max ? reach_max : narrow_max;
+    enum { WALK, FITS, FAILED, WIDE };
+    int state = !have ? FITS : known_big ? FAILED : known_wide ? WIDE : !g_valid(g, begin) ? FITS : WALK;
+    int64_t *mine = scratch + (size_t)(have ? i : 0) * per;
+    unsigned long long *hash = reinterpret_cast<unsigned long long *>(mine);
+    int64_t *cur = mine + kReachHash, *nxt = cur + kReachFrontier;
+    const unsigned long long tag = ((round & 0x3FFFFFull) + 1) << 40;
+    auto insert = [&](int64_t e) -> bool {           // as in bubble_reach_stamp
+        uint32_t h = (uint32_t)(((uint64_t)e * 0x9E3779B97F4A7C15ull) >> 49) & (kReachHash - 1);
+        const unsigned long long me = tag | (unsigned long long)e;
+        for (;;) {
+            unsigned long long v = __hip_atomic_load(&hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == me) return false;
+            if ((v & ~0xFFFFFFFFFFull) != tag) {
+                if (__hip_atomic_compare_exchange_strong(&hash[h], &v, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+                if (v == me) return false;
+                continue;
+            }
+            h = (h + 1) & (kReachHash - 1);
+        }
+    };
+    if (gl == 0) {
+        s_cnt[grp][0] = 0; s_cnt[grp][1] = 1; s_cnt[grp][2] = 0; s_cnt[grp][3] = 0;
+        if (state == WALK) {
+            insert(begin);
+            __hip_atomic_store(&cur[0], begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!owner.stamp(begin, key)) s_cnt[grp][2] = 1;
+        }
+    }
+    __syncthreads();
+    int n_cur = 1;
+    for (int level = 0; level < max_len; ++level) {
+        const bool walking = state == WALK && n_cur > 0;
+        if (!__any(walking)) break;
+        for (int i0 = 0; __any(walking && i0 < n_cur); i0 += G) {
+            const int idx = i0 + gl;
+            if (walking && idx < n_cur) {
+                int64_t out[8];
+                const int od = d_outgoing(g, __hip_atomic_load(&cur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), out);
+                for (int x = 0; x < od; ++x) {
+                    if (!insert(out[x])) continue;
+                    const int seen = atomicAdd(&s_cnt[grp][1], 1) + 1, at = atomicAdd(&s_cnt[grp][0], 1);
+                    if (seen > limit || at >= kReachFrontier) { s_cnt[grp][2] = 1; s_cnt[grp][3] = 1; continue; }
+                    __hip_atomic_store(&nxt[at], out[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool fits = owner.stamp(out[x], key);
+                    int64_t in[8];
+                    const int id = d_incoming(g, out[x], in);
+                    for (int y = 0; y < id; ++y) fits = owner.stamp(in[y], key) && fits;
+                    if (!fits) s_cnt[grp][2] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (walking) {
+            if (s_cnt[grp][2]) state = !s_cnt[grp][3] ? FAILED : (reach_max <= narrow_max ? FAILED : WIDE);
+            else n_cur = s_cnt[grp][0];
+        }
+        __syncthreads();
+        if (gl == 0) s_cnt[grp][0] = 0;
+        __syncthreads();
+        int64_t *t = cur; cur = nxt; nxt = t;
+    }
+    if (gl != 0 || !have || state == WALK || state == FITS) return;
+    if (state == WIDE) {
+        if (!known_wide) pos[i] = pw | kKnownWide;
+        wide_list[atomicAdd(wide_count, 1u)] = i;
+        return;
+    }
+    if (!known_big && s_cnt[grp][3]) pos[i] = pw | kKnownBig;          // (only with reach_max <= narrow_max: the region is too large for any walk)
+    bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier);
+}
+// the listed candidates (regions of more than kNarrowMax edges), one WAVE each
+__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, int max_len, int64_t *scratch, size_t per,
+                                                          StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier, const uint32_t *wide_list,
+                                                          const uint32_t *wide_count) {
+    __shared__ int s_cnt[4];
+    const uint32_t n_wide = *wide_count;
+    for (uint32_t b = blockIdx.x; b < n_wide; b += gridDim.x) {
+        const uint32_t i = wide_list[b];
+        const unsigned long long key = (round << 32) | (0xFFFFFFFFull - i);
+        __syncthreads();                                                // the previous candidate's counters are no longer read
+        if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt, 1ull << 63)) continue;
+        if (threadIdx.x != 0) continue;
+        if (s_cnt[3]) pos[i] |= kKnownBig;
+        bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier);
+    }
 }
 __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
                                                           StampTab owner, unsigned long long round, uint32_t *ok, const uint32_t *barrier) {
@@ -518,7 +617,7 @@ __global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *
     for (int b = 0; b < kMaxBranches; b += 2) { mult[b] = (int)(uint32_t)res[1 + b / 2]; mult[b + 1] = (int)(uint32_t)(res[1 + b / 2] >> 32); }
     uint32_t st = 0;
     if (res[0] & 1) st = bubble_pop(d, marked, br, mult, nb, len, max_len) ? 1u : 2u;
-    status[pos[i] & ~kKnownBig] = st;
+    status[pos[i] & kPosMask] = st;
     keep[i] = 0;
     atomicAdd(n_done, 1u);
 }
@@ -784,6 +883,7 @@ struct BubbleWork {
     size_t per = 0;          // int64 of scratch per candidate
     uint32_t window = 0;
     int reach_max = kReachMax;
+    int narrow_max = kNarrowMax;
     uint64_t round = 0;
 };
 
@@ -811,8 +911,11 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 16, hipMemcpyHostToDevice, w.st));
         const StampTab tab{b.stamp_key.as<unsigned long long>(), b.stamp_val.as<unsigned long long>(), b.stamp_mask, (unsigned long long)(b.round + 1) << 40};
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3(m), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per, tab,
-                           (unsigned long long)b.round, b.reach_max, barrier);
+        // (the list of the wide candidates lives in `ok` until the check kernel writes that; its length in the fourth counter)
+        hipLaunchKernelGGL(bubble_reach_narrow_kernel, dim3((m + 64 / kNarrowLanes - 1) / (64 / kNarrowLanes)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len,
+                           b.scratch.as<int64_t>(), b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 16384u)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch.as<int64_t>(), b.per,
+                           tab, (unsigned long long)b.round, b.reach_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
                            (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier);
         hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
@@ -853,6 +956,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     // test knobs: tiny windows exercise the carry of pending candidates, a tiny reach limit the hold-back of a region that does not fit
     if (const char *e = getenv("MGTA_DENOVO_WINDOW")) b.window = (uint32_t)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));
+    if (const char *e = getenv("MGTA_DENOVO_NARROW_MAX")) b.narrow_max = std::min(kReachFrontier, std::max(1, atoi(e)));   // (tiny: every region takes the wave-wide walk)
     b.scratch.alloc((size_t)b.window * b.per * 8, w.live(), w.peak());
     found.alloc(nb * 4 + 64, w.live(), w.peak());
     if (nb) {

@@ -354,10 +354,12 @@ static int main_search(int argc, char **argv) {
         //   37 k / 50 k: 2048 + 4  3.5 / 5.4    (8192 + 2: 4.1 / 7.4;  1024 + 4: 3.7 / 5.4;  4096 + 4: 3.6 / 5.5)
         //   80 k / 108 k: 4096 + 2  5.3 / 8.7   (8192 + 2: 5.6 / 9.2;  4096 + 4: 5.5 / 8.6;  2048 + 2: 7.0 / 8.4)
         //  200 k / 270 k: 8192 + 2  9.0 / 15.8  (8192 + 4: 10.3 / 16.7;  4096 + 4: 11.8 / 18.2);  414 k: 8192 + 2 14.4 (4096 + 2: 15.4)
+        //  from ~400 k seeds on one seed per expansion: 414 k seeds (10 M-read graph) 8192 + 1 12.7 s; 400 k seeds of rplB on the 100 M-read
+        //  graph (profiles/r03/sweep_window_400k_100M.log): 8192 + 2 26.8 s, 8192 + 1 22.1 / 22.2 / 25.3 s, 4096 + 1 21.9 s, unordered 15.9 s
         const size_t ns = kmers.size();
         const int window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
         // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
-        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : window == 1 ? 0 : (ns < 65536 ? 4 : 2)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
+        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : window == 1 ? 0 : (ns < 65536 ? 4 : ns < 393216 ? 2 : 1)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);

@@ -732,10 +732,16 @@ template <int W> struct LocalCfg {
     static constexpr int kChunk = kTile / kSortWaves;
 };
 
-template <int W>
+// segments just too long for that tile still fit the LDS of a workgroup that has it to itself: twice the tile (one segment, no
+// neighbours: segment_lds_kernel); 0 = no such tile for this key width
+template <int W> struct BigCfg {
+    static constexpr int kTile = W <= 4 ? 8192 : (W <= 8 ? 4096 : 0);
+};
+
+template <int W, int TILE = LocalCfg<W>::kTile>
 struct LocalShared {
-    Key<W> keys[LocalCfg<W>::kTile];
-    uint16_t seg[LocalCfg<W>::kTile];
+    Key<W> keys[TILE];
+    uint16_t seg[TILE];
     uint16_t whist[kSortWaves][256];
     uint32_t start[256];
     uint32_t scratch[kSortThreads / 64 + 1];
@@ -836,16 +842,16 @@ __device__ __forceinline__ int tile_load(LocalShared<W> &sh, const Key<W> *keys,
 // one stable LSD pass over the tile: keys (+ segment ranks) go from registers (wave-chunk order) to their sorted LDS positions
 // [0, nt); with `reload` they come back into registers in position order.  All threads call; every wave's row of sh.whist
 // must be zero on entry (tile_zero_counts) and is zero again on return.  Four workgroup barriers.
-template <int W>
-__device__ __forceinline__ void tile_zero_counts(LocalShared<W> &sh) {
+template <int W, int TILE = LocalCfg<W>::kTile>
+__device__ __forceinline__ void tile_zero_counts(LocalShared<W, TILE> &sh) {
     uint16_t *whist = sh.whist[wave_id()];
     for (int i = lane_id(); i < 256; i += 64) whist[i] = 0;             // wave-private: no barrier needed before the wave counts
 }
 
-template <int W>
-__device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[LocalCfg<W>::kIpt], uint32_t (&seg)[LocalCfg<W>::kIpt], uint32_t nt,
+template <int W, int TILE = LocalCfg<W>::kTile>
+__device__ __forceinline__ void lds_pass(LocalShared<W, TILE> &sh, Key<W> (&key)[TILE / kSortThreads], uint32_t (&seg)[TILE / kSortThreads], uint32_t nt,
                                          Digit d, bool by_seg, int seg_shift, bool reload, uint32_t off = 0) {
-    constexpr int kIpt = LocalCfg<W>::kIpt, kChunk = LocalCfg<W>::kChunk;
+    constexpr int kIpt = TILE / kSortThreads, kChunk = TILE / kSortWaves;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];
     uint32_t dr[kIpt], cnt[kIpt];
@@ -900,7 +906,7 @@ __device__ __forceinline__ void lds_pass(LocalShared<W> &sh, Key<W> (&key)[Local
         }
     }
     __syncthreads();
-    tile_zero_counts<W>(sh);                                              // own row, read by this wave only since the last barrier
+    tile_zero_counts<W, TILE>(sh);                                        // own row, read by this wave only since the last barrier
     if (reload) {
 #pragma unroll
         for (int it = 0; it < kIpt; ++it) {
@@ -1161,6 +1167,33 @@ __global__ __launch_bounds__(kSortThreads, 8) void local_lsd_kernel(Key<W> *keys
 #pragma unroll
     for (int it = 0; it < kIpt; ++it) {
         uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+        if (j < nt) keys[first + j] = sh.keys[j];
+    }
+}
+
+// one workgroup per listed segment of LocalCfg::kTile < keys <= BigCfg::kTile: the same LSD passes with the LDS of a whole CU (a
+// hot 16-mer prefix of 5-8 thousand keys took eight global census + scatter round trips of ~100 us each in segment_sort_kernel)
+template <int W>
+__global__ __launch_bounds__(kSortThreads) void segment_lds_kernel(Key<W> *keys, const uint64_t *start, const uint64_t *end, LocalPlan lp) {
+    constexpr int TILE = BigCfg<W>::kTile > 0 ? BigCfg<W>::kTile : LocalCfg<W>::kTile, kIpt = TILE / kSortThreads, kChunk = TILE / kSortWaves;
+    __shared__ LocalShared<W, TILE> sh;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const uint64_t first = wave_uniform(start[blockIdx.x]), cnt = wave_uniform(end[blockIdx.x]) - first;
+    if (cnt <= (uint64_t)LocalCfg<W>::kTile || cnt > (uint64_t)BigCfg<W>::kTile) return;
+    const uint32_t nt = (uint32_t)cnt;
+    Key<W> key[kIpt];
+    uint32_t seg[kIpt];
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {
+        const uint32_t j = (uint32_t)wv * kChunk + (uint32_t)it * 64 + (uint32_t)lane;
+        seg[it] = 0;
+        if (j < nt) key[it] = keys[first + j];
+    }
+    tile_zero_counts<W, TILE>(sh);
+    for (int pass = 0; pass < lp.n_low; ++pass) lds_pass<W, TILE>(sh, key, seg, nt, lp.low_plan[pass], false, 0, pass + 1 < lp.n_low);
+#pragma unroll
+    for (int it = 0; it < kIpt; ++it) {                                  // n_low >= 1: LDS holds the result
+        const uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
         if (j < nt) keys[first + j] = sh.keys[j];
     }
 }
@@ -1670,8 +1703,11 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             fprintf(stderr, "\n");
         }
         hipLaunchKernelGGL((local_lsd_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, d_big, d_big + big_cap, 1, lp);
+        static const bool big_tile = !getenv("MGTA_SORT_NO_BIG_TILE");  // (measurement knob)
+        const bool use_big = BigCfg<WT>::kTile > 0 && big_tile && !low.empty();
+        if (use_big) hipLaunchKernelGGL((segment_lds_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, d_big, d_big + big_cap, lp);
         hipLaunchKernelGGL((segment_sort_kernel<WT>), dim3(n_big), dim3(kSortThreads), 0, stream, src, dst, d_big, d_big + big_cap, d_plan,
-                           (int)low.size(), (uint32_t)LocalCfg<WT>::kTile);
+                           (int)low.size(), (uint32_t)(use_big ? BigCfg<WT>::kTile : LocalCfg<WT>::kTile));
     }
     MGTA_HIP_CHECK(hipEventRecord(le1, stream));
     MGTA_HIP_CHECK(hipEventSynchronize(le1));

@@ -74,7 +74,7 @@ def window_and_rate(n_seeds: int) -> tuple[int, int]:
     holds; MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE override (any integer >= -64 for the rate: < 0 = seeds per expansion)"""
     w, r = os.environ.get("MEGAGTA_CACHE_WINDOW"), os.environ.get("MEGAGTA_CACHE_COST_RATE")
     window = int(w) if w not in (None, "", "-2") else 1024 if n_seeds < 32768 else 2048 if n_seeds < 65536 else 4096 if n_seeds < 196608 else 8192
-    rate = int(r) if r not in (None, "") else 0 if window == 1 else (4 if n_seeds < 65536 else 2)     # window 1 = the sequential run: no cost term
+    rate = int(r) if r not in (None, "") else 0 if window == 1 else (4 if n_seeds < 65536 else 2 if n_seeds < 393216 else 1)     # window 1 = the sequential run: no cost term
     return window, rate
 
 

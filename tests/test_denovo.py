@@ -120,6 +120,15 @@ def test_device_ordered_rounds(ctx, oracle):
         finally:
             del os.environ[knob]
         assert got2 == want and gst2["n_bubbles"] == wst["n_bubbles"] and gst2["n_bubble_rounds"] > gst["n_bubble_rounds"], (knob, value)
+    # the reach walk takes eight lanes per candidate up to 512 edges and a whole wave beyond (round 3): which of the two walks a region
+    # takes changes nothing, not even the number of rounds
+    for value in ("2", "24"):
+        os.environ["MGTA_DENOVO_NARROW_MAX"] = value
+        try:
+            got3, gst3 = api.Graph(ctx, st.edges()).denovo(150, False, 0)
+        finally:
+            del os.environ["MGTA_DENOVO_NARROW_MAX"]
+        assert got3 == want and gst3["n_bubbles"] == wst["n_bubbles"] and gst3["n_bubble_rounds"] == gst["n_bubble_rounds"], value
 
 
 @pytest.mark.gpu

@@ -213,6 +213,39 @@ def test_redundant_reads_long_runs(ctx, oracle, k):
     _same(g, o)
 
 
+@pytest.mark.parametrize("k,m", [(21, 1), (44, 1), (79, 1), (31, 2)])
+def test_segments_between_one_and_two_lds_tiles(ctx, oracle, k, m):
+    """a 16-mer prefix with 5-8 thousand keys (more than the 4096-key LDS tile, no more than twice that: sorted by a workgroup that has the
+    CU's LDS to itself, round 3) next to shorter and longer ones (poly-C: one tile; poly-G: the global route), with and without stage 1"""
+    rng = np.random.default_rng(11 * k + m)
+    reads = []
+
+    def homopolymer(c, copies, mixed):
+        out = [np.full(150, c, np.uint8) for _ in range(copies)]
+        for _ in range(mixed):                                         # the same leading characters, then something else: unequal keys of the segment
+            r = rng.integers(0, 4, 150).astype(np.uint8)
+            r[:k + 12] = c
+            out.append(r)
+        return out
+    per = 150 - k
+    reads += homopolymer(0, 6400 // per, 30)                           # A (and its T on the other strand): ~6.4 k equal keys + ~400 others
+    reads += homopolymer(1, 2600 // per, 10)                           # C / G: fits one tile
+    for _ in range(2500):
+        reads.append(rng.integers(0, 4, int(rng.integers(k + 1, 160))).astype(np.uint8))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    packed, start = readlib.pack_for_build(reads)
+    rd = ctx.upload_reads(packed, start)
+    if m == 1:
+        g = ctx.build_sdbg(rd, k)
+        o = oracle.Stream.build(packed, start, k, threads=4).edges()
+    else:
+        g = ctx.build_sdbg(rd, k, min_count=m, need_mercy=True)
+        o = oracle.Stream.build_solid(packed, start, k, m, True, threads=4).edges()
+    assert g.stats["n_big_segments"] >= 2                              # the A and the T segment at least were deferred
+    _same(g, o)
+
+
 @pytest.mark.parametrize("k,m,mercy,assist", [(21, 2, True, 0), (31, 3, False, 12), (44, 2, True, 12), (63, 2, True, 0),
                                                (111, 2, True, 0), (120, 3, False, 6), (127, 2, True, 6)])   # k > 110: 10- / 11-word sort records (round 2)
 def test_min_count_vs_oracle_seeded(ctx, oracle, k, m, mercy, assist):
