@@ -290,18 +290,20 @@ struct StampTab {
     }
 };
 
-struct SinkNone { __device__ void operator()(int64_t) {} };
+struct SinkNone { __device__ void operator()(int64_t) {} __device__ bool stop() const { return false; } };
 struct SinkStamp {
     StampTab tab;
     unsigned long long key;
     bool ok;
     __device__ void operator()(int64_t e) { if (!tab.stamp(e, key)) ok = false; }
+    __device__ bool stop() const { return false; }
 };
 struct SinkCheck {
     StampTab tab;
     unsigned long long key;
     bool ok;
-    __device__ void operator()(int64_t e) { if (tab.lookup(e) != key) ok = false; }
+    __device__ void operator()(int64_t e) { if (ok && tab.lookup(e) != key) ok = false; }
+    __device__ bool stop() const { return !ok; }                   // an edge somebody below reaches: the candidate waits, whatever the search would find
 };
 
 // BranchGroup::Search (branch_group.cpp:22-103).  br[b * max_len + j] = j-th edge of branch b; every still-valid edge whose validity
@@ -313,7 +315,7 @@ __device__ bool bubble_search(const GraphDev &g, int64_t begin, int max_len, int
     int64_t out[8];
     const int outd = d_outgoing(g, begin, out);
     for (int x = 0; x < outd; ++x) sink(out[x]);
-    if (outd <= 1 || outd > kMaxBranches) return false;
+    if (outd <= 1 || outd > kMaxBranches || sink.stop()) return false;
     nb = 1; len = 1;
     br[0] = begin;
     mult[0] = 0;
@@ -351,6 +353,7 @@ __device__ bool bubble_search(const GraphDev &g, int64_t begin, int max_len, int
         end = br[j];
         const int eo = d_outgoing(g, end, out);
         for (int x = 0; x < eo; ++x) sink(out[x]);
+        if (sink.stop()) return false;
         if (eo == 1) {
             converged = true;
             for (int b = 1; b < nb && converged; ++b) converged = br[(size_t)b * max_len + j] == end;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(64) void bubble_find_kernel(GraphDev g, const int64
 // Every edge a search from `begin` can read or write in ANY graph that has a subset of today's valid edges: the edges within max_len
 // forward steps and the valid edges into them.  Stamped with `key`; false when the region does not fit the scratch (the caller then
 // holds back every higher candidate of the round).
-// One WAVE per candidate: the lanes take the edges of a level side by side (a region of thousands of edges in a repeat would
+// The lanes of the workgroup take the edges of a level side by side (a region of thousands of edges in a repeat would
 // otherwise keep one lane busy for milliseconds while the round waits for it).  Which edges end up stamped, and whether the region
 // fits, depends on the region alone (counts per level and in all), not on the order the lanes find them in.
 __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len, int64_t *scratch, const StampTab &owner, unsigned long long key,
@@ -435,7 +438,7 @@ __device__ bool bubble_reach_stamp(const GraphDev &g, int64_t begin, int max_len
     __syncthreads();
     int n_cur = 1;
     for (int level = 0; level < max_len && n_cur > 0; ++level) {
-        for (int i0 = 0; i0 < n_cur; i0 += 64) {
+        for (int i0 = 0; i0 < n_cur; i0 += (int)blockDim.x) {
             const int i = i0 + lane;
             if (i < n_cur) {
                 int64_t out[8];
@@ -567,8 +570,10 @@ __global__ __launch_bounds__(64) void bubble_reach_narrow_kernel(GraphDev g, con
     if (!known_big && s_cnt[grp][3]) pos[i] = pw | kKnownBig;          // (only with reach_max <= narrow_max: the region is too large for any walk)
     bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier);
 }
-// the listed candidates (regions of more than kNarrowMax edges), one WAVE each
-__global__ __launch_bounds__(64) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, int max_len, int64_t *scratch, size_t per,
+// the listed candidates (regions of more than kNarrowMax edges), one workgroup of four waves each: the lanes take the edges of a level
+// side by side (a region of thousands of edges in a repeat would otherwise keep one lane busy for milliseconds while the round waits)
+constexpr int kWideThreads = 256;
+__global__ __launch_bounds__(kWideThreads) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, int max_len, int64_t *scratch, size_t per,
                                                           StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier, const uint32_t *wide_list,
                                                           const uint32_t *wide_count) {
     __shared__ int s_cnt[4];
@@ -914,7 +919,7 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         // (the list of the wide candidates lives in `ok` until the check kernel writes that; its length in the fourth counter)
         hipLaunchKernelGGL(bubble_reach_narrow_kernel, dim3((m + 64 / kNarrowLanes - 1) / (64 / kNarrowLanes)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len,
                            b.scratch.as<int64_t>(), b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 16384u)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch.as<int64_t>(), b.per,
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 8192u)), dim3(kWideThreads), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch.as<int64_t>(), b.per,
                            tab, (unsigned long long)b.round, b.reach_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
                            (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier);

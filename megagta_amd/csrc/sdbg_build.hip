@@ -115,6 +115,7 @@ struct ScanArgs {
     unsigned long long *n_sentinel;        // closed-form writers, k+1 even: number of sentinel keys written (see item_write_closed_kernel)
     uint32_t multi_width, multi_n;         // count mode: multi_n > 0 counts multi_n consecutive bucket ranges of multi_width buckets from
                                            // b_lo in one scan: block_count[range * gridDim.x + workgroup]
+    uint64_t multi_magic;                  // ceil(2^32 / multi_width) (the range of a bucket without a division per item)
 };
 constexpr int kMaxCountRanges = 64;
 
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     const int lane = lane_id(), wv = wave_id();
     __shared__ uint64_t s_start[kReadsPerBlock + 1];                  // one coalesced load instead of two dependent ones per read
     const bool multi = !WRITE && a.multi_n > 0;
+    const uint64_t multi_magic = a.multi_magic;                      // ceil(2^32 / multi_width): exact quotients for operands of at most 2^16
     uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
     uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
     if (threadIdx.x == 0) s_cursor = 0;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
                     const uint32_t b = (uint32_t)((two << (2 * from)) >> 48);
                     if (b < a.b_lo || b >= a.b_hi) return;
                     if (WRITE) items[cnt] = make_key<W>(src, from, n, k, prev);
-                    else if (multi) atomicAdd(&s_range_cnt[(b - a.b_lo) / a.multi_width], 1u);
+                    else if (multi) atomicAdd(&s_range_cnt[(uint32_t)(((uint64_t)(b - a.b_lo) * multi_magic) >> 32)], 1u);   // = (b - b_lo) / multi_width: both at most 2^16
                     ++cnt;
                 };
                 if (run_first) {                                       // left $  (s2.cpp:531-540)
@@ -1953,7 +1955,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         static const bool closed_even = !(getenv("MGTA_CLOSED_EVEN") && atoi(getenv("MGTA_CLOSED_EVEN")) == 0);   // 0: k+1 even takes the scans
         const bool closed_form = (((k + 1) & 1) || closed_even) && !sa.is_solid && b_lo == 0 && b_hi == (uint32_t)MGTA_NUM_BUCKETS && !ctx->force_full_lsd;
         const uint32_t *counts = d_block_count;
-        sa.multi_n = 0; sa.multi_width = 0;
+        sa.multi_n = 0; sa.multi_width = 0; sa.multi_magic = 0;
         if (n_blocks && closed_form)
             hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(256), 0, stream, sa.start, sa.n_reads, n_blocks, k,
                                sa.block_count, sa.n_kmers);
@@ -1964,7 +1966,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             if (!multi_n && ranges_left > 1 && ranges_left <= (uint32_t)kMaxCountRanges) {
                 d_multi_count = pool_get<uint32_t>(ctx, S_MULTI_COUNT, (uint64_t)ranges_left * n_blocks * 4);
                 ScanArgs sm = sa;
-                sm.block_count = d_multi_count; sm.b_hi = bucket_end; sm.multi_width = width; sm.multi_n = ranges_left;
+                sm.block_count = d_multi_count; sm.b_hi = bucket_end; sm.multi_width = width; sm.multi_n = ranges_left; sm.multi_magic = ((1ull << 32) + width - 1) / width;
                 hipLaunchKernelGGL((item_scan_kernel<W, false>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sm);
                 multi_n = ranges_left; multi_width = width; multi_lo = b_lo;
             }
