@@ -136,6 +136,8 @@ struct AstarArgs {
                                         // for memory (call_for_memory)
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
+    int defer;                    // ordered launch: a lowest running search that finds no memory ends as status 2 and the pass goes on (the host runs it
+                                  // alone afterwards); 0: the pass gives up and the host starts the batch again with more room
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
                                   // direction at a time, with the whole pool to itself)
 };
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     used = GX::bcast(used, 0, gbase);
                     if (used <= own || starved > (1u << 18)) {                       // (the second: a backstop -- no room for ten seconds of calling)
                         status = 2; st = S_DONE;
-                        if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
+                        if (gl == 0 && !a.defer) st_agent(&a.start_limit[4], 1ull);    // no further seed is taken: the pass is going to be run again
                     }
                 } else if (level >= 0 && (uint64_t)n_expanded < (256ull << (2 * level))) {
                     if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {

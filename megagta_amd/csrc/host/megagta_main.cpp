@@ -320,6 +320,9 @@ static int main_search(int argc, char **argv) {
     size_t n_edges = 0;
     mgta_sdbg *g = graph_get(ctx, argv[1], &gk, &n_edges);
     logf("Done! Time elapsed: %.4lf", now_s() - t0);
+    // the build's key buffers (tens of GB in the worker) make room for the searches' pool: the graph is packed, its files are written from
+    // the host copy, and no build follows the search of a run
+    mgta_ctx_release_scratch(ctx);
     const size_t klen = (size_t)gk + 1;
     auto run_gene = [&](const GeneEntry &gene, mgta_ctx *ctx) {
         double tg = now_s();
@@ -364,8 +367,8 @@ static int main_search(int argc, char **argv) {
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
-        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, pool %.1f of %.1f GB)",
-             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries,
+        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, %lld run alone after the others, pool %.1f of %.1f GB)",
+             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries, (long long)st.n_deferred,
              st.pool_used / 1e9, st.pool_bytes / 1e9);
     };
     // the genes of the list one after the other (search.cpp:124).  MEGAGTA_SEARCH_LANES=2 searches two genes side by side on one
