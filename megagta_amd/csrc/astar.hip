@@ -364,6 +364,13 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
                 todo[d].swap(again);
             }
+            unsigned long long h_lim[8] = {0};
+            if (gated && attempt == 1) MGTA_HIP_CHECK(hipMemcpy(h_lim, d_start_limit.p, 64, hipMemcpyDeviceToHost));
+            if (h_lim[4]) {          // the deferring pass gave up as well: more than kMaxDeferred searches that fit nowhere
+                set_error("more than %d searches do not fit the device memory left for them even as the lowest running seeds (pool of %llu bytes)", kMaxDeferred,
+                          (unsigned long long)pool_bytes);
+                return MGTA_EOVERFLOW;
+            }
             if (gated && attempt == 1 && (!todo[0].empty() || !todo[1].empty())) {
                 ST.n_deferred = (int64_t)(todo[0].size() + todo[1].size());
                 fprintf(stderr, "[megagta_amd] search: %zu searches do not fit the pool (%.1f GB) even as the lowest running seeds: run alone now, after the others\n",
