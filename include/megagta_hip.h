@@ -244,9 +244,6 @@ typedef struct mgta_astar_stats {
     double ms_total, ms_kernel;
     int64_t n_grown, n_rehash, n_recycled;                /* searches that outgrew their base arena, hash tables re-built, chunks re-used */
     uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / most of it in use at once */
-    int64_t n_deferred;                                   /* ordered window: searches too large for the pool even as the lowest running seed,
-                                                           * run alone after the pass (their own view is the ordered one; the seeds behind them
-                                                           * did not see their paths).  Normally 0 */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */

@@ -262,13 +262,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             // a context that shares the device with another batch (two genes searched side by side) takes its share of the CUs
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(2, (int64_t)ctx->num_cus * (use_lds ? 1 : 2) * ctx->search_share_num / ctx->search_share_den));
             if (const char *e = getenv("MGTA_ASTAR_BLOCKS")) blocks = std::min<int64_t>(blocks, std::max(2, atoi(e)));   // (diagnostic)
-            // ordered launches: pass 0 as configured; if its lowest running seed found no memory, pass 1 = the whole batch again with all
-            // the memory there is, and a search that still does not fit ends as deferred while the pass goes on; pass 2 = the deferred
-            // searches alone, one at a time (per direction), gate off: each sees exactly what it saw in its place (the cache entries of later
-            // seeds are not visible to it), only the seeds behind it did not see ITS path.  Independent searches: 1/8 of the grid, then one at a time.
-            const bool deferred_pass = gated && attempt >= 2;
-            if (attempt == 2 && !gated) blocks = std::max<int64_t>(2, blocks / 8);
-            if (attempt == 3 || deferred_pass) blocks = 2;
+            if (attempt == 2) blocks = std::max<int64_t>(2, blocks / 8);
+            if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
             // pool = the slots' base arenas + what the searches grow into.  Device memory beyond the first ~24 GB of a process costs
@@ -325,10 +320,9 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
             a.pool.soft_limit = dyn / 2;
-            a.gate = gated && !deferred_pass;
-            a.defer = gated && attempt == 1;
+            a.gate = gated;
             a.free_share = free_share;
-            a.active_slots = (attempt == 3 || deferred_pass) ? 1u : (uint32_t)spb;
+            a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_seed.p, 0xFF, slots * 8, st));
@@ -364,20 +358,11 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
                 todo[d].swap(again);
             }
-            unsigned long long h_lim[8] = {0};
-            if (gated && attempt == 1) MGTA_HIP_CHECK(hipMemcpy(h_lim, d_start_limit.p, 64, hipMemcpyDeviceToHost));
-            if (h_lim[4]) {          // the deferring pass gave up as well: more than kMaxDeferred searches that fit nowhere
-                set_error("more than %d searches do not fit the device memory left for them even as the lowest running seeds (pool of %llu bytes)", kMaxDeferred,
-                          (unsigned long long)pool_bytes);
-                return MGTA_EOVERFLOW;
-            }
-            if (gated && attempt == 1 && (!todo[0].empty() || !todo[1].empty())) {
-                ST.n_deferred = (int64_t)(todo[0].size() + todo[1].size());
-                fprintf(stderr, "[megagta_amd] search: %zu searches do not fit the pool (%.1f GB) even as the lowest running seeds: run alone now, after the others\n",
-                        todo[0].size() + todo[1].size(), pool_bytes / 1e9);
-            } else if (deferred_pass) {
-                if (!todo[0].empty() || !todo[1].empty()) break;                 // alone with all the memory and still too large: reported below
-            } else if (gated && (!todo[0].empty() || !todo[1].empty())) {
+            // ordered launches: the batch is started again ONCE, with all the memory there is (pass 1 takes `avail`); a lowest running seed
+            // that finds no memory there either cannot be served by any further pass -- fewer workgroups do not enlarge the pool, and at 50 M
+            // reads two more restarts on an eighth of the device and on two workgroups were minutes each for nothing: reported below
+            if (gated && attempt >= 1 && (!todo[0].empty() || !todo[1].empty())) break;
+            if (gated && (!todo[0].empty() || !todo[1].empty())) {
                 fprintf(stderr, "[megagta_amd] search: %zu searches found no memory even as the lowest running seeds (pool %.1f GB); the batch of %lld seeds "
                         "starts again with more room\n", todo[0].size() + todo[1].size(), pool_bytes / 1e9, (long long)n);
                 for (int d = 0; d < 2; ++d) {

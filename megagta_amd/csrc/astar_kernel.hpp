@@ -28,7 +28,6 @@ constexpr int kMaxLevels = 20;                 // levels of a growable array (le
 // heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels); with 8 lanes per search (twice the
 // searches per workgroup) the root block and four child blocks, so that the HMM tables of a 360-column model still fit beside them
 constexpr uint32_t lds_heap_slots(int G) { return G >= 16 ? 72u : 40u; }
-constexpr int kMaxDeferred = 64;              // ordered launch, second pass: searches run alone afterwards before the pass gives up for good
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
@@ -137,8 +136,6 @@ struct AstarArgs {
                                         // for memory (call_for_memory)
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
-    int defer;                    // ordered launch: a lowest running search that finds no memory ends as status 2 and the pass goes on (the host runs it
-                                  // alone afterwards); 0: the pass gives up and the host starts the batch again with more room
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
                                   // direction at a time, with the whole pool to itself)
 };
@@ -828,13 +825,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     used = GX::bcast(used, 0, gbase);
                     if (used <= own || starved > (1u << 18)) {                       // (the second: a backstop -- no room for ten seconds of calling)
                         status = 2; st = S_DONE;
-                        if (gl == 0) {
-                            // no further seed is taken, the pass is going to be run again -- or, in the pass that defers such searches, goes on
-                            // unless they are many (every one of them holds the whole device up for a tenth of a second and more)
-                            bool give_up = !a.defer;
-                            if (a.defer) give_up = __hip_atomic_fetch_add(&a.start_limit[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)kMaxDeferred;
-                            if (give_up) st_agent(&a.start_limit[4], 1ull);
-                        }
+                        if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
                     }
                 } else if (level >= 0 && (uint64_t)n_expanded < (256ull << (2 * level))) {
                     if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {

@@ -367,8 +367,8 @@ static int main_search(int argc, char **argv) {
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
-        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, %lld run alone after the others, pool %.1f of %.1f GB)",
-             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries, (long long)st.n_deferred,
+        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, pool %.1f of %.1f GB)",
+             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries,
              st.pool_used / 1e9, st.pool_bytes / 1e9);
     };
     // the genes of the list one after the other (search.cpp:124).  MEGAGTA_SEARCH_LANES=2 searches two genes side by side on one

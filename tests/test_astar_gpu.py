@@ -248,10 +248,6 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
                         assert "do not fit" in str(e)
                         sizes.append((window, kb, "error"))
                         continue
-                    if st["n_deferred"] > 0:              # a search too large for the whole (tiny) pool even as the lowest running seed, but not
-                        sizes.append((window, kb, "deferred %d" % st["n_deferred"]))   # when alone: run after the others (the seeds behind it did
-                        assert len(got) == len(want)      # not see its path: the one documented deviation, reported in the stats)
-                        continue
                     sizes.append((window, kb, st["n_retries"]))
                     seen_yield |= st["n_retries"] > 0
                     assert st["n_expansions"] == st0["n_expansions"], sizes
