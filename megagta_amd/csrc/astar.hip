@@ -358,10 +358,6 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
                 todo[d].swap(again);
             }
-            // ordered launches: the batch is started again ONCE, with all the memory there is (pass 1 takes `avail`); a lowest running seed
-            // that finds no memory there either cannot be served by any further pass -- fewer workgroups do not enlarge the pool, and at 50 M
-            // reads two more restarts on an eighth of the device and on two workgroups were minutes each for nothing: reported below
-            if (gated && attempt >= 1 && (!todo[0].empty() || !todo[1].empty())) break;
             if (gated && (!todo[0].empty() || !todo[1].empty())) {
                 fprintf(stderr, "[megagta_amd] search: %zu searches found no memory even as the lowest running seeds (pool %.1f GB); the batch of %lld seeds "
                         "starts again with more room\n", todo[0].size() + todo[1].size(), pool_bytes / 1e9, (long long)n);
