@@ -297,6 +297,19 @@ static mgta_hmm *upload_hmm(mgta_ctx *ctx, const std::string &path) {
     return out;
 }
 
+// ordered-commit window B and cost term R of a gene's batch by its number of seeds, with the MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE
+// overrides (search_dist.py::window_and_rate is the same table for the multi-GPU ranks; `megagta searchplan N` prints it, tests compare)
+static void search_plan(size_t ns, int *window, int *rate) {
+    int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
+    if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
+    int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (> 0: expansions per seed, < 0: seeds
+    bool cost_rate_set = false;                     // per expansion, 0: no cost term); unset = chosen per gene by its number of seeds
+    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) { cost_rate = atoi(e); cost_rate_set = true; }
+    *window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
+    // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
+    *rate = cost_rate_set ? cost_rate : *window == 1 ? 0 : (ns < 65536 ? 4 : ns < 393216 ? 2 : 1);
+}
+
 static int main_search(int argc, char **argv) {
     RssLine rss;
     if (argc < 7) {
@@ -308,11 +321,6 @@ static int main_search(int argc, char **argv) {
     double pen = atof(argv[6]);
     // argv[7] (num_threads) is accepted and ignored: the batch runs on the device.  The shared term_nodes cache (search.cpp:182)
     // runs with an ordered-commit window (deterministic); MEGAGTA_CACHE_WINDOW overrides: 0 = no sharing, 1 = exactly `search ... 1`
-    int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
-    if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
-    int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (> 0: expansions per seed, < 0: seeds
-    bool cost_rate_set = false;                     // per expansion, 0: no cost term); unset = chosen per gene by its number of seeds
-    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) { cost_rate = atoi(e); cost_rate_set = true; }
     double t0 = now_s();
     logf("Loading SdBG...");
     mgta_ctx *ctx = ctx_get();
@@ -360,9 +368,9 @@ static int main_search(int argc, char **argv) {
         //  from ~400 k seeds on one seed per expansion: 414 k seeds (10 M-read graph) 8192 + 1 12.7 s; 400 k seeds of rplB on the 100 M-read
         //  graph (profiles/r03/sweep_window_400k_100M.log): 8192 + 2 26.8 s, 8192 + 1 22.1 / 22.2 / 25.3 s, 4096 + 1 21.9 s, unordered 15.9 s
         const size_t ns = kmers.size();
-        const int window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
-        // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
-        if (mgta_ctx_set_search_cost_rate(ctx, cost_rate_set ? cost_rate : window == 1 ? 0 : (ns < 65536 ? 4 : ns < 393216 ? 2 : 1)) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
+        int window = 0, rate = 0;
+        search_plan(ns, &window, &rate);
+        if (mgta_ctx_set_search_cost_rate(ctx, rate) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
@@ -796,6 +804,14 @@ static int dispatch(int argc, char **argv) {
     if (sub == "sdbgmerge") {    // after a build over N GPUs: <prefix> <N> -> PREFIX.sdbg_info naming the N files (host only)
         if (argc < 4 || atoi(argv[3]) < 1) { fprintf(stderr, "Usage %s <sdbg_prefix> <num_parts>\n", argv[1]); return 1; }
         merge_sdbg_parts(argv[2], atoi(argv[3]));
+        return 0;
+    }
+    if (sub == "searchplan") {   // <n_seeds>...: the window and cost term `search` would take for batches of that many seeds (host only)
+        for (int i = 2; i < argc; ++i) {
+            int window = 0, rate = 0;
+            search_plan((size_t)atoll(argv[i]), &window, &rate);
+            printf("%s %d %d\n", argv[i], window, rate);
+        }
         return 0;
     }
     if (sub == "dumpversion") { printf("%s\n", mgta_version()); return 0; }

@@ -224,3 +224,25 @@ def test_driver_checkpoint_order_of_the_last_step(tmp_path, monkeypatch):
     drv.opt.continue_mode, drv.opt.last_cp = True, 4
     drv.search_contigs(44)
     assert "again" not in calls and drv.cp == 1
+
+
+def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
+    """the ordered-commit window and the cost term are chosen by the number of seeds of a gene's batch: `megagta search` (C++,
+    `megagta searchplan N...` prints its choice, host only) and the multi-GPU ranks (search_dist.window_and_rate) must agree, with and
+    without the MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE overrides"""
+    import subprocess
+    from megagta_amd import search_dist
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "megagta_amd", "bin", "megagta")
+    ns = [0, 1, 7000, 32767, 32768, 65535, 65536, 196607, 196608, 393215, 393216, 1_000_000, 9_300_000]
+    for env in ({}, {"MEGAGTA_CACHE_WINDOW": "1"}, {"MEGAGTA_CACHE_WINDOW": "-1"}, {"MEGAGTA_CACHE_WINDOW": "64", "MEGAGTA_CACHE_COST_RATE": "-2"},
+                {"MEGAGTA_CACHE_COST_RATE": "0"}, {"MEGAGTA_CACHE_WINDOW": "1", "MEGAGTA_CACHE_COST_RATE": "3"}):
+        for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        out = subprocess.run([exe, "searchplan"] + [str(n) for n in ns], capture_output=True, text=True, check=True, env=dict(os.environ)).stdout.split("\n")
+        got = [tuple(int(x) for x in line.split()[1:]) for line in out if line.strip()]
+        assert got == [search_dist.window_and_rate(n) for n in ns], env
+    for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
+        monkeypatch.delenv(key, raising=False)
+    assert search_dist.window_and_rate(400_000) == (8192, 1) and search_dist.window_and_rate(100_000) == (4096, 2)
