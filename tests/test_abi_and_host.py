@@ -246,3 +246,12 @@ def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
     for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
         monkeypatch.delenv(key, raising=False)
     assert search_dist.window_and_rate(400_000) == (8192, 1) and search_dist.window_and_rate(100_000) == (4096, 2)
+
+
+def test_bucket_range_of_the_count_scan_without_a_division():
+    """the count scan of a multi-range build finds the range of an item's bucket as ((b - b_lo) * ceil(2^32 / width)) >> 32 (sdbg_build.hip,
+    ScanArgs::multi_magic) instead of dividing per item: exact for every width and every offset a 65536-bucket space can produce"""
+    x = np.arange(0, 65536, dtype=np.uint64)
+    for d in range(1, 65537):
+        m = np.uint64(((1 << 32) + d - 1) // d)
+        assert np.array_equal((x * m) >> np.uint64(32), x // np.uint64(d)), d
