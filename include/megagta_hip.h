@@ -75,9 +75,11 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);   /* < 0
  * hash table being re-built at twice the size when half full.  When the pool itself runs dry: an independent search (cache_mode 0 / -1)
  * that has waited in vain is run again by the host with fewer searches at a time (mgta_astar_stats.n_retries); under the ordered-commit
  * window (cache_mode B >= 1) a starved search gives its memory back and starts again IN PLACE -- its slot keeps holding the window, the
- * lowest running seed never yields -- so the result stays a function of (seed order, B, cost rate) whatever starved when; only if the
- * lowest seed alone finds no room is the whole batch started again (caches empty, a note on stderr).  Small values exercise these paths
- * on small inputs (tests). */
+ * lowest running seed never yields and has a reserve of its own (an eighth of the memory on top of the pool; with an explicit pool_bytes
+ * an eighth OF it) -- so the result stays a function of (seed order, B, cost rate) whatever starved when; only if the lowest seed outgrows
+ * the reserve as well does the pass give up, and the batch RESUMES behind its commit frontier (everything that has ended is final; the
+ * caches stay) with a larger share in the reserve: 1/2, then 7/8, then one search at a time (mgta_astar_stats.n_resumes, a note on
+ * stderr).  Small values exercise these paths on small inputs (tests). */
 int mgta_ctx_set_search_arena(mgta_ctx *, int log2_base_nodes, uint64_t pool_bytes);
 
 /* ------------------------------------------------------------------------------------------------
@@ -244,6 +246,12 @@ typedef struct mgta_astar_stats {
     double ms_total, ms_kernel;
     int64_t n_grown, n_rehash, n_recycled;                /* searches that outgrew their base arena, hash tables re-built, chunks re-used */
     uint64_t pool_bytes, pool_used;                       /* device memory set aside for the searches / most of it in use at once */
+    int64_t n_resumes;                                    /* ordered window only: passes that gave up (the lowest running search outgrew its
+                                                           * reserve) and were resumed behind the commit frontier (normally 0) */
+    uint64_t reserve_bytes, reserve_used;                 /* the lowest running search's reserve (last pass) / most of it ever in use */
+    int64_t max_search_nodes, max_search_expansions;      /* the largest single search of the batch: nodes opened, nodes expanded */
+    int64_t hmm_in_lds;                                   /* 1: the HMM tables were staged in LDS; 0: (M + 1)(A + 11) * 8 B beside the heap tops
+                                                           * exceed the CU's 160 KB (models longer than ~400 columns): read from device memory */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */

@@ -50,7 +50,9 @@ class AstarSide(C.Structure):
 class AstarStats(C.Structure):
     _fields_ = [("n_seeds", C.c_int64), ("n_expansions", C.c_int64), ("n_opened", C.c_int64), ("n_retries", C.c_int64),
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double), ("n_grown", C.c_int64), ("n_rehash", C.c_int64),
-                ("n_recycled", C.c_int64), ("pool_bytes", C.c_uint64), ("pool_used", C.c_uint64)]
+                ("n_recycled", C.c_int64), ("pool_bytes", C.c_uint64), ("pool_used", C.c_uint64), ("n_resumes", C.c_int64),
+                ("reserve_bytes", C.c_uint64), ("reserve_used", C.c_uint64), ("max_search_nodes", C.c_int64),
+                ("max_search_expansions", C.c_int64), ("hmm_in_lds", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

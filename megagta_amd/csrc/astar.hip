@@ -131,9 +131,35 @@ int mgta_astar_batch(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, con
     return mgta_astar_batch_on(g ? g->ctx : nullptr, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, sink, user, stats);
 }
 
+}  // extern "C"
+
+namespace {
+struct PackedOut {               // mgta_astar_batch_packed: the contigs written straight into one malloc'd buffer
+    char **contigs;
+    uint64_t *offsets;           // [n + 1]
+    mgta_astar_side *sides;      // [2 n] or null
+};
+int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state,
+                     int64_t n, int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user,
+                     mgta_astar_stats *stats, const PackedOut *packed);
+}  // namespace
+
+extern "C" {
 int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state,
                         int64_t n, int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user,
                         mgta_astar_stats *stats) {
+    // (no exception crosses the C boundary: a host allocation that fails inside is an error code like any other)
+    try {
+        return astar_batch_impl(ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, sink, user, stats, nullptr);
+    } catch (const std::bad_alloc &) { set_error("mgta_astar_batch: out of host memory"); return MGTA_ENOMEM; }
+      catch (const std::exception &e) { set_error("mgta_astar_batch: %s", e.what()); return MGTA_EHIP; }
+}
+}  // extern "C"
+
+namespace {
+int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state,
+                     int64_t n, int prune_len, double low_cov_penalty, int cache_mode, mgta_contig_sink sink, void *user,
+                     mgta_astar_stats *stats, const PackedOut *packed) {
     if (!ctx || !g || !fwd || !rev || n < 0 || (n > 0 && (!kmers || !start_state))) { set_error("mgta_astar_batch: bad argument"); return MGTA_EINVAL; }
     if (cache_mode < -1) { set_error("cache_mode must be >= -1"); return MGTA_EINVAL; }
     const bool free_share = cache_mode == -1;          // shared caches without any ordering (timing-dependent results, like the reference's OMP run)
@@ -217,6 +243,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         const size_t lds_fix = G == 8 ? lds_fixed<8>() : G == 16 ? lds_fixed<16>() : G == 32 ? lds_fixed<32>() : lds_fixed<64>();
         const bool use_lds = lds_fix + tab_bytes + 1024 <= 160 * 1024;             // heap tops + level tables + HMM tables
         const size_t lds_bytes = lds_fix + (use_lds ? tab_bytes : 0);
+        ST.hmm_in_lds = use_lds ? 1 : 0;
 
         std::vector<int64_t> todo[2];
         for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
@@ -240,15 +267,20 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, cap * sizeof(CacheEnt), st));
                 a.cache[d] = d_cache[d].as<CacheEnt>(); a.cache_mask[d] = cap - 1;
             }
-            d_start_limit.alloc(64);                                                // [0..1] limit per direction, [2..3] scan lock, [4] pass given up
-            MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 64, st));
-            a.start_limit = d_start_limit.as<unsigned long long>();
+            d_start_limit.alloc(128);                                               // [0..1] limit per direction, [2..3] scan lock, [4] pass given up, [5] call for memory;
+            a.start_limit = d_start_limit.as<unsigned long long>();                 // [8..10] the reserve's bump pointer, high-water mark and owner
+            a.pool.rbump = a.start_limit + 8;
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         }
 
         // ordered launches (window B >= 1) never re-run single searches: a search that starves yields its memory and starts again in place
-        // (astar_kernel.hpp), so the result stays a function of (seed order, B, rate).  Only when the LOWEST running seed itself cannot
-        // be served does the pass give up; the whole batch then starts again, caches empty, with more room and fewer searches at a time.
+        // (astar_kernel.hpp), so the result stays a function of (seed order, B, rate), and the lowest running search -- the one every
+        // later seed waits for -- has a RESERVE of its own behind the pool.  Only when that search has used up the reserve as well does the
+        // pass give up.  Everything that has ended by then is final (a seed only ever started once nothing unfinished could still become
+        // visible to it), so the next pass RESUMES behind the commit frontier: results, caches and statuses stay, the seeds that have not
+        // ended run again in their order, with a larger share of the memory in the reserve (1/8, 1/2, 7/8; the last pass one search per
+        // direction at a time with everything).  The reference has no such limit to hit: PoolST / HashMapST grow until the host is out of
+        // memory (pool_st.h:43, hash_table_st.h:559-568).
         const bool gated = cache_mode > 0 && !free_share;
         const int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 12;
         const uint64_t slot_bytes = 128ull << log_b0;                               // per node of the base arena: 64 B + 2 heap slots + 2 hash entries of 16 B
@@ -262,13 +294,13 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             // a context that shares the device with another batch (two genes searched side by side) takes its share of the CUs
             blocks = std::min<int64_t>(blocks, std::max<int64_t>(2, (int64_t)ctx->num_cus * (use_lds ? 1 : 2) * ctx->search_share_num / ctx->search_share_den));
             if (const char *e = getenv("MGTA_ASTAR_BLOCKS")) blocks = std::min<int64_t>(blocks, std::max(2, atoi(e)));   // (diagnostic)
-            if (attempt == 2) blocks = std::max<int64_t>(2, blocks / 8);
+            if (!gated && attempt == 2) blocks = std::max<int64_t>(2, blocks / 8);
             if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
-            // pool = the slots' base arenas + what the searches grow into.  Device memory beyond the first ~24 GB of a process costs
-            // 20-90 ms/GB to obtain (profiles/r02/vmm_probe.log), so the pool follows the job: at least 4 GB; 24 MB per search in
-            // flight (196 GB for a full grid) for independent searches -- at 100 M reads they average 29 k expansions
+            // pool = the slots' base arenas + what the searches grow into (+ the reserve).  Device memory beyond the first ~24 GB of a
+            // process costs 20-90 ms/GB to obtain (profiles/r02/vmm_probe.log), so the pool follows the job: at least 4 GB; 24 MB per
+            // search in flight (196 GB for a full grid) for independent searches -- at 100 M reads they average 29 k expansions
             // and hold 62 GB together -- and 8 MB per slot (64 GB) where the searches share their paths and most end after a few
             // hundred; 16 MB for batches of a million searches and more (20 M reads: 68 GB in use at most, 93 GB handed out).  No new search starts while half
             // of it is in use, so a small pool costs searches in flight, not failures.
@@ -278,18 +310,37 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
                                                  : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
-            // the first re-run has the pool of the first pass to itself with a fraction of the searches; only the later ones ask for
-            // everything that is free (obtaining 200 GB takes seconds)
-            if (attempt == 1 && !ctx->astar_pool_bytes && ar.pool.bytes > slots * slot_bytes) dyn = std::max<uint64_t>(dyn, ar.pool.bytes - slots * slot_bytes);
-            if ((attempt > 1 || (gated && attempt == 1)) && !ctx->astar_pool_bytes) dyn = avail;
-            dyn = std::min<uint64_t>(dyn, avail > slots * slot_bytes ? avail - slots * slot_bytes : 0);
+            const uint64_t room = avail > slots * slot_bytes ? avail - slots * slot_bytes : 0;
+            uint64_t reserve = 0;
+            if (gated) {
+                // dyn is what the searches share, the reserve comes on top in the first pass (an eighth of it, at least 1 GB where the
+                // pool is sized by the job); a pass that resumes takes all the memory there is and moves the border
+                static const int kShare8[4] = {1, 4, 7, 0};                         // eighths of the whole in the reserve
+                if (ctx->astar_pool_bytes) {                                        // (tests: pool_bytes is the whole)
+                    reserve = attempt < 3 ? dyn * kShare8[attempt] / 8 : 0;
+                    dyn -= reserve;
+                } else if (attempt == 0) {
+                    reserve = std::max<uint64_t>(dyn / 8, 1ull << 30);
+                    if (dyn + reserve > room) { const uint64_t whole = std::min(dyn + reserve, room); reserve = whole / 8; dyn = whole - reserve; }
+                } else {
+                    reserve = attempt < 3 ? room / 8 * kShare8[attempt] : 0;
+                    dyn = room - reserve;
+                }
+            } else {
+                // the first re-run has the pool of the first pass to itself with a fraction of the searches; only the later ones ask for
+                // everything that is free (obtaining 200 GB takes seconds)
+                if (attempt == 1 && !ctx->astar_pool_bytes && ar.pool.bytes > slots * slot_bytes) dyn = std::max<uint64_t>(dyn, ar.pool.bytes - slots * slot_bytes);
+                if (attempt > 1 && !ctx->astar_pool_bytes) dyn = avail;
+                dyn = std::min<uint64_t>(dyn, room);
+            }
             // a pool of nearly that size is there (the previous gene's, sized from a slightly different count of free bytes): keep it
             // rather than obtain 100+ GB again for a few per cent more
-            if (attempt == 0 && !ctx->astar_pool_bytes && ar.pool.p && ar.pool.bytes > slots * slot_bytes &&
-                ar.pool.bytes - slots * slot_bytes >= dyn - dyn / 4 && ar.pool.bytes - slots * slot_bytes < dyn)
-                dyn = ar.pool.bytes - slots * slot_bytes;
+            if (attempt == 0 && !ctx->astar_pool_bytes && ar.pool.p && ar.pool.bytes > slots * slot_bytes + reserve &&
+                ar.pool.bytes - slots * slot_bytes - reserve >= dyn - dyn / 4 && ar.pool.bytes - slots * slot_bytes - reserve < dyn)
+                dyn = ar.pool.bytes - slots * slot_bytes - reserve;
             dyn &= ~((1ull << kUnitLog) - 1);
-            const uint64_t pool_bytes = slots * slot_bytes + dyn;
+            reserve &= ~((1ull << kUnitLog) - 1);
+            const uint64_t pool_bytes = slots * slot_bytes + dyn + reserve;
             if (ar.pool.bytes < pool_bytes || !ar.pool.p) {
                 ar.pool.release();
                 ar.pool.alloc(pool_bytes, &ctx->live_bytes, &ctx->peak_bytes);
@@ -311,7 +362,8 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
                 MGTA_HIP_CHECK(hipMemcpyAsync(w + 16 + 2 * kNumClasses, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
                 const unsigned long long bump0 = slots * slot_bytes;
                 MGTA_HIP_CHECK(hipMemcpyAsync(w, &bump0, 8, hipMemcpyHostToDevice, st));
-                a.pool.base = ar.pool.as<char>(); a.pool.bytes = pool_bytes;
+                a.pool.base = ar.pool.as<char>(); a.pool.bytes = slots * slot_bytes + dyn;
+                a.pool.reserve_off = slots * slot_bytes + dyn; a.pool.reserve_bytes = reserve;
                 a.pool.bump = reinterpret_cast<unsigned long long *>(w);
                 a.pool.stat = reinterpret_cast<unsigned long long *>(w + 2);
                 a.pool.lock = w + 16; a.pool.cnt = w + 16 + kNumClasses;
@@ -324,6 +376,7 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             if (cache_mode > 0) {
+                MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 128, st));           // (limits are recomputed: a conservative restart of the gate)
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_seed.p, 0xFF, slots * 8, st));
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_progress.p, 0, slots * 8, st));
@@ -342,8 +395,12 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            unsigned long long h_pool[8];                                           // bump, stat[0..6]
+            unsigned long long h_pool[8], h_lim[16];                                // bump, stat[0..6]; the gate's words and the reserve's
+            uint32_t h_cnt[kNumClasses];
+            memset(h_lim, 0, sizeof(h_lim));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 64, hipMemcpyDeviceToHost, st));
+            MGTA_HIP_CHECK(hipMemcpyAsync(h_cnt, ar.meta.as<uint32_t>() + 16 + kNumClasses, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+            if (cache_mode > 0) MGTA_HIP_CHECK(hipMemcpyAsync(h_lim, d_start_limit.p, 128, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
             MGTA_HIP_CHECK(hipGetLastError());
             float ms = 0;
@@ -353,28 +410,40 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
             ST.n_retries += (int64_t)h_pool[7];                                      // searches that started again in place
             ST.pool_bytes = pool_bytes;
             ST.pool_used = std::max<uint64_t>(ST.pool_used, slots * slot_bytes + h_pool[6]);   // base arenas + most ever handed out at once
+            ST.reserve_bytes = reserve;
+            ST.reserve_used = std::max<uint64_t>(ST.reserve_used, h_lim[9]);
+            size_t left = 0, starved_out = 0;
             for (int d = 0; d < 2; ++d) {
                 std::vector<int64_t> again;
-                for (int64_t s : todo[d]) if (h_status[(size_t)s * 2 + d] == 2) again.push_back(s);
-                todo[d].swap(again);
-            }
-            if (gated && (!todo[0].empty() || !todo[1].empty())) {
-                fprintf(stderr, "[megagta_amd] search: %zu searches found no memory even as the lowest running seeds (pool %.1f GB); the batch of %lld seeds "
-                        "starts again with more room\n", todo[0].size() + todo[1].size(), pool_bytes / 1e9, (long long)n);
-                for (int d = 0; d < 2; ++d) {
-                    todo[d].resize(n);
-                    for (int64_t s = 0; s < n; ++s) todo[d][s] = s;
-                    MGTA_HIP_CHECK(hipMemsetAsync(d_cache[d].p, 0, d_cache[d].bytes, st));
+                for (int64_t s : todo[d]) {
+                    const int32_t v = h_status[(size_t)s * 2 + d];
+                    if (v == 2) ++starved_out;
+                    if (v == 2 || (gated && v == 0)) again.push_back(s);            // (ordered: whatever has not ended runs again, in seed order)
                 }
-                MGTA_HIP_CHECK(hipMemsetAsync(d_status.p, 0, n * 8, st));
-                MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 64, st));
+                todo[d].swap(again);
+                left += todo[d].size();
             }
-            ST.n_retries += (int64_t)(todo[0].size() + todo[1].size());
-            if (getenv("MGTA_ASTAR_VERBOSE"))
-                fprintf(stderr, "[astar] pass %d: %lld workgroups, pool %.1f GB, handed out once %.1f GB, most in use %.1f GB, %llu chunks reused, "
-                        "%llu requests refused, %llu searches started again in place, %.0f ms, %zu searches to run again\n", attempt, (long long)blocks,
-                        pool_bytes / 1e9, h_pool[0] / 1e9, (slots * slot_bytes + h_pool[6]) / 1e9, h_pool[1], h_pool[2], h_pool[7], ms,
-                        todo[0].size() + todo[1].size());
+            const bool verbose = getenv("MGTA_ASTAR_VERBOSE") != nullptr;
+            if (verbose || (gated && left)) {
+                std::string lists;
+                for (int c = 0; c < kNumClasses; ++c)
+                    if (h_cnt[c]) { char b[48]; snprintf(b, sizeof(b), " %u x %s", h_cnt[c], c + kUnitLog >= 30 ? (std::to_string(1u << (c + kUnitLog - 30)) + " GB").c_str() : c + kUnitLog >= 20 ? (std::to_string(1u << (c + kUnitLog - 20)) + " MB").c_str() : (std::to_string(1u << (c + kUnitLog - 10)) + " KB").c_str()); lists += b; }
+                fprintf(stderr, "[astar] pass %d: %lld workgroups, pool %.1f GB (reserve %.1f GB, %.1f GB of it used), handed out once %.1f GB, most in use %.1f GB, "
+                        "%llu chunks reused, %llu requests refused, %llu searches started again in place, %.0f ms, %zu searches to run again; free lists at the end:%s\n",
+                        attempt, (long long)blocks, pool_bytes / 1e9, reserve / 1e9, h_lim[9] / 1e9, h_pool[0] / 1e9, (slots * slot_bytes + h_pool[6]) / 1e9, h_pool[1],
+                        h_pool[2], h_pool[7], ms, left, lists.empty() ? " none" : lists.c_str());
+            }
+            if (gated && left) {
+                ++ST.n_resumes;
+                fprintf(stderr, "[megagta_amd] search: %zu search(es) found no memory even as the lowest running seed with a reserve of %.1f GB (pool %.1f GB); "
+                        "the batch of %lld seeds resumes behind its commit frontier (%zu searches left) with a larger reserve\n", starved_out, reserve / 1e9,
+                        pool_bytes / 1e9, (long long)n, left);
+                for (int d = 0; d < 2; ++d)                                          // (status 2 -> 0: a search that is cut off again must not look starved)
+                    for (int64_t s : todo[d]) h_status[(size_t)s * 2 + d] = 0;
+                MGTA_HIP_CHECK(hipMemcpyAsync(d_status.p, h_status.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            } else {
+                ST.n_retries += (int64_t)left;                                       // independent searches run again by the host
+            }
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         }
         if (!todo[0].empty() || !todo[1].empty()) {
@@ -421,25 +490,52 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         float ms = 0;
         MGTA_HIP_CHECK(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
         ST.ms_total = ms;
-        std::string left;
-        for (int64_t s = 0; s < n; ++s) {
-            for (int d = 0; d < 2; ++d) {
-                if (h_status[(size_t)s * 2 + d] == 3) {
-                    set_error("seed %lld: k-mer / model position outside the model (start_state %d)", (long long)s, start_state[s]);
-                    return MGTA_EINVAL;
-                }
-                ST.n_expansions += h_sides[(size_t)s * 2 + d].n_expanded;
-                ST.n_opened += h_sides[(size_t)s * 2 + d].n_opened;
+        uint32_t max_nodes = 0, max_exp = 0;
+        for (int64_t s = 0; s < n * 2; ++s) {
+            if (h_status[(size_t)s] == 3) {
+                set_error("seed %lld: k-mer / model position outside the model (start_state %d)", (long long)(s / 2), start_state[s / 2]);
+                return MGTA_EINVAL;
             }
-            if (sink) {
+            ST.n_expansions += h_sides[(size_t)s].n_expanded;
+            ST.n_opened += h_sides[(size_t)s].n_opened;
+            max_nodes = std::max<uint32_t>(max_nodes, (uint32_t)h_sides[(size_t)s].n_opened);
+            max_exp = std::max<uint32_t>(max_exp, (uint32_t)h_sides[(size_t)s].n_expanded);
+        }
+        ST.max_search_nodes = max_nodes; ST.max_search_expansions = max_exp;
+        auto rev_comp = [](char *dst, const char *l, uint32_t ll) {                // RevComp, hmm_graph_search.h:362-398
+            for (uint32_t i = 0; i < ll; ++i) {
+                const char c = l[ll - 1 - i];
+                dst[i] = c == 'a' ? 't' : c == 'c' ? 'g' : c == 'g' ? 'c' : c == 't' ? 'a' : c;
+            }
+        };
+        if (packed) {
+            // contig i = left + lower-cased seed k-mer + right (hmm_graph_search.h:60-81), written once into its final place
+            const uint64_t total = n_chars + (uint64_t)n * (uint64_t)klen;
+            char *buf = static_cast<char *>(malloc(total + 1));
+            if (!buf) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
+            uint64_t at = 0;
+            for (int64_t s = 0; s < n; ++s) {
+                packed->offsets[s] = at;
+                const uint32_t ll = h_len[(size_t)2 * s + 1], rl = h_len[(size_t)2 * s];
+                rev_comp(buf + at, h_out.data() + h_off[(size_t)2 * s + 1], ll);
+                at += ll;
+                const char *km = kmers + (size_t)s * klen;
+                for (int j = 0; j < klen; ++j) buf[at + j] = (char)tolower((unsigned char)km[j]);   // the seed k-mer, lower case (search.cpp:156)
+                at += klen;
+                memcpy(buf + at, h_out.data() + h_off[(size_t)2 * s], rl);
+                at += rl;
+            }
+            packed->offsets[n] = at;
+            buf[at] = 0;
+            if (packed->sides) memcpy(packed->sides, h_sides.data(), h_sides.size() * sizeof(mgta_astar_side));
+            *packed->contigs = buf;
+        } else if (sink) {
+            std::string left;
+            for (int64_t s = 0; s < n; ++s) {
                 const char *r = h_out.data() + h_off[(size_t)2 * s];
-                const char *l = h_out.data() + h_off[(size_t)2 * s + 1];
-                uint32_t ll = h_len[(size_t)2 * s + 1];
+                const uint32_t ll = h_len[(size_t)2 * s + 1];
                 left.assign(ll, ' ');
-                for (uint32_t i = 0; i < ll; ++i) {                                  // RevComp, hmm_graph_search.h:362-398
-                    char c = l[ll - 1 - i];
-                    left[i] = c == 'a' ? 't' : c == 'c' ? 'g' : c == 'g' ? 'c' : c == 't' ? 'a' : c;
-                }
+                rev_comp(&left[0], h_out.data() + h_off[(size_t)2 * s + 1], ll);
                 int src = sink(user, s, left.data(), (int64_t)ll, r, (int64_t)h_len[(size_t)2 * s], &h_sides[(size_t)2 * s],
                                &h_sides[(size_t)2 * s + 1]);
                 if (src != 0) { set_error("contig sink returned %d", src); return MGTA_ESINK; }
@@ -449,45 +545,27 @@ int mgta_astar_batch_on(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const 
         return MGTA_OK;
     } catch (const HipError &e) { return e.code; }
 }
+}  // namespace
 
+extern "C" {
 // The same batch with the results in flat arrays instead of one call-back per seed (a Python caller pays microseconds per call-back:
 // minutes at millions of seeds): contig i = (*contigs)[offsets[i] .. offsets[i + 1]) = left + lower-cased k-mer + right, exactly the
 // sequence line `search` writes (hmm_graph_search.h:60-81).
-namespace {
-struct PackSink {
-    std::string text;
-    uint64_t *offsets;
-    mgta_astar_side *sides;
-    const char *kmers;
-    int klen;
-};
-int pack_sink(void *user, int64_t i, const char *left, int64_t ll, const char *right, int64_t rl, const mgta_astar_side *rs, const mgta_astar_side *ls) {
-    PackSink &p = *static_cast<PackSink *>(user);
-    p.offsets[i] = p.text.size();
-    p.text.append(left, (size_t)ll);
-    const char *km = p.kmers + (size_t)i * p.klen;
-    for (int j = 0; j < p.klen; ++j) p.text.push_back((char)tolower((unsigned char)km[j]));       // the seed k-mer, lower case (search.cpp:156)
-    p.text.append(right, (size_t)rl);
-    if (p.sides) { p.sides[2 * i] = *rs; p.sides[2 * i + 1] = *ls; }
-    return 0;
-}
-}  // namespace
-
 int mgta_astar_batch_packed(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *rev, const char *kmers, const int32_t *start_state, int64_t n,
                             int prune_len, double low_cov_penalty, int cache_mode, char **contigs, uint64_t *offsets, mgta_astar_side *sides,
                             mgta_astar_stats *stats) {
     if (!g || !contigs || !offsets) { set_error("mgta_astar_batch_packed: bad argument"); return MGTA_EINVAL; }
     *contigs = nullptr;
-    PackSink ps{std::string(), offsets, sides, kmers, g->dev.k + 1};
-    const int rc = mgta_astar_batch_on(g->ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, pack_sink, &ps, stats);
-    if (rc != MGTA_OK) return rc;
-    offsets[n] = ps.text.size();
-    char *buf = static_cast<char *>(malloc(ps.text.size() + 1));
-    if (!buf) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
-    memcpy(buf, ps.text.data(), ps.text.size());
-    buf[ps.text.size()] = 0;
-    *contigs = buf;
-    return MGTA_OK;
+    const PackedOut po{contigs, offsets, sides};
+    try {
+        if (n == 0) {
+            char *buf = static_cast<char *>(malloc(1));
+            if (!buf) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
+            buf[0] = 0; offsets[0] = 0; *contigs = buf;
+        }
+        return astar_batch_impl(g->ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, nullptr, nullptr, stats, &po);
+    } catch (const std::bad_alloc &) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
+      catch (const std::exception &e) { set_error("mgta_astar_batch_packed: %s", e.what()); return MGTA_EHIP; }
 }
 
 }  // extern "C"

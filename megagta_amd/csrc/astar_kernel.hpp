@@ -91,6 +91,14 @@ struct PoolDev {
                                   // [4] bytes handed out and not yet returned, [5] its high-water mark (sampled when a search starts),
                                   // [6] searches that gave their memory back and started again in place (ordered launches only)
     unsigned long long soft_limit;   // no new search starts while more than this is in use: the ones that run keep room to grow
+    // The RESERVE: the last reserve_bytes of the pool, behind `bytes`, with a bump pointer of its own and no free lists.  Only the LOWEST
+    // running search of an ordered launch takes chunks from it, and only when the lists and the bump pointer above have nothing for it
+    // (late in a batch the free memory sits in lists of other sizes, and the searches that hold the rest run on without needing more):
+    // the one search every later seed waits for always finds room.  One owner at a time (the owner word is claimed by CAS: the two
+    // directions take their seeds from two queues, so a search can be the lowest running one for a while and then see a lower one
+    // start); the owner resets the bump pointer when it ends or yields; chunks of the reserve never enter a free list.
+    unsigned long long reserve_off, reserve_bytes;
+    unsigned long long *rbump;    // [0] next never-used byte of the reserve, [1] its high-water mark over the launch, [2] owner (search id + 1, 0 = free)
 };
 
 struct AstarArgs {
@@ -251,6 +259,7 @@ __device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit
     const int lane = lane_id();
     c += (int)(unit >> kBorrowShift);                                 // a borrowed chunk goes back to its own list
     unit &= kUnitMask;
+    if (P.reserve_bytes != 0ull && ((unsigned long long)unit << kUnitLog) >= P.reserve_off) return;   // the reserve is reset as a whole by its owner
     __hip_atomic_fetch_sub(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t turn = __ballot(true);
     while (turn) {
@@ -278,6 +287,30 @@ __device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit
 __device__ __forceinline__ void pool_release_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A chunk of the reserve (see PoolDev): called by lane 0 of the one search that owns it.
+__device__ __forceinline__ uint32_t reserve_alloc(const PoolDev &P, int c) {
+    const unsigned long long size = 1ull << (c + kUnitLog);
+    const unsigned long long old = __hip_atomic_fetch_add(&P.rbump[0], size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + size > P.reserve_bytes) {
+        __hip_atomic_fetch_sub(&P.rbump[0], size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return kNoChunk;
+    }
+    __hip_atomic_fetch_max(&P.rbump[1], old + size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // an earlier owner ran on another CU
+    return (uint32_t)((P.reserve_off + old) >> kUnitLog);
+}
+
+// lane 0 of a search that has found itself the lowest running one: claim the reserve (false: an earlier lowest search still holds it)
+__device__ __forceinline__ bool reserve_claim(const PoolDev &P, long long sid) {
+    unsigned long long expect = 0ull;
+    return __hip_atomic_compare_exchange_strong(&P.rbump[2], &expect, (unsigned long long)sid + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the owner ends or yields (after pool_release_fence(): its dirty lines are written back): everything in the reserve is free again
+__device__ __forceinline__ void reserve_release(const PoolDev &P) {
+    st_agent(&P.rbump[0], 0ull);
+    st_agent(&P.rbump[2], 0ull);
 }
 
 // ---- growable arrays of one search ---------------------------------------------------------------------------------------------
@@ -522,11 +555,19 @@ __device__ __forceinline__ long long cost_term(int rate, unsigned long long c) {
 // Highest seed that may start now: no unfinished search can still become visible to it (see AstarArgs::window).  Every lane of
 // the WAVE calls it and returns the same value; start_limit keeps the maximum ever computed (the bound only grows).  The table
 // reads are atomics performed at the coherence point, four in flight per lane.
+// The seed at position q of this direction's list of seeds to run (ascending seed indices; a launch that resumes a batch behind its
+// commit frontier holds a sub-sequence of them): every seed below it is finished or in the table; past the end, past every seed.
+__device__ __forceinline__ long long seed_at(const AstarArgs &a, int dir, unsigned long long q) {
+    const int64_t n = dir ? a.n_todo[1] : a.n_todo[0];
+    const int64_t *todo = dir ? a.todo[1] : a.todo[0];
+    return q < (unsigned long long)n ? (long long)todo[q] : (long long)a.n_seeds;
+}
 template <int G>
 __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, int lane) {
     constexpr uint32_t SPB = kAstarWaves * Grp<G>::kGroups;           // search slots per workgroup
-    const long long head = (long long)ld_agent(&a.queue[dir]);        // the queue first: every seed below it is in the table by now
+    const unsigned long long hq = ld_agent(&a.queue[dir]);            // the queue first: every seed below it is in the table by now
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long head = seed_at(a, dir, hq);
     long long bound = head + a.window - 1;
     const uint32_t n_dir = a.n_slots / 2;                             // this direction's slots: workgroups 2b + dir
     for (uint32_t t0 = 0; t0 < n_dir; t0 += 256) {
@@ -683,6 +724,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
     bool yield_check = false;                                         // ordered launch: starved for long -- give the memory back unless this is the lowest running seed
+    bool lowest_check = false;                                        // ordered launch: waiting for memory -- is this the lowest running search (the reserve's owner)?
+    bool use_reserve = false;                                         // this IS the lowest running search: what the pool cannot give it comes from the reserve
     uint32_t prog_floor = 0;                                          // expansions already announced for this seed before it started again in place
     bool have_curr = false;                                           // the node to expand is already popped (the search was waiting for memory)
     int32_t goal = -1, inter = 0, cur = 0;
@@ -729,7 +772,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also
                     // sees a slot that holds it (or its committed paths)
                     st_agent(&a.run_progress[slot], 0ull);
-                    st_agent(&a.run_seed[slot], (long long)ld_agent(&a.queue[dir]));
+                    st_agent(&a.run_seed[slot], seed_at(a, dir, ld_agent(&a.queue[dir])));
                     qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     qi = (long long)atomicAdd(&a.queue[dir], 1ull);
@@ -806,8 +849,16 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         // run in its place): a search that has waited long for memory gives back what it holds and starts again IN PLACE -- same seed,
         // its slot keeps announcing it, so every later seed waits for it exactly as before and nobody ever saw anything of it -- unless it
         // is the lowest running seed: that one keeps what it has and is served by the others' memory.  Wave-level scan, rare.
-        if (a.gate && __ballot(st == S_RUN && yield_check) != 0ull) {
+        if (a.gate && __ballot(st == S_RUN && (yield_check || lowest_check)) != 0ull) {
             const long long lo = lowest_running<G>(a, lane);
+            if (st == S_RUN && lowest_check) {
+                lowest_check = false;
+                if (sid == lo && !use_reserve) {                      // asks again at once, now with the reserve behind it
+                    int got = 0;
+                    if (gl == 0) got = reserve_claim(a.pool, sid) ? 1 : 0;
+                    if (GX::bcast(got, 0, gbase)) { use_reserve = true; starved = 0; yield_check = false; }
+                }
+            }
             if (st == S_RUN && yield_check) {
                 yield_check = false;
                 int level = -1;
@@ -816,14 +867,18 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
                     // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
-                    unsigned long long own = 0;
-                    for (int l = 1; l < n_levels; ++l) own += 1ull << (AR.chunk_class(l) + (int)(seg[l] >> kBorrowShift) + kUnitLog);
-                    for (int l = 1; l < h_levels; ++l) own += 1ull << (H.ar.chunk_class(l) + (int)(hseg[l] >> kBorrowShift) + kUnitLog);
-                    if (hclass > base_hclass) own += 1ull << (hclass + (int)(hunit >> kBorrowShift) + kUnitLog);
+                    unsigned long long own = 0;                                       // (what it holds of the pool proper: the reserve is not in `used`)
+                    auto in_pool = [&](uint32_t u) { return a.pool.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < a.pool.reserve_off; };
+                    for (int l = 1; l < n_levels; ++l) if (in_pool(seg[l])) own += 1ull << (AR.chunk_class(l) + (int)(seg[l] >> kBorrowShift) + kUnitLog);
+                    for (int l = 1; l < h_levels; ++l) if (in_pool(hseg[l])) own += 1ull << (H.ar.chunk_class(l) + (int)(hseg[l] >> kBorrowShift) + kUnitLog);
+                    if (hclass > base_hclass && in_pool(hunit)) own += 1ull << (hclass + (int)(hunit >> kBorrowShift) + kUnitLog);
                     unsigned long long used = 0;
                     if (gl == 0) used = ld_agent(&a.pool.stat[4]);
                     used = GX::bcast(used, 0, gbase);
-                    if (used <= own || starved > (1u << 18)) {                       // (the second: a backstop -- no room for ten seconds of calling)
+                    int got = 0;
+                    if (!use_reserve && a.pool.reserve_bytes != 0ull && gl == 0) got = reserve_claim(a.pool, sid) ? 1 : 0;
+                    if (GX::bcast(got, 0, gbase)) { use_reserve = true; starved = 0; }
+                    else if (used <= own || starved > (1u << 18)) {                  // (the second: a backstop -- no room for ten seconds of calling)
                         status = 2; st = S_DONE;
                         if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
                     }
@@ -837,6 +892,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         }
                     }
                     n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+                    if (use_reserve) {   // (it took the reserve as the lowest running search and a lower one has started since)
+                        if (gl == 0) reserve_release(a.pool);
+                        use_reserve = false;
+                    }
                     if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[6], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     prog_floor = n_expanded > prog_floor ? n_expanded : prog_floor;
                     starved = 0; have_curr = false;
@@ -852,6 +911,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
+            use_reserve = false; lowest_check = false; yield_check = false;
             for (uint32_t i = (uint32_t)gl; i <= hmask; i += G) hash_put(hash, i, 0ull, 0u);
             const char *km = a.kmers + seed * a.klen;
             const int n_aa = a.klen / 3;
@@ -944,7 +1004,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 uint32_t unit = 0;
                 if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && AR.chunk_class(n_levels) < kNumClasses) {
-                    if (gl == 0) unit = pool_alloc(a.pool, AR.chunk_class(n_levels));
+                    if (gl == 0) {
+                        unit = pool_alloc(a.pool, AR.chunk_class(n_levels));
+                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, AR.chunk_class(n_levels));
+                    }
                     unit = GX::bcast(unit, 0, gbase);
                     if (unit == kNoChunk) break;
                     if (gl == 0) seg[n_levels] = unit;
@@ -958,7 +1021,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 uint32_t unit = 0;
                 const uint32_t need = heap_slots_needed(n_heap + kMaxNew);
                 while (need > cap_heap && h_levels < kMaxLevels && H.ar.chunk_class(h_levels) < kNumClasses) {
-                    if (gl == 0) unit = pool_alloc(a.pool, H.ar.chunk_class(h_levels));
+                    if (gl == 0) {
+                        unit = pool_alloc(a.pool, H.ar.chunk_class(h_levels));
+                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, H.ar.chunk_class(h_levels));
+                    }
                     unit = GX::bcast(unit, 0, gbase);
                     if (unit == kNoChunk) break;
                     if (gl == 0) hseg[h_levels] = unit;
@@ -971,7 +1037,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             while (!stop && !wait_mem && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
                 uint32_t unit = kNoChunk;
                 if (hclass + 1 < kNumClasses && hmask < 0x7FFFFFFFu) {
-                    if (gl == 0) unit = pool_alloc(a.pool, hclass + 1);
+                    if (gl == 0) {
+                        unit = pool_alloc(a.pool, hclass + 1);
+                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, hclass + 1);
+                    }
                     unit = GX::bcast(unit, 0, gbase);
                 }
                 if (unit == kNoChunk) { wait_mem = true; break; }
@@ -1012,6 +1081,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             have_curr = false;
             if (wait_mem) {
                 have_curr = !first;
+                // the lowest running search does not wait: the reserve is there for it (a scan of the slot table: asked early, then rarely)
+                if (a.gate && !use_reserve && a.pool.reserve_bytes != 0ull && (starved & 1023u) == 8u) lowest_check = true;
                 // when every search in flight waits, nobody ends and nothing comes back: a search gives up after a wait in proportion
                 // to the work it would lose (a quarter of its expansions so far in iterations, 2^8 .. 2^17), so the young ones free
                 // their memory for the others within milliseconds and the ones that have run for seconds wait for seconds
@@ -1333,6 +1404,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
             }
             n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            if (use_reserve) {           // the reserve's owner ends: all of it is free for the next lowest search
+                if (gl == 0) reserve_release(a.pool);
+                use_reserve = false;
+            }
             if (a.gate && gl == 0) {     // the paths are in the cache (atomics, all performed): this search no longer holds anybody back
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&a.run_seed[slot], -1ll);

@@ -17,13 +17,16 @@
 
 namespace mgta_host {
 
+static thread_local bool t_soft_die = false;
+void set_soft_die(bool on) { t_soft_die = on; }
 void die(const char *fmt, ...) {
+    char msg[1024];
     va_list ap;
     va_start(ap, fmt);
-    fprintf(stderr, "    [ERROR] ");
-    vfprintf(stderr, fmt, ap);
-    fprintf(stderr, "\n");
+    vsnprintf(msg, sizeof(msg), fmt, ap);
     va_end(ap);
+    if (t_soft_die) throw StepFailure(msg);                            // (a background thread: the failure is reported by the step that waits for it)
+    fprintf(stderr, "    [ERROR] %s\n", msg);
     fflush(stderr);
     exit(1);
 }

@@ -6,12 +6,17 @@
 //   gene_list.txt, *_starting_kmers.txt   search.cpp:105-162
 #pragma once
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace mgta_host {
 
 [[noreturn]] void die(const char *fmt, ...);
+// A thread that has called set_soft_die(true) gets a StepFailure exception from die() instead of the process exiting under the feet of
+// whatever step the main thread is in (the worker's background writer of PREFIX.sdbg.*).
+struct StepFailure : std::runtime_error { using std::runtime_error::runtime_error; };
+void set_soft_die(bool on);
 void logf(const char *fmt, ...);   // stderr progress line, "    [file:line] ..." style is not required by the driver
 
 // ---- packed reads ---------------------------------------------------------------------------------

@@ -57,11 +57,20 @@ struct Session {
     mgta_sdbg *graph = nullptr;   // graph of the last buildgraph, not used yet
     std::string graph_prefix;
     std::thread writer;           // PREFIX.sdbg.* of the last buildgraph being written while the next step already runs on the resident graph
+    std::string writer_error;     // why that thread failed (set by the thread, read after the join)
 };
 static Session g_sess;
-// the graph files of the last buildgraph are complete (called before anything reads them, before the next build, at the end)
-static void writer_join() {
+// The graph files of the last buildgraph are complete: called before anything reads them, before the next build, at the end, and by the
+// driver's "sync" request before it writes the checkpoint that says "graph built" (the reference writes its checkpoint after the files:
+// megagta.py:538-586).  Returns 1 when the writer failed (disk full, ...): the failure belongs to the build, not to whatever step
+// happened to be running when the thread hit it.
+static int writer_join() {
     if (g_sess.writer.joinable()) g_sess.writer.join();
+    if (g_sess.writer_error.empty()) return 0;
+    fprintf(stderr, "    [ERROR] writing the graph files of the last buildgraph failed: %s\n", g_sess.writer_error.c_str());
+    fflush(stderr);
+    g_sess.writer_error.clear();
+    return 1;
 }
 
 static int env_int(const char *name, int dflt) {
@@ -126,7 +135,7 @@ static mgta_sdbg *graph_get(mgta_ctx *ctx, const std::string &prefix, int *k_out
         return g;
     }
     graph_drop();
-    writer_join();
+    if (writer_join() != 0) die("the graph files of %s are incomplete", prefix.c_str());
     mgta_sdbg *g = nullptr;                                              // the files are copied to the device as they are and parsed there
     if (mgta_sdbg_load_files(ctx, prefix.c_str(), &g) != MGTA_OK) die("mgta_sdbg_load_files: %s", mgta_last_error());
     *k_out = mgta_sdbg_k(g); *n_edges = (size_t)mgta_sdbg_size(g);
@@ -210,7 +219,7 @@ static int main_buildgraph(int argc, char **argv) {
     const int share = (65536 + world - 1) / world, b_lo = std::min(65536, rank * share), b_hi = std::min(65536, (rank + 1) * share);
 
     double t0 = now_s();
-    writer_join();
+    if (writer_join() != 0) return 1;
     PackedReads local;
     PackedReads::Mark mk;
     PackedReads &pr = lib_get(lib_file + ".bin", lib_file, assist, true, local, mk);
@@ -269,7 +278,12 @@ static int main_buildgraph(int argc, char **argv) {
         logf("Total number of edges: %zu", s.recs.size());
         logf("Total number of $v edges: %zu (write %.3f s)", s.words_per_tip ? s.tips.size() / s.words_per_tip : 0, now_s() - t1);
     };
-    if (hand_over && !getenv("MEGAGTA_SYNC_WRITES")) g_sess.writer = std::thread(write_files);
+    if (hand_over && !getenv("MEGAGTA_SYNC_WRITES"))
+        g_sess.writer = std::thread([write_files]() {
+            set_soft_die(true);
+            try { write_files(); }
+            catch (const std::exception &e) { g_sess.writer_error = e.what(); }
+        });
     else write_files();
     return 0;
 }
@@ -299,12 +313,23 @@ static mgta_hmm *upload_hmm(mgta_ctx *ctx, const std::string &path) {
 
 // ordered-commit window B and cost term R of a gene's batch by its number of seeds, with the MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE
 // overrides (search_dist.py::window_and_rate is the same table for the multi-GPU ranks; `megagta searchplan N` prints it, tests compare)
+// an integer from the environment: unset or empty = not given; anything that is not an integer is refused (search_dist.py::_env_int is the
+// same rule for the multi-GPU ranks, so that one environment means one mode on both paths)
+static bool env_int_strict(const char *name, int *out) {
+    const char *e = getenv(name);
+    if (!e || !*e) return false;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end) die("%s must be an integer (got '%s')", name, e);
+    *out = (int)std::max(-1000000000l, std::min(1000000000l, v));
+    return true;
+}
 static void search_plan(size_t ns, int *window, int *rate) {
-    int cache_window = -2;                          // -2 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
-    if (const char *e = getenv("MEGAGTA_CACHE_WINDOW")) cache_window = atoi(e);
+    int cache_window = -2;                          // < -1 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
+    env_int_strict("MEGAGTA_CACHE_WINDOW", &cache_window);
     int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (> 0: expansions per seed, < 0: seeds
-    bool cost_rate_set = false;                     // per expansion, 0: no cost term); unset = chosen per gene by its number of seeds
-    if (const char *e = getenv("MEGAGTA_CACHE_COST_RATE")) { cost_rate = atoi(e); cost_rate_set = true; }
+                                                    // per expansion, 0: no cost term); unset = chosen per gene by its number of seeds
+    const bool cost_rate_set = env_int_strict("MEGAGTA_CACHE_COST_RATE", &cost_rate);
     *window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
     // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
     *rate = cost_rate_set ? cost_rate : *window == 1 ? 0 : (ns < 65536 ? 4 : ns < 393216 ? 2 : 1);
@@ -375,9 +400,11 @@ static int main_search(int argc, char **argv) {
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
-        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, pool %.1f of %.1f GB)",
-             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries,
-             st.pool_used / 1e9, st.pool_bytes / 1e9);
+        logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, %lld resumed passes, pool %.1f of %.1f GB, "
+             "reserve %.2f of %.1f GB; largest search %lld nodes / %lld expansions)",
+             gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries, (long long)st.n_resumes,
+             st.pool_used / 1e9, st.pool_bytes / 1e9, st.reserve_used / 1e9, st.reserve_bytes / 1e9, (long long)st.max_search_nodes,
+             (long long)st.max_search_expansions);
     };
     // the genes of the list one after the other (search.cpp:124).  MEGAGTA_SEARCH_LANES=2 searches two genes side by side on one
     // graph, each batch on its own context (stream + work memory) and half of the CUs (mgta_astar_batch_on): measured and NOT the
@@ -681,11 +708,17 @@ static int main_serve() {
             if (!e) break;
         }
         if (f[0] == "quit") break;
-        if (f[0] == "release") {                                          // hand the device memory back (another process is going to need it)
-            graph_drop();
+        if (f[0] == "sync") {                                             // the files of the last buildgraph are on disk (or: why not)
+            fprintf(rep, "DONE %d\n", writer_join());
+            fflush(rep);
+            continue;
+        }
+        if (f[0] == "release") {                                          // hand the device memory back (another process is going to need it:
+            graph_drop();                                                 // it reads the graph from the files, so they are complete first)
+            const int wrc = writer_join();
             if (g_sess.ctx) mgta_ctx_release_scratch(g_sess.ctx);
             if (g_sess.ctx2) mgta_ctx_release_scratch(g_sess.ctx2);
-            fprintf(rep, "DONE 0\n");
+            fprintf(rep, "DONE %d\n", wrc);
             fflush(rep);
             continue;
         }
@@ -721,10 +754,10 @@ static int main_serve() {
         fflush(rep);
     }
     graph_drop();
-    writer_join();
+    const int wrc = writer_join();
     if (g_sess.ctx2) mgta_ctx_destroy(g_sess.ctx2);
     if (g_sess.ctx) mgta_ctx_destroy(g_sess.ctx);
-    return 0;
+    return wrc;
 }
 
 int main(int argc, char **argv) {
@@ -804,6 +837,25 @@ static int dispatch(int argc, char **argv) {
     if (sub == "sdbgmerge") {    // after a build over N GPUs: <prefix> <N> -> PREFIX.sdbg_info naming the N files (host only)
         if (argc < 4 || atoi(argv[3]) < 1) { fprintf(stderr, "Usage %s <sdbg_prefix> <num_parts>\n", argv[1]); return 1; }
         merge_sdbg_parts(argv[2], atoi(argv[3]));
+        return 0;
+    }
+    if (sub == "hmmdump") {      // host-only check of the HMMER3 text parser + heuristic (tests): the tables `search` uploads, as hex doubles
+        if (argc != 3) { fprintf(stderr, "Usage: megagta hmmdump <file.hmm>\n"); return 1; }
+        ProfileHmm hm;
+        if (!parse_hmm(argv[2], hm)) die("cannot open HMM %s", argv[2]);
+        const size_t M1 = (size_t)hm.M + 1;
+        printf("M %d\nA %d\nalpha", hm.M, hm.A);
+        for (int c = 0; c < 127; ++c) printf(" %d", hm.alpha[c]);
+        printf("\ncompo");
+        for (int j = 0; j < hm.A; ++j) printf(" %a", hm.compo[j]);
+        printf("\n");
+        for (int k = 0; k <= hm.M; ++k) {
+            printf("msc %d", k);
+            for (int j = 0; j < hm.A; ++j) printf(" %a", hm.msc[(size_t)k * hm.A + j]);
+            printf("\ntsc %d", k);
+            for (int t = 0; t < 7; ++t) printf(" %a", hm.tsc[(size_t)t * M1 + k]);
+            printf("\nmaxm %d %a\nh %d %a %a %a\n", k, hm.max_match[k], k, hm.h[k], hm.h[M1 + k], hm.h[2 * M1 + k]);
+        }
         return 0;
     }
     if (sub == "searchplan") {   // <n_seeds>...: the window and cost term `search` would take for batches of that many seeds (host only)

@@ -214,11 +214,35 @@ def contig_file(k): return graph_prefix(k) + ".contigs.fa"
 def log_file(): return opt.out_dir + "log"
 
 
-def write_cp():
-    global cp
+deferred_cp = []      # checkpoints of steps whose files a worker thread is still writing (`buildgraph` in the worker)
+
+
+def flush_deferred_cp():
+    """the worker's background writer has finished (request "sync"): only now does cp.txt say that those graphs are built.  The reference
+    writes a checkpoint after the step's files are complete (megagta.py:380-385,586); a run killed in between re-builds the graph."""
+    global deferred_cp
+    if not deferred_cp:
+        return
+    if worker is not None:
+        ret = worker.request(["sync"])
+        if ret != 0:
+            fail_step("writing the graph files", ret)
     with open(opt.temp_dir + "cp.txt", "a") as f:
-        f.write(f"{cp}\tdone\n")
+        for line in deferred_cp:
+            f.write(line)
+    deferred_cp = []
+
+
+def write_cp(defer=False):
+    global cp
+    line = f"{cp}\tdone\n"
     cp += 1
+    if defer and worker is not None:
+        deferred_cp.append(line)
+        return
+    flush_deferred_cp()
+    with open(opt.temp_dir + "cp.txt", "a") as f:
+        f.write(line)
 
 
 def should_run():
@@ -351,8 +375,11 @@ def build_graph(k, assist):
             cmd += ["--assist_seq", assist]
         if opt.gpus > 1:
             run_multi_gpu_build(cmd, k)
+            write_cp()
         else:
             run_step(cmd, "Building sdbg for k = %d" % k)
+            write_cp(defer=True)      # (the worker replies while a thread still writes PREFIX.sdbg.*: the checkpoint waits for the files)
+        return
     write_cp()
 
 
@@ -367,6 +394,7 @@ def fail_step(what, ret):
 def release_worker_memory():
     """the worker hands its device memory back before other processes use GPU 0; a worker that cannot answer is dropped"""
     global worker
+    flush_deferred_cp()                                  # (a writer failure is the build's failure, not a refusal to release)
     if worker is not None and worker.request(["release"]) != 0:
         logging.debug("the worker did not release its memory: it is stopped, the remaining steps run one process each")
         worker.close()
@@ -492,6 +520,7 @@ def main(argv=None):
                 for gene in opt.gene_info:
                     find_seed(k, gene)
                 search_contigs(k)
+        flush_deferred_cp()
         if worker is not None:
             worker.close()
         logging.info("--- [%s] ALL DONE. Time elapsed: %f seconds ---" % (datetime.now().strftime("%c"), time.time() - t0))

@@ -72,10 +72,22 @@ def write_fasta(path: str, gene: str, contigs, offsets) -> None:
 def window_and_rate(n_seeds: int) -> tuple[int, int]:
     """as `megagta search` (csrc/host/megagta_main.cpp): the ordered-commit window and the cost term by the number of seeds the batch
     holds; MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE override (any integer >= -64 for the rate: < 0 = seeds per expansion)"""
-    w, r = os.environ.get("MEGAGTA_CACHE_WINDOW"), os.environ.get("MEGAGTA_CACHE_COST_RATE")
-    window = int(w) if w not in (None, "", "-2") else 1024 if n_seeds < 32768 else 2048 if n_seeds < 65536 else 4096 if n_seeds < 196608 else 8192
-    rate = int(r) if r not in (None, "") else 0 if window == 1 else (4 if n_seeds < 65536 else 2 if n_seeds < 393216 else 1)     # window 1 = the sequential run: no cost term
+    w, r = _env_int("MEGAGTA_CACHE_WINDOW"), _env_int("MEGAGTA_CACHE_COST_RATE")
+    window = w if w is not None and w >= -1 else 1024 if n_seeds < 32768 else 2048 if n_seeds < 65536 else 4096 if n_seeds < 196608 else 8192
+    rate = r if r is not None else 0 if window == 1 else (4 if n_seeds < 65536 else 2 if n_seeds < 393216 else 1)     # window 1 = the sequential run: no cost term
     return window, rate
+
+
+def _env_int(name: str):
+    """an integer from the environment exactly as `megagta search` reads it (env_int_strict, strtol's syntax): unset or empty = not given,
+    anything that is not an integer is refused -- one environment means one mode for the binary and for the ranks"""
+    import re
+    v = os.environ.get(name)
+    if v is None or v == "":
+        return None
+    if not re.fullmatch(r"[ \t\n\v\f\r]*[+-]?[0-9]+", v):
+        raise SystemExit(f"{name} must be an integer (got '{v}')")
+    return max(-1000000000, min(1000000000, int(v)))
 
 
 def main(argv: list[str]) -> int:

@@ -45,4 +45,6 @@ for B, R in settings:
     _, offs, st = api.astar_search_packed(graph, fw, rv, kmers, states, 20, 0.5, cache_mode=B, cost_rate=R)
     dt = time.time() - t
     print(f"window {B:6d} rate {R:3d}: {dt:6.1f} s  {len(ps) / dt / 1e3:6.1f} seeds/ms  {st['n_expansions'] / 1e6:8.0f} M expansions  {st['n_expansions'] / max(1e-9, st['ms_total'] * 1e3):6.1f} M/s  "
-          f"restarted {st['n_retries']} grown {st['n_grown']} pool {st['pool_used'] / 1e9:.1f} GB  contig bytes {int(offs[-1])}", flush=True)
+          f"restarted {st['n_retries']} resumed {st['n_resumes']} grown {st['n_grown']} pool {st['pool_used'] / 1e9:.1f} of {st['pool_bytes'] / 1e9:.1f} GB "
+          f"reserve {st['reserve_used'] / 1e9:.2f} of {st['reserve_bytes'] / 1e9:.1f} GB  largest search {st['max_search_nodes']} nodes / "
+          f"{st['max_search_expansions']} expansions  contig bytes {int(offs[-1])}", flush=True)

@@ -117,3 +117,32 @@ def write_buildlib_inputs(d: str) -> str:
     lib = f"{d}/reads.lib"
     open(lib, "w").write(f"a.fa\nse {d}/a.fa\np1.fq.gz,p2.fq.gz\npe {d}/p1.fq.gz {d}/p2.fq.gz\ni.fq\ninterleaved {d}/i.fq\n")
     return lib
+
+
+# ---- tests/golden/bigm: models too long for the LDS of a CU.  The inputs are regenerated from their seeds (the committed goldens hold the
+# reference's answers and an md5 of every input).
+BIGM_CASES = {"m600": dict(M=600, n_reads=2400, seed=61, n_seeds=40), "m1200": dict(M=1200, n_reads=3000, seed=62, n_seeds=32)}
+
+
+def bigm_inputs(case: str, outdir: str):
+    """the seeded inputs of one case: reads (uint8 codes) and gene models written under outdir/genes -> (metagenome, gene dir)"""
+    from megagta_amd import synth
+    c = BIGM_CASES[case]
+    mg = synth.make_metagenome(c["n_reads"], 150, ((case, c["M"]),), seed=c["seed"], reads_per_genome=600, genome_len=6000)
+    synth.write_gene_models(mg.genes, os.path.join(outdir, "genes"))
+    return mg, os.path.join(outdir, "genes", case)
+
+
+def bigm_case(golden_dir: str, case: str, outdir: str):
+    """-> (packed reads, start_idx, gene dir, cold goldens, warm goldens); checks the regenerated inputs against the stored md5s"""
+    import hashlib
+    from megagta_amd import synth
+    meta = json.load(open(os.path.join(golden_dir, "bigm", "cases.json")))[case]
+    mg, gdir = bigm_inputs(case, outdir)
+    for tag, name in (("for", "for_enone.hmm"), ("rev", "rev_enone.hmm")):
+        assert hashlib.md5(open(os.path.join(gdir, name), "rb").read()).hexdigest() == meta["md5"][tag], f"{case}: regenerated {name} differs from the generator's"
+    synth.write_lib_bin(mg.reads, os.path.join(outdir, "reads.lib"))
+    assert hashlib.md5(open(os.path.join(outdir, "reads.lib.bin"), "rb").read()).hexdigest() == meta["md5"]["reads"], f"{case}: regenerated reads differ"
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    gold = {m: parse_probe_astar(gz_lines(os.path.join(golden_dir, "bigm", f"{case}_astar_{m}.txt.gz"))) for m in ("cold", "warm")}
+    return packed, start, gdir, gold["cold"], gold["warm"]

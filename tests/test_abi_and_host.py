@@ -235,7 +235,9 @@ def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "megagta_amd", "bin", "megagta")
     ns = [0, 1, 7000, 32767, 32768, 65535, 65536, 196607, 196608, 393215, 393216, 1_000_000, 9_300_000]
     for env in ({}, {"MEGAGTA_CACHE_WINDOW": "1"}, {"MEGAGTA_CACHE_WINDOW": "-1"}, {"MEGAGTA_CACHE_WINDOW": "64", "MEGAGTA_CACHE_COST_RATE": "-2"},
-                {"MEGAGTA_CACHE_COST_RATE": "0"}, {"MEGAGTA_CACHE_WINDOW": "1", "MEGAGTA_CACHE_COST_RATE": "3"}):
+                {"MEGAGTA_CACHE_COST_RATE": "0"}, {"MEGAGTA_CACHE_WINDOW": "1", "MEGAGTA_CACHE_COST_RATE": "3"},
+                {"MEGAGTA_CACHE_WINDOW": "", "MEGAGTA_CACHE_COST_RATE": ""}, {"MEGAGTA_CACHE_WINDOW": "-3"}, {"MEGAGTA_CACHE_WINDOW": "-2", "MEGAGTA_CACHE_COST_RATE": "-1"},
+                {"MEGAGTA_CACHE_WINDOW": "0"}, {"MEGAGTA_CACHE_WINDOW": " +16"}):     # (advisor r3: '' and values below -1 meant different modes on the two sides)
         for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
@@ -243,9 +245,67 @@ def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
         out = subprocess.run([exe, "searchplan"] + [str(n) for n in ns], capture_output=True, text=True, check=True, env=dict(os.environ)).stdout.split("\n")
         got = [tuple(int(x) for x in line.split()[1:]) for line in out if line.strip()]
         assert got == [search_dist.window_and_rate(n) for n in ns], env
+    for bad in ("x", "8k", "4 ", "1.5"):                                   # not an integer: refused on both sides, never read as 0
+        monkeypatch.setenv("MEGAGTA_CACHE_WINDOW", bad)
+        r = subprocess.run([exe, "searchplan", "1000"], capture_output=True, text=True, env=dict(os.environ))
+        assert r.returncode != 0 and "MEGAGTA_CACHE_WINDOW must be an integer" in r.stderr, bad
+        with pytest.raises(SystemExit, match="MEGAGTA_CACHE_WINDOW must be an integer"):
+            search_dist.window_and_rate(1000)
     for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
         monkeypatch.delenv(key, raising=False)
     assert search_dist.window_and_rate(400_000) == (8192, 1) and search_dist.window_and_rate(100_000) == (4096, 2)
+
+
+def test_graph_checkpoint_waits_for_the_worker_to_finish_the_files(tmp_path, monkeypatch):
+    """advisor r3: in the worker `buildgraph` replies while a thread still writes PREFIX.sdbg.*; the checkpoint that says "graph built" is
+    written only after the worker's "sync" request has confirmed the files (the reference writes cp.txt after the step's files are
+    complete: megagta.py:380-385,586), and a writer failure is the build's failure: no checkpoint, non-zero exit"""
+    import importlib
+    from megagta_amd import megagta as drv
+
+    class FakeWorker:
+        def __init__(self, sync_rc):
+            self.sync_rc, self.requests = sync_rc, []
+
+        def request(self, fields):
+            self.requests.append(fields[0])
+            return self.sync_rc if fields[0] == "sync" else 0
+
+        def close(self):
+            self.requests.append("close")
+
+    for sync_rc in (0, 1):
+        drv = importlib.reload(drv)
+        out = tmp_path / f"run{sync_rc}"
+        drv.opt.out_dir = str(out) + "/"
+        drv.opt.temp_dir = drv.opt.out_dir + "tmp/"
+        os.makedirs(drv.opt.temp_dir)
+        drv.opt.k_list, drv.opt.lib = [29, 44], drv.opt.temp_dir + "reads.lib"
+        w = FakeWorker(sync_rc)
+        drv.worker = w
+        monkeypatch.setattr(drv, "run_step", lambda cmd, what, stdin_path=None, stdout_path=None: w.requests.append(cmd[1]))
+        cp_path = drv.opt.temp_dir + "cp.txt"
+        drv.build_graph(29, "")
+        assert not os.path.exists(cp_path) or open(cp_path).read() == ""          # the files may still be in flight: nothing is promised yet
+        if sync_rc == 0:
+            drv.assemble(29)
+            assert w.requests == ["buildgraph", "denovo", "sync"]
+            assert open(cp_path).read() == "0\tdone\n1\tdone\n"
+        else:
+            with pytest.raises(SystemExit) as e:
+                drv.assemble(29)
+            assert e.value.code == 1 and "sync" in w.requests
+            assert not os.path.exists(cp_path) or open(cp_path).read() == ""      # --continue re-builds the graph
+    # one process per step (no worker): the step returns when its files are complete, the checkpoint follows at once
+    drv = importlib.reload(drv)
+    out = tmp_path / "run_steps"
+    drv.opt.out_dir = str(out) + "/"
+    drv.opt.temp_dir = drv.opt.out_dir + "tmp/"
+    os.makedirs(drv.opt.temp_dir)
+    drv.opt.k_list, drv.opt.lib = [29, 44], drv.opt.temp_dir + "reads.lib"
+    monkeypatch.setattr(drv, "run_step", lambda *a, **k: None)
+    drv.build_graph(29, "")
+    assert open(drv.opt.temp_dir + "cp.txt").read() == "0\tdone\n"
 
 
 def test_bucket_range_of_the_count_scan_without_a_division():

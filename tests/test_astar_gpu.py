@@ -67,6 +67,7 @@ def test_cold_cache_vs_reference(toy, fname, prune, search_mode):
     g, fw, rv, d = toy
     gold = H.parse_probe_astar(H.gz_lines(os.path.join(d, fname)))
     res, st = api.astar_search(g, fw, rv, [r["kmer"] for r in gold], [r["start_state"] for r in gold], prune, 0.5)
+    assert st["hmm_in_lds"] == 1
     if search_mode[1]:
         assert st["n_grown"] > 0 and st["n_rehash"] > 0 and st["n_retries"] == 0
     for r, ref in zip(res, gold):
@@ -75,6 +76,27 @@ def test_cold_cache_vs_reference(toy, fname, prune, search_mode):
         assert r.contig(ref["kmer"]) == ref["contig"]
     assert st["n_expansions"] == sum(r["R"]["closed"] + r["L"]["closed"] for r in gold) + \
            sum(int(x.right_side["n_expanded"] > x.right_side["n_closed"]) + int(x.left_side["n_expanded"] > x.left_side["n_closed"]) for x in res)
+
+
+@pytest.mark.parametrize("case", ["m600", "m1200"])
+def test_models_beyond_the_lds_vs_reference(ctx, golden_dir, tmp_path, case, search_mode):
+    """astar_kernel<G, false>: a 600- / 1200-column model's tables ((M + 1)(A + 11) * 8 B = 149 / 298 KB) do not fit a CU's 160 KB of LDS
+    beside the heap tops, the kernel reads them from device memory (the reference has no bound on M: profile_hmm.h:11-100).  Goldens from
+    the reference's probe (tests/golden/bigm): cold per seed in every lane mode, and the sequential shared-cache run (window 1 ==
+    `search ... 1`)"""
+    from megagta_amd import api
+    packed, start, gdir, cold, warm = H.bigm_case(golden_dir, case, str(tmp_path))
+    g = api.Graph(ctx, ctx.build_sdbg(ctx.upload_reads(packed, start), 44))
+    fw = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(gdir, "for_enone.hmm")))
+    rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(os.path.join(gdir, "rev_enone.hmm")))
+    for gold, mode in ((cold, 0), (warm, 1)):
+        res, st = api.astar_search(g, fw, rv, [r["kmer"] for r in gold], [r["start_state"] for r in gold], 20, 0.5, cache_mode=mode)
+        assert st["hmm_in_lds"] == 0                                  # the variant under test is the one that ran
+        for r, ref in zip(res, gold):
+            _check_side(r.right_side, ref["R"])
+            _check_side(r.left_side, ref["L"])
+            assert r.contig(ref["kmer"]) == ref["contig"]
+    assert st["max_search_expansions"] > 10000                        # (these searches are long ones: ~10^5 expansions per seed)
 
 
 def test_vs_oracle_bigger_graph(ctx, oracle):
@@ -235,8 +257,8 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
         g = api.Graph(ctx, stream)
         fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
         kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
-        seen_yield, sizes = False, []
-        for (window, rate), pools in (((8, 0), (2048, 4096, 8192, 16384)), ((64, 4), (8192, 16384))):
+        seen_yield, seen_resume, seen_reserve, sizes = False, False, False, []
+        for (window, rate), pools in (((8, 0), (512, 1024, 2048, 4096, 8192, 16384)), ((64, 4), (1024, 8192, 16384))):
             want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
             assert st0["n_retries"] == 0
             try:
@@ -248,14 +270,17 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
                         assert "do not fit" in str(e)
                         sizes.append((window, kb, "error"))
                         continue
-                    sizes.append((window, kb, st["n_retries"]))
+                    sizes.append((window, kb, st["n_retries"], st["n_resumes"], st["reserve_used"]))
                     seen_yield |= st["n_retries"] > 0
+                    seen_resume |= st["n_resumes"] > 0        # the lowest search outgrew its reserve: the batch went on behind its commit frontier
+                    seen_reserve |= st["reserve_used"] > 0    # the lowest search was served by the reserve
                     assert st["n_expansions"] == st0["n_expansions"], sizes
                     for a, b, km in zip(got, want, kmers):
                         assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side, sizes
             finally:
                 ctx.set_search_arena(0, 0)
-        assert seen_yield, sizes
+        print(sizes)
+        assert seen_yield and seen_resume and seen_reserve, sizes
 
 
 @pytest.mark.parametrize("M,k1,prune,pen,seed", [(60, 30, 20, 0.5, 1), (90, 36, 0, 0.5, 2), (150, 45, 20, 0.0, 3), (75, 45, 5, 2.0, 4),

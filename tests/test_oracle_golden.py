@@ -175,6 +175,22 @@ def test_astar(oracle, golden_dir, mode, fname, prune):
         assert fasta[1::2] == contigs
 
 
+@pytest.mark.parametrize("case,mode", [("m600", "cold"), ("m600", "warm"), ("m1200", "warm")])
+def test_astar_models_beyond_the_lds(oracle, golden_dir, tmp_path, case, mode):
+    """600- and 1200-column models (tests/golden/bigm, from the reference's probe): the oracle's searcher on the models the device reads
+    from global memory instead of LDS -- per seed, both directions, scores bit-equal"""
+    packed, start, gdir, cold, warm = H.bigm_case(golden_dir, case, str(tmp_path))
+    g = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=4))
+    S = oracle.Searcher(g, oracle.Hmm(os.path.join(gdir, "for_enone.hmm")), oracle.Hmm(os.path.join(gdir, "rev_enone.hmm")), 20, 0.5)
+    gold = cold if mode == "cold" else warm
+    assert len(gold) >= 30
+    for rec in gold:
+        contig, R, L = S.search(rec["kmer"], rec["start_state"], cold=(mode == "cold"))
+        _side_matches(R, rec["R"])
+        _side_matches(L, rec["L"])
+        assert contig == rec["contig"]
+
+
 @pytest.mark.parametrize("case,k,threads", [("toy", 44, 4), ("toy", 29, 2), ("ragged", 47, 3), ("ragged", 21, 8)])
 def test_oracle_sdbg_reader_pinned_by_fresh_reference_files(oracle, golden_dir, tmp_path, case, k, threads):
     """the golden stream MD5s are computed by the oracle's own `.sdbg` reader: pin that reader directly.  A raw-file MD5 cannot serve
