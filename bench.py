@@ -41,6 +41,45 @@ REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
 DRIVER = os.path.join(ROOT, "megagta_amd", "megagta.py")
 
 
+def host_cores() -> dict:
+    """logical CPUs this process may use and the box's physical cores ((physical id, core id) pairs of /proc/cpuinfo)"""
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return {"logical_cpus": logical, "usable_cpus": usable, "physical_cores": len(phys) or None}
+
+
+def source_signature(*names: str) -> str:
+    """md5 over the kernel sources a profile was taken with: a PMC summary under profiles/ is only quoted in the bench line while the
+    kernels it measured are the ones that ran (a changed kernel makes the file stale, and the line says so instead of quoting it)"""
+    import hashlib
+    h = hashlib.md5()
+    for n in names:
+        with open(os.path.join(ROOT, "megagta_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+BUILD_SOURCES = ("sdbg_build.hip", "sdbg_solid.hpp", "scan.hpp", "device_utils.hpp")
+ASTAR_SOURCES = ("astar_kernel.hpp", "graph.hpp", "device_utils.hpp")
+
+
 def b_build(k: int, L: int, edges_per_kmer: float) -> float:
     """algorithmic bytes per (k+1)-mer occurrence = 2 items x (write + read) x 4W + read the
     packed base once + 2 B per emitted edge."""
@@ -65,7 +104,46 @@ def parity_vs_reference_graph(ctx, sample: np.ndarray, k: int, ref_prefix: str) 
             "note": "edge stream (bucket sizes, records, large multiplicities, tip labels) of the CPU-baseline sample: device vs the reference binary's .sdbg files"}
 
 
-def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int, ctx=None) -> dict:
+def search_cpu_baseline(tmp: str, graph_prefix: str, lib_bin: str, genes, k: int, cores: int, n_seeds: int = 8000) -> dict:
+    """The search half of the metric on the host: the reference `search` (search.cpp:71-197, OMP over the seeds) on the graph it has just
+    built of the CPU-baseline sample, seeds of the first gene from its own `findstart` (a contiguous block of the sorted list, as the
+    product-mode leg takes them), best of 16 / 32 / 64 threads; seconds = its own "Done <gene>: time" line (the seed loop, search.cpp:184-194).
+    Expansions = closed-set insertions + one start expansion per search, counted by the reference's own classes run
+    sequentially over the same seeds (oracle/_ref/probe astar ... warm: the multi-thread run shares its caches by timing, so its own
+    count differs from run to run by a little; it prints none)."""
+    import re
+    from megagta_amd import synth
+    probe = os.path.join(ROOT, "oracle", "_ref", "probe")
+    gl = synth.write_gene_models(genes[:1], os.path.join(tmp, "models"))
+    name, fwd, rev, faa = open(gl).readline().split()
+    lines = sorted(subprocess.run([REF, "findstart", faa, lib_bin, str(k + 1), str(min(cores, 16))], check=True, capture_output=True).stdout.decode().splitlines())
+    lo = max(0, (len(lines) - n_seeds) // 2)
+    lines = lines[lo:lo + n_seeds]
+    if not lines:
+        return {"error": "the reference's findstart found no seed in the sample"}
+    sp = os.path.join(tmp, "sb")
+    open(f"{sp}_{name}_starting_kmers.txt", "w").write("\n".join(lines) + "\n")
+    secs = {}
+    for threads in sorted({max(1, min(cores, 16)), max(1, min(cores, 32)), max(1, min(cores, 64))}):
+        t = time.time()
+        r = subprocess.run([REF, "search", graph_prefix, gl, sp, os.path.join(tmp, f"so{threads}"), "20", "0.5", str(threads)], check=True, capture_output=True)
+        wall = time.time() - t
+        m = re.search(r"Done %s: time ([0-9.]+)" % re.escape(name), r.stderr.decode(errors="replace"))
+        secs[threads] = float(m.group(1)) if m else wall
+    best_t = min(secs, key=secs.get)
+    t = time.time()
+    pr = subprocess.run([probe, "astar", graph_prefix, fwd, rev, f"{sp}_{name}_starting_kmers.txt", "20", "0.5", "warm"], check=True, capture_output=True).stdout.decode()
+    t_probe = time.time() - t
+    closed = sum(int(x) for x in re.findall(r" closed (\d+) ", pr))
+    n_exp = closed + 2 * len(lines)
+    return {"value": n_exp / secs[best_t], "unit": "HMM-scored node expansions/s", "cores": best_t, "kind": "reference",
+            "seeds": len(lines), "gene": name, "expansions": n_exp, "seconds": secs[best_t], "seconds_by_threads": secs,
+            "one_thread_sequential": {"seconds": t_probe, "value": n_exp / t_probe, "note": "oracle/_ref/probe astar warm: the reference's classes, one thread, incl. loading the graph"},
+            "sample": f"{len(lines)} `findstart` seeds of {name} (a contiguous block of the sorted list) on the reference's own graph of the first reads (graph k={k}); "
+                      f"`megagta search ... {best_t}`, seed-loop seconds from its own log line; expansions counted by a sequential run of the same classes"}
+
+
+def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int, ctx=None, genes=None) -> dict:
     from megagta_amd import synth
     n = min(sample_reads, reads.shape[0])
     sample = reads[:n]
@@ -89,11 +167,17 @@ def cpu_baseline(reads: np.ndarray, k: int, sample_reads: int, ctx=None) -> dict
             out = {"value": n_kmers / dt / 1e9, "unit": "Gk-mer/s", "cores": threads, "kind": "reference",
                    "sample": f"first {n} reads x {reads.shape[1]} bp of the same set, graph k={k}, `megagta buildgraph` "
                              f"(reads.lib.bin -> .sdbg files, {dt:.2f} s wall incl. file I/O; best of 16 / 64 threads)"}
+            out["host"] = host_cores()
             if ctx is not None:
                 try:
                     out["_parity"] = parity_vs_reference_graph(ctx, sample, k, os.path.join(tmp, f"g{threads}"))
                 except Exception as e:                                   # the baseline number must not die with the check
                     out["_parity"] = {"error": str(e)[-400:]}
+            if genes:
+                try:
+                    out["_search"] = search_cpu_baseline(tmp, os.path.join(tmp, f"g{threads}"), os.path.join(tmp, "reads.lib.bin"), genes, k, cores)
+                except Exception as e:
+                    out["_search"] = {"error": str(e)[-400:]}
             return out
         from oracle import oracle as O
         packed, start = synth.pack_reads_for_build(sample)
@@ -124,7 +208,7 @@ def write_fasta_fast(reads: np.ndarray, path: str) -> None:
     rec.tofile(path)
 
 
-def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,36,45") -> dict:
+def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,36,45", n_large: int = 0, large_deadline: float = 0.0) -> dict:
     """reads.fa -> contigs/<gene>/{nucl,prot}_merged.fasta through megagta.py, wall seconds.  Two read sets of their own (the same
     model as the build leg's, 15x coverage each: a prefix of the 100 M reads would be a 0.3x sample of 50 000 genomes with next to
     nothing to assemble): `n_ours` reads for our driver run, and `n_ref` reads on which the reference binary runs behind the same driver
@@ -191,6 +275,15 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             out["speedup_same_sample"] = dtr / dt
             if "ours_unordered_cache" in out:
                 out["speedup_same_sample_unordered_cache"] = dtr / out["ours_unordered_cache"]["seconds"]
+        if n_large > 0:
+            # a point beyond the same-sample size, ours only (the reference needs ~70 s per million reads): skipped when the run is late
+            if time.time() > large_deadline:
+                out["ours_large"] = {"reads": n_large, "skipped": "the bench run was %.0f s old when this leg was due: not started" % (time.time() - _T0)}
+            else:
+                dtl, ncl = run(n_large, "ours_large", ["-t", str(min(cores, 16))])
+                note(f"e2e ours: {n_large} reads in {dtl:.1f} s")
+                out["ours_large"] = {"reads": n_large, "seconds": dtl, "reads_per_s": n_large / dtl, "contigs": ncl,
+                                     "note": "megagta.py -k %s on %d reads, default mode, ours only (the reference was not run at this size)" % (klist, n_large)}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -279,6 +372,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--seeds", type=int, default=60000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
+    ap.add_argument("--e2e-large-reads", type=int, default=20_000_000, help="a larger reads->contigs run, ours only (0 = skip; skipped anyway when the bench run is already late)")
     ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="small set on which the reference's thread count is chosen before it runs on the e2e set (0 = no reference run)")
     ap.add_argument("--product-seeds", type=int, default=60_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
@@ -402,6 +496,7 @@ def main():
 
         def sstep(genes=None):
             tot = {"n_expansions": 0, "ms_kernel": 0.0, "n_retries": 0, "n_grown": 0, "pool_used": 0}
+            mine_all = []
             for gi in (range(len(mg.genes)) if genes is None else genes):
                 mine = share[gi]
                 kmers, states = [seeds[gi][i][0] for i in mine], [seeds[gi][i][1] - 1 for i in mine]
@@ -412,9 +507,11 @@ def main():
                         tot[key] += st[key]
                     tot["pool_used"] = max(tot["pool_used"], st["pool_used"])
                 if world > 1:
-                    mdist.all_gather_packed_contigs(len(seeds[gi]), mine, cont, offs)
+                    mine_all.append((len(seeds[gi]), mine, cont, offs))
                 elif len(mine):
                     last_contigs[gi] = (cont, offs)
+            if world > 1:                                   # the path's one exchange: ONE all-gather of the contigs of every gene, at the end
+                mdist.all_gather_all_genes([m[0] for m in mine_all], [m[1] for m in mine_all], [m[2] for m in mine_all], [m[3] for m in mine_all])
             return tot
 
         # warm-up: the first gene alone at 100 M reads (it obtains the pool at its full size and loads the kernels; a whole step takes
@@ -453,16 +550,22 @@ def main():
                                   "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
             # what the kernel really moves: L2 misses per expansion from the PMC pass of the round (TCC_MISS_sum over the A* dispatches /
             # expansions; PMC cannot be collected inline), one 128-byte line each, against the same measured ceiling
-            cp = os.path.join(ROOT, "profiles", "r03", "astar_counters_100M.json")
+            cp = os.path.join(ROOT, "profiles", "astar_counters_latest.json")
             if os.path.exists(cp):
                 try:
                     cj = json.load(open(cp))
-                    n_exp = 306951464 + 921574632                        # expansions of the profiled command (profiles/r03/astar_counters_100M.md)
-                    mpe = cj["astar_tcc"]["counters_sum_over_astar_dispatches"]["TCC_MISS_sum"] / n_exp
-                    search["roofline"]["traffic"] = {"l2_misses_per_expansion": mpe, "line_bytes": 128, "achieved": rate * mpe * 128 / 1e9, "unit": "GB/s",
-                                                     "frac_of_random_line_ceiling": rate * mpe * 128 / 1e9 / ceiling,
-                                                     "note": "TCC_MISS_sum per expansion on the 100 M-read graph (profiles/r03/astar_counters_100M.md) x this run's rate: "
-                                                             "priced on the lines it actually misses, the kernel runs at about the device's random-line rate"}
+                    lanes = 8 if max(len(x) for x in seeds) >= 32768 else 16
+                    same = cj.get("reads") == args.reads and cj.get("graph_k") == k and cj.get("lanes_per_search") == lanes and \
+                        cj.get("source_signature") == source_signature(*ASTAR_SOURCES)
+                    if same:
+                        mpe = cj["TCC_MISS_sum"] / cj["expansions"]
+                        search["roofline"]["traffic"] = {"l2_misses_per_expansion": mpe, "line_bytes": 128, "achieved": rate * mpe * 128 / 1e9, "unit": "GB/s",
+                                                         "frac_of_random_line_ceiling": rate * mpe * 128 / 1e9 / ceiling,
+                                                         "note": "TCC_MISS_sum / expansions of the PMC pass `%s` (collected %s at commit %s) x this run's rate: priced on "
+                                                                 "the lines it actually misses" % (cj.get("command"), cj.get("collected"), cj.get("commit"))}
+                    else:
+                        search["roofline"]["traffic"] = None
+                        search["roofline"]["traffic_source"] = "profiles/astar_counters_latest.json is of another workload, lane group or kernel source: not quoted"
                 except Exception:
                     pass
         if rank == 0 and world == 1 and last_contigs:
@@ -519,12 +622,19 @@ def main():
         local_total = sum(x["ms_local_sort"] for x in stats)
         dom_name, dom_ms = ("local_sort_kernel", ms_local) if local_total >= scatter_total else ("radix_scatter_kernel", ms_scatter)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch of the dominant kernel from the PMC passes (they cannot be collected inline: separate rocprofv3 runs,
+        # scripts/profile_r04.sh) -- quoted only when that profile is of THIS workload and of THESE kernel sources, else null with the reason
+        traffic, traffic_note = None, "no PMC summary (profiles/traffic_latest.json)"
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             tj = json.load(open(tp))
-            if tj.get("reads") == args.reads:
+            if tj.get("reads") != args.reads or tj.get("graph_k", k) != k:
+                traffic_note = f"profiles/traffic_latest.json is of another workload ({tj.get('reads')} reads)"
+            elif tj.get("source_signature") != source_signature(*BUILD_SOURCES):
+                traffic_note = "profiles/traffic_latest.json is STALE: the build kernels changed since it was collected (%s)" % tj.get("collected", "no date")
+            else:
                 traffic = tj.get(dom_name + "_bytes_per_launch")
+                traffic_note = "2 x FETCH_SIZE + WRITE_SIZE per launch, %s, collected %s at commit %s" % (tj.get("_source", ""), tj.get("collected"), tj.get("commit"))
         edges_per_kmer = s["n_edges"] / max(1, n_kmers) * world
         gene_txt = " + ".join(g[0] for g in gene_specs)
         out = {
@@ -537,7 +647,7 @@ def main():
                        "reads": args.reads, "read_len": L, "graph_k": k, "n_kmers": n_kmers, "n_items": s["n_items"],
                        "n_edges_rank0": s["n_edges"], "passes": s["n_passes"]},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": dom_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": dom_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "other_kernels": {"radix_scatter_kernel": {"avg_launch_ms": ms_scatter, "launches_per_step": launches / args.steps,
                                                                     "achieved": alg_bytes / (ms_scatter * 1e-3) / 1e9 if ms_scatter > 0 else 0.0},
@@ -551,6 +661,7 @@ def main():
                             "pcie_inclusive_note": "inputs resident; uploading the packed reads (0.25 B/base + 8 B/read at ~55 GB/s) and returning "
                                                    "2 B/edge would add ~%.0f ms per build" % ((args.reads * (L * 0.25 + 8) + s["n_edges"] * 2) / 55e9 * 1e3)},
             "input_generation_s": t_gen,
+            "host": host_cores(),
         }
         if search is not None:
             out["search"] = search
@@ -570,16 +681,24 @@ def main():
                     # allocations of the leg's child processes waited 5 s for that (profiles/r02/vmm_probe.log: 20-90 ms/GB)
                     time.sleep(8 if args.reads > 20_000_000 else 1)
                     note("e2e leg ...")
-                    out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}")
+                    out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}", n_large=args.e2e_large_reads,
+                                         large_deadline=_T0 + 400.0)     # (the leg takes ~100 s and the CPU baselines ~45 s: the whole run stays under ten minutes)
                     note("e2e leg done")
                 except Exception as e:                                   # the bench line must not die with a leg
                     out["e2e"] = {"error": str(e)[-600:]}
             if not args.no_cpu_baseline:
                 note("cpu baseline ...")
-                cb = cpu_baseline(mg.sample_reads, k, args.cpu_sample, ctx)
+                cb = cpu_baseline(mg.sample_reads, k, args.cpu_sample, ctx, mg.genes)
                 if "_parity" in cb:
                     out["parity_1M"] = cb.pop("_parity")
                     note(f"parity vs the reference's graph of the sample: {out['parity_1M']}")
+                if "_search" in cb:
+                    sb = cb.pop("_search")
+                    if "search" in out:
+                        out["search"]["cpu_baseline"] = sb
+                    else:
+                        out["search_cpu_baseline"] = sb
+                    note(f"search cpu baseline: {sb}")
                 out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -472,11 +472,15 @@ constexpr unsigned long long kKnownWide = 1ull << 62;  // ... its region has mor
 constexpr unsigned long long kPosMask = ~(kKnownBig | kKnownWide);
 constexpr int kNarrowLanes = 8, kNarrowMax = 512;
 
-// the tail of a candidate whose region does not fit (or is known not to): nobody above may commit this round (what this one can reach is
-// not known), and it stamps at least what its search reads today, so that it can still commit itself once nothing below reaches that
+// The tail of a candidate whose region does not fit (or is known not to): what it can reach in a later graph is not known, so it stamps
+// what its search reads TODAY and is marked (unknown[i]).  If nothing below it touches that read set (its check passes), its search at
+// its turn is today's search -- same reads, same pop, all inside the stamped set -- and it commits like any other candidate without
+// holding anybody back; only when its check FAILS (some lower pending candidate may change what it reads, so what it will read and
+// write at its turn is open) does it become the round's barrier: nobody above it commits.  Round 3 raised the barrier at every such
+// candidate, whatever its check said: every region that did not fit cost a round (100 M reads, k = 29: thousands of rounds).
 __device__ void bubble_reach_failed(const GraphDev &g, const int64_t *cand, uint32_t i, int max_len, int64_t *scratch, size_t per, const StampTab &owner,
-                                    unsigned long long key, uint32_t *barrier) {
-    atomicMin(barrier, i);
+                                    unsigned long long key, uint32_t *barrier, uint32_t *unknown) {
+    unknown[i] = 1u;
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkStamp s{owner, key, true};
     bubble_search(g, cand[i], max_len, scratch + (size_t)i * per, mult, nb, len, s);
@@ -489,7 +493,7 @@ __device__ void bubble_reach_failed(const GraphDev &g, const int64_t *cand, uint
 // walk below (list), now and in later rounds (kKnownWide); what this walk stamped of it is a subset of what that one stamps.
 __global__ __launch_bounds__(64) void bubble_reach_narrow_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, uint32_t n, int max_len, int64_t *scratch, size_t per,
                                                                  StampTab owner, unsigned long long round, int reach_max, int narrow_max, uint32_t *barrier,
-                                                                 uint32_t *wide_list, uint32_t *wide_count) {
+                                                                 uint32_t *wide_list, uint32_t *wide_count, uint32_t *unknown) {
     constexpr int G = kNarrowLanes, NG = 64 / G;
     __shared__ int s_cnt[NG][4];                                       // per candidate: [0] edges of the next level, [1] edges seen, [2] stop, [3] the region is over the limit
     const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
@@ -568,14 +572,14 @@ __global__ __launch_bounds__(64) void bubble_reach_narrow_kernel(GraphDev g, con
         return;
     }
     if (!known_big && s_cnt[grp][3]) pos[i] = pw | kKnownBig;          // (only with reach_max <= narrow_max: the region is too large for any walk)
-    bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier);
+    bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier, unknown);
 }
 // the listed candidates (regions of more than kNarrowMax edges), one workgroup of four waves each: the lanes take the edges of a level
 // side by side (a region of thousands of edges in a repeat would otherwise keep one lane busy for milliseconds while the round waits)
 constexpr int kWideThreads = 256;
 __global__ __launch_bounds__(kWideThreads) void bubble_reach_kernel(GraphDev g, const int64_t *cand, uint64_t *pos, int max_len, int64_t *scratch, size_t per,
                                                           StampTab owner, unsigned long long round, int reach_max, uint32_t *barrier, const uint32_t *wide_list,
-                                                          const uint32_t *wide_count) {
+                                                          const uint32_t *wide_count, uint32_t *unknown) {
     __shared__ int s_cnt[4];
     const uint32_t n_wide = *wide_count;
     for (uint32_t b = blockIdx.x; b < n_wide; b += gridDim.x) {
@@ -585,24 +589,29 @@ __global__ __launch_bounds__(kWideThreads) void bubble_reach_kernel(GraphDev g, 
         if (bubble_reach_stamp(g, cand[i], max_len, scratch + (size_t)i * per, owner, key, round, reach_max, s_cnt, 1ull << 63)) continue;
         if (threadIdx.x != 0) continue;
         if (s_cnt[3]) pos[i] |= kKnownBig;
-        bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier);
+        bubble_reach_failed(g, cand, i, max_len, scratch, per, owner, key, barrier, unknown);
     }
 }
+// (the search's results: behind the reach walk's hash table and frontiers -- the packed multiplicities can have bits 40 and above set,
+// where the table keeps its round tag, so inside the table a later round could take them for live entries: advisor r3)
+constexpr size_t kResOffset = (size_t)kReachHash + 2 * kReachFrontier;
 __global__ __launch_bounds__(64) void bubble_check_kernel(GraphDev g, const int64_t *cand, uint32_t n, int max_len, int64_t *scratch, size_t per,
-                                                          StampTab owner, unsigned long long round, uint32_t *ok, const uint32_t *barrier) {
+                                                          StampTab owner, unsigned long long round, uint32_t *ok, uint32_t *barrier, const uint32_t *unknown) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    if (i > *barrier) { ok[i] = 0; return; }                            // held back this round whatever its stamps say: no search
+    if (i > __hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok[i] = 0; return; }   // (already held back, whatever its stamps say: no search.  Only a
+                                                                        // short cut -- the barrier is final when this kernel has ended, the commit reads it then)
     int mult[kMaxBranches], nb = 0, len = 0;
     SinkCheck s{owner, (round << 32) | (0xFFFFFFFFull - i), true};
     int64_t *br = scratch + (size_t)i * per;
     const bool found = bubble_search(g, cand[i], max_len, br, mult, nb, len, s);
     ok[i] = s.ok ? 1u : 0u;
+    if (!s.ok && unknown[i]) atomicMin(barrier, i);                     // what this one will read and write at its turn is open: nobody above it commits
     // what the search found stays behind the branches for the commit: a candidate that passed read only edges nobody else of this round
     // writes (the committing candidates' read and write sets are disjoint by the stamp rule), so the search it would run again there,
     // after other candidates' pops, finds exactly this
     if (s.ok) {
-        int64_t *res = br + (size_t)kMaxBranches * max_len;
+        int64_t *res = br + kResOffset;
         res[0] = (int64_t)(found ? 1 : 0) | ((int64_t)nb << 8) | ((int64_t)len << 16);
         for (int b = 0; b < kMaxBranches; b += 2) res[1 + b / 2] = (int64_t)(uint32_t)mult[b] | ((int64_t)(uint32_t)mult[b + 1] << 32);
     }
@@ -617,7 +626,7 @@ __global__ __launch_bounds__(64) void bubble_commit_kernel(Dn d, const int64_t *
     if (!ok[i] || i > *barrier) { keep[i] = 1; return; }
     int mult[kMaxBranches];
     int64_t *br = scratch + (size_t)i * per;
-    const int64_t *res = br + (size_t)kMaxBranches * max_len;                 // left by the check kernel (see there)
+    const int64_t *res = br + kResOffset;                                       // left by the check kernel (see there)
     const int nb = (int)((res[0] >> 8) & 255), len = (int)(res[0] >> 16);
     for (int b = 0; b < kMaxBranches; b += 2) { mult[b] = (int)(uint32_t)res[1 + b / 2]; mult[b + 1] = (int)(uint32_t)(res[1 + b / 2] >> 32); }
     uint32_t st = 0;
@@ -882,7 +891,7 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
 }
 
 struct BubbleWork {
-    DevBuf scratch, stamp_key, stamp_val, marked, status, win[2], pos[2], ok, keep, base, tmp, small;
+    DevBuf scratch, stamp_key, stamp_val, marked, status, win[2], pos[2], ok, keep, base, tmp, small, unknown;
     uint64_t stamp_mask = 0;
     int64_t n_crowded = 0;   // rounds in which the stamp table turned a candidate away
     size_t per = 0;          // int64 of scratch per candidate
@@ -915,14 +924,15 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         const int64_t *c = b.win[cur].as<int64_t>();
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         MGTA_HIP_CHECK(hipMemcpyAsync(b.small.p, init, 16, hipMemcpyHostToDevice, w.st));
+        MGTA_HIP_CHECK(hipMemsetAsync(b.unknown.p, 0, (size_t)m * 4, w.st));
         const StampTab tab{b.stamp_key.as<unsigned long long>(), b.stamp_val.as<unsigned long long>(), b.stamp_mask, (unsigned long long)(b.round + 1) << 40};
         // (the list of the wide candidates lives in `ok` until the check kernel writes that; its length in the fourth counter)
         hipLaunchKernelGGL(bubble_reach_narrow_kernel, dim3((m + 64 / kNarrowLanes - 1) / (64 / kNarrowLanes)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len,
-                           b.scratch.as<int64_t>(), b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
+                           b.scratch.as<int64_t>(), b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3, b.unknown.as<uint32_t>());
         hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 8192u)), dim3(kWideThreads), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch.as<int64_t>(), b.per,
-                           tab, (unsigned long long)b.round, b.reach_max, barrier, b.ok.as<uint32_t>(), barrier + 3);
+                           tab, (unsigned long long)b.round, b.reach_max, barrier, b.ok.as<uint32_t>(), barrier + 3, b.unknown.as<uint32_t>());
         hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
-                           (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier);
+                           (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier, b.unknown.as<uint32_t>());
         hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
                            b.ok.as<uint32_t>(), barrier, b.marked.as<unsigned long long>(), b.status.as<uint32_t>(), b.keep.as<uint32_t>(), n_done);
         if (shed) {      // the candidates beyond the cut stay pending, behind the ones this round keeps
@@ -951,7 +961,8 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     BubbleWork b;
     DevBuf branching, found, cand, flag, again, counter;
     uint64_t nb = edges_where(w, PredBranching{}, branching);
-    b.per = std::max<size_t>((size_t)kMaxBranches * max_len + 1 + kMaxBranches / 2, (size_t)kReachHash + 2 * kReachFrontier);
+    b.per = kResOffset + 1 + kMaxBranches / 2;                         // reach hash (the search's branches overlay it: edge ids read as stale entries) | frontiers | results
+    static_assert((size_t)kMaxBranches * (2 * kMaxK + 4) <= (size_t)kReachHash, "the branches of a search fit the hash region");
     // candidates per round: as many as an eighth of the free device memory (2 .. 32 GB) holds scratch for -- a round costs ~24 ms of
     // launches and look-ups whatever it commits, 100 M reads took 513 rounds with 8 GB
     size_t free_b = 0, total_b = 0;
@@ -990,6 +1001,7 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     for (int i = 0; i < 2; ++i) { b.win[i].alloc((size_t)b.window * 8, w.live(), w.peak()); b.pos[i].alloc((size_t)b.window * 8, w.live(), w.peak()); }
     b.ok.alloc((size_t)b.window * 4, w.live(), w.peak());
     b.keep.alloc((size_t)b.window * 4, w.live(), w.peak());
+    b.unknown.alloc((size_t)b.window * 4, w.live(), w.peak());
     b.base.alloc((size_t)b.window * 8, w.live(), w.peak());
     b.tmp.alloc(scan_tmp_elems(b.window) * 8, w.live(), w.peak());
     b.small.alloc(64, w.live(), w.peak());

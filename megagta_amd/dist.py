@@ -28,17 +28,22 @@ def _dev():
 
 def all_gather_bytes(flat: torch.Tensor, group=None) -> list[torch.Tensor]:
     """all-gather of uint8 tensors of different lengths (they stay where they are: device tensors over RCCL, CPU tensors over gloo):
-    an 8-byte all-gather tells the sizes, then ONE all-gather of the payloads padded to the longest"""
+    an 8-byte all-gather tells the sizes, then ONE `all_gather_into_tensor` of the payloads (padded to the longest: the collective moves
+    equal pieces) into one buffer of world x longest bytes -- the returned tensors are views of it, no copy per rank"""
     world = dist.get_world_size(group)
     n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
-    ns = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(ns, n, group=group)
-    sizes = [int(x.item()) for x in ns]
-    pad = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=flat.device)
-    pad[: flat.numel()] = flat
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:s] for o, s in zip(out, sizes)]
+    ns = torch.zeros(world, dtype=torch.int64, device=flat.device)
+    dist.all_gather_into_tensor(ns, n, group=group)
+    sizes = [int(x) for x in ns.cpu().tolist()]
+    longest = max(max(sizes), 1)
+    if flat.numel() == longest:
+        pad = flat.contiguous()
+    else:
+        pad = torch.zeros(longest, dtype=torch.uint8, device=flat.device)
+        pad[: flat.numel()] = flat
+    out = torch.empty(world * longest, dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * longest: r * longest + s] for r, s in enumerate(sizes)]
 
 
 def all_gather_record_shards(shard: torch.Tensor, group=None) -> torch.Tensor:
@@ -78,23 +83,24 @@ def gene_seed_share(seeds_per_gene: list[int], rank: int, world: int) -> list[np
     return out
 
 
-def all_gather_packed_contigs(n_seeds: int, mine: np.ndarray, contigs: np.ndarray, offsets: np.ndarray, group=None) -> tuple[np.ndarray, np.ndarray]:
-    """mine[i] = global seed index of this rank's contig i = contigs[offsets[i]:offsets[i+1]] (uint8).  Returns (contigs, offsets) of
-    ALL seeds in seed order on every rank.  The path's one exchange: ONE all-gather of a length-prefixed byte buffer per rank
-    ([n][seed index, length] * n [bytes]), padded to the longest (an 8-byte all-gather tells the sizes).  No Python work per seed:
-    the merge is numpy gathers over pieces of at most 64 MB."""
+def _contig_blob(mine: np.ndarray, contigs: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+    """one rank's contigs of one gene as bytes: [n][seed index, length] * n [contig bytes]"""
     mine = np.asarray(mine, dtype=np.int64)
     offsets = np.asarray(offsets, dtype=np.int64)
     head = np.empty(1 + 2 * mine.size, dtype=np.int64)
     head[0] = mine.size
     head[1::2] = mine
     head[2::2] = np.diff(offsets)
-    blob = np.concatenate([head.view(np.uint8), np.ascontiguousarray(contigs, dtype=np.uint8)[: int(offsets[-1]) if offsets.size else 0]])
-    parts = [p.cpu().numpy() for p in all_gather_bytes(torch.from_numpy(blob).to(_dev()), group)]
+    return np.concatenate([head.view(np.uint8), np.ascontiguousarray(contigs, dtype=np.uint8)[: int(offsets[-1]) if offsets.size else 0]])
+
+
+def _merge_contig_blobs(n_seeds: int, parts: list[np.ndarray]) -> tuple[np.ndarray, np.ndarray]:
+    """the ranks' blobs of one gene -> (contigs, offsets) of all its seeds in seed order.  No Python work per seed: numpy gathers over
+    pieces of at most 64 MB."""
     lens = np.zeros(n_seeds, dtype=np.int64)
     heads = []
     for b in parts:
-        n = int(b[:8].view(np.int64)[0])
+        n = int(b[:8].view(np.int64)[0]) if b.size >= 8 else 0
         h = b[8:8 + 16 * n].view(np.int64)
         heads.append((n, h[0::2], h[1::2]))
         lens[h[0::2]] = h[1::2]
@@ -116,6 +122,35 @@ def all_gather_packed_contigs(n_seeds: int, mine: np.ndarray, contigs: np.ndarra
             out[pos + shift] = b[pos]
             i = j
     return out, out_off
+
+
+def all_gather_packed_contigs(n_seeds: int, mine: np.ndarray, contigs: np.ndarray, offsets: np.ndarray, group=None) -> tuple[np.ndarray, np.ndarray]:
+    """mine[i] = global seed index of this rank's contig i = contigs[offsets[i]:offsets[i+1]] (uint8).  Returns (contigs, offsets) of
+    ALL seeds in seed order on every rank: one gene's exchange (all_gather_all_genes is the whole run's)."""
+    return all_gather_all_genes([n_seeds], [mine], [contigs], [offsets], group)[0]
+
+
+def all_gather_all_genes(n_seeds: list[int], mine: list[np.ndarray], contigs: list[np.ndarray], offsets: list[np.ndarray],
+                         group=None) -> list[tuple[np.ndarray, np.ndarray]]:
+    """The path's ONE exchange (BASELINE.json north_star: "a single RCCL all-gather of contigs over xGMI at the end"): every rank passes, for
+    every gene of the run, the contigs of the seeds it searched (mine[g][i] = seed index of contigs[g][offsets[g][i]:offsets[g][i+1]]);
+    every rank gets, per gene, (contigs, offsets) of all seeds in seed order.  One buffer per rank -- [per gene: blob length][blobs] --
+    and ONE all-gather of it (an 8-byte one tells the sizes)."""
+    blobs = [_contig_blob(m, c, o) for m, c, o in zip(mine, contigs, offsets)]
+    table = np.array([b.size for b in blobs], dtype=np.int64)
+    buf = np.concatenate([table.view(np.uint8)] + blobs) if blobs else np.zeros(0, np.uint8)
+    parts = [p.cpu().numpy() for p in all_gather_bytes(torch.from_numpy(buf).to(_dev()), group)]
+    G = len(blobs)
+    out = []
+    starts = []
+    for p in parts:
+        t = p[:8 * G].view(np.int64)
+        st = np.zeros(G + 1, dtype=np.int64)
+        np.cumsum(t, out=st[1:])
+        starts.append(st + 8 * G)
+    for g in range(G):
+        out.append(_merge_contig_blobs(n_seeds[g], [p[int(st[g]):int(st[g + 1])] for p, st in zip(parts, starts)]))
+    return out
 
 
 def contig_list(contigs: np.ndarray, offsets: np.ndarray) -> list[str]:

@@ -120,6 +120,9 @@ def main(argv: list[str]) -> int:
     genes = read_gene_list(gene_list)
     seeds = [read_seeds(f"{seeds_prefix}_{name}_starting_kmers.txt") for name, _, _ in genes]
     share = mdist.gene_seed_share([len(s[0]) if s else 0 for s in seeds], rank, world)
+    # every rank searches its share of every gene; the results stay on the rank until ONE all-gather at the end brings all genes' contigs
+    # together (north_star: "a single RCCL all-gather of contigs over xGMI at the end"); rank 0 then writes the files
+    results = []
     for gi, (name, fwd, rev) in enumerate(genes):
         if seeds[gi] is None:                                         # search.cpp:163-167: report and go on with the next gene
             if rank == 0:
@@ -137,12 +140,20 @@ def main(argv: list[str]) -> int:
                                                            cache_mode=window, cost_rate=rate)
             nexp = st["n_expansions"]
             fw.free(); rv.free()
-        if world > 1:
-            contigs, offsets = mdist.all_gather_packed_contigs(len(kmers), mine, contigs, offsets)
+        results.append((name, len(kmers), mine, contigs, offsets))
         if rank == 0:
-            write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
             print(f"    [megagta_amd] Done {name}: {len(kmers)} seeds over {world} rank(s), rank 0: {mine.size} seeds, {nexp} expansions, "
                   f"{time.time() - tg:.2f} s", file=sys.stderr, flush=True)
+    tg = time.time()
+    if world > 1:
+        merged = mdist.all_gather_all_genes([r[1] for r in results], [r[2] for r in results], [r[3] for r in results], [r[4] for r in results])
+    else:
+        merged = [(r[3], r[4]) for r in results]
+    if rank == 0:
+        for (name, _, _, _, _), (contigs, offsets) in zip(results, merged):
+            write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
+        print(f"    [megagta_amd] {len(results)} gene(s): one all-gather of {sum(int(o[-1]) for _, o in merged)} contig bytes + the files in {time.time() - tg:.2f} s",
+              file=sys.stderr, flush=True)
     graph.free()
     ctx.close()
     if world > 1:

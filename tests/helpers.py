@@ -146,3 +146,55 @@ def bigm_case(golden_dir: str, case: str, outdir: str):
     packed, start = synth.pack_reads_for_build(mg.reads)
     gold = {m: parse_probe_astar(gz_lines(os.path.join(golden_dir, "bigm", f"{case}_astar_{m}.txt.gz"))) for m in ("cold", "warm")}
     return packed, start, gdir, gold["cold"], gold["warm"]
+
+
+def fasta_seqs(path):
+    return [l for l in open(path).read().splitlines() if l and l[0] != ">"]
+
+
+def stagewise_vs_reference(out, work, gene_list: str, oracle, ref_bin: str, our_bin: str, min_multiset: float = 0.95):
+    """A finished `megagta.py -k 30,36,45` run under `out` against the reference BINARY fed the same inputs, stage by stage (the
+    reference's driver sequence megagta.py:538-720): the three graphs (buildgraph with the previous k's contigs as assist sequences),
+    the contigs of the intermediate k (denovo -t 1), the seeds of every gene (findstart, sorted: the reference shuffles its lines),
+    and the raw contigs of every gene: MEGAGTA_CACHE_WINDOW=1 byte-identical to the reference's `search ... 1` on the same graph and
+    seed files, the driver's own run (whatever window it ran with) compared as a multiset.  -> {gene: (equal as a multiset, seeds)}"""
+    import subprocess
+    from collections import Counter
+    run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
+    lib = str(out / "tmp" / "reads.lib")
+    common = ["-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4", "--num_output_threads", "1",
+              "--read_lib_file", lib]
+    prev = None
+    for k in (29, 35, 44):                                            # the three graphs
+        cmd = [ref_bin, "buildgraph", "-k", str(k), "--output_prefix", str(work / f"ref_{k}")] + common
+        if prev is not None:
+            cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
+        run(cmd)
+        assert oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges().md5() == oracle.Stream.read(str(work / f"ref_{k}")).edges().md5(), k
+        prev = k
+    for k, nxt in ((29, 35), (35, 44)):                               # the contigs of the intermediate k
+        run([ref_bin, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(work / f"ref_{k}"), "-t", "1", "--min_standalone", "400", "--max_tip_len", "150",
+             "--min_contig", str(nxt + 1)])
+        assert (out / f"k{k}" / f"{k}.contigs.fa").read_text() == (work / f"ref_{k}.contigs.fa").read_text(), k
+    genes = {l.split()[0]: l.split()[3] for l in open(gene_list)}
+    n_seeds = {}
+    for gene, faa in genes.items():                                   # the seeds of every gene
+        ref_seeds = run([ref_bin, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")]).stdout.decode().splitlines()
+        ours = (out / "k44" / f"44_{gene}_starting_kmers.txt").read_text().splitlines()
+        assert ours == sorted(ref_seeds) and len(ours) > 64, gene
+        n_seeds[gene] = len(ours)
+    # the reference's one-thread search on OUR graph files and seed files; window 1 == that run, byte for byte, all genes in one call
+    run([ref_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ref1"), "20", "0.5", "1"])
+    run([our_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ours_w1"), "20", "0.5", "4"],
+        env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
+    res = {}
+    for gene in genes:
+        assert (work / f"ours_w1_raw_contigs_{gene}.fasta").read_text() == (work / f"ref1_raw_contigs_{gene}.fasta").read_text(), gene
+        ours, ref = fasta_seqs(out / "k44" / f"44_raw_contigs_{gene}.fasta"), fasta_seqs(work / f"ref1_raw_contigs_{gene}.fasta")
+        assert len(ours) == len(ref) == n_seeds[gene]
+        a, b = Counter(ours), Counter(ref)
+        common_n = sum((a & b).values())
+        assert common_n >= min_multiset * len(ref), (gene, common_n, len(ref))
+        res[gene] = (common_n, len(ref), a == b)
+        assert (out / "contigs" / gene / "nucl_merged.fasta").stat().st_size > 0 and (out / "contigs" / gene / "prot_merged.fasta").stat().st_size > 0
+    return res

@@ -68,13 +68,21 @@ def _worker8(rank, world, port, tmp, ret):
     from megagta_amd import dist as mdist, search_dist
     share = mdist.gene_seed_share([n for _, n in GENES10], rank, world)
     took = 0
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda out, inp, group=None: (calls.append(int(inp.numel())), real(out, inp, group=group))[1]
+    results = []
     for gi, (name, n) in enumerate(GENES10):                          # the loop of search_dist.main with the search replaced by _fake_contig
         mine = share[gi]
         took += int(mine.size)
         blobs = [_fake_contig(gi, int(i)) for i in mine]
         offs = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.int64)
-        c, o = mdist.all_gather_packed_contigs(n, mine, np.frombuffer(b"".join(blobs), dtype=np.uint8), offs)
-        if rank == 0:
+        results.append((mine, np.frombuffer(b"".join(blobs), dtype=np.uint8), offs))
+    merged = mdist.all_gather_all_genes([n for _, n in GENES10], [r[0] for r in results], [r[1] for r in results], [r[2] for r in results])
+    dist.all_gather_into_tensor = real
+    assert len(calls) == 2 and calls[0] == 1, calls                   # ONE all-gather of contigs for all ten genes (+ the 8-byte one that tells the sizes)
+    if rank == 0:
+        for (name, n), (c, o) in zip(GENES10, merged):
             search_dist.write_fasta(os.path.join(tmp, f"out_raw_contigs_{name}.fasta"), name, c, o)
     ret[rank] = (took, sum(1 for x in share if x.size))
     dist.destroy_process_group()
@@ -83,7 +91,7 @@ def _worker8(rank, world, port, tmp, ret):
 @pytest.mark.parametrize("world", [8, 4])
 def test_ten_genes_on_eight_and_four_ranks(tmp_path, world):
     """config 5's shape on the CPU: ten genes of very different seed counts over 8 ranks (fewer ranks than genes: whole genes are dealt,
-    heaviest first) and over 4; every seed is searched exactly once, one all-gather per gene, and the files rank 0 writes are the ones
+    heaviest first) and over 4; every seed is searched exactly once, ONE all-gather of contigs for the whole run (north_star), and the files rank 0 writes are the ones
     a single process would write (record names and order of hmm_graph_search.h:79)"""
     mgr = mp.Manager()
     ret = mgr.dict()

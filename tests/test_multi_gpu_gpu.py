@@ -145,6 +145,94 @@ def test_config4_five_genes_two_ranks_every_artefact_equals_the_one_gpu_run(five
         assert a == b and len(a) > 0, f
     log = (outs[2] / "log").read_text()
     assert "on 2 GPUs" in log and "rank 1 of 2" in log
+    # ... and the one-GPU run against the REFERENCE binary, stage by stage (config 4 in small: the gene loop of search.cpp:105-122 over five
+    # genes): three graphs, two sets of contigs, five seed files, five raw-contig files (window 1 == `search ... 1` byte for byte; the
+    # driver's window-16 run as a multiset)
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/megagta (the prebuilt reference) is not present: the reference half of the test")
+    res = H.stagewise_vs_reference(outs[1], d, gl, O, REF, BIN)
+    assert set(res) == set(genes)
+    print("config4 vs reference: " + ", ".join(f"{g} {c}/{n}" for g, (c, n, _) in res.items()) + " raw contigs equal `search ... 1` as a multiset (window 16)")
+
+
+RCCL_WORLD1 = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from megagta_amd import dist as mdist
+assert dist.get_backend() == "nccl" and mdist._dev().type == "cuda"
+rng = np.random.default_rng(3)
+recs = torch.from_numpy(rng.integers(0, 65536, 100001, dtype=np.uint16).view(np.uint8).copy()).cuda()
+whole = mdist.all_gather_record_shards(recs)
+assert whole.is_cuda and torch.equal(whole, recs)                       # device to device: the shard never visits the host
+n_seeds = [0, 5, 1000]
+mine = [np.arange(n, dtype=np.int64) for n in n_seeds]
+blobs = [[(b"acgt" * ((i * 7 + g) % 40))[: (i * 13 + g) % 150] for i in range(n)] for g, n in enumerate(n_seeds)]
+offs = [np.concatenate([[0], np.cumsum([len(b) for b in bl])]).astype(np.int64) for bl in blobs]
+cont = [np.frombuffer(b"".join(bl), dtype=np.uint8) for bl in blobs]
+merged = mdist.all_gather_all_genes(n_seeds, mine, cont, offs)
+for g, (c, o) in enumerate(merged):
+    assert [x.encode() for x in mdist.contig_list(c, o)] == blobs[g], g
+c, o = mdist.all_gather_packed_contigs(n_seeds[2], mine[2], cont[2], offs[2])
+assert np.array_equal(c, cont[2]) and np.array_equal(o, offs[2])
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL world 1 ok")
+"""
+
+
+def test_rccl_backend_world_one_runs_the_two_exchanges_on_device_tensors(tmp_path):
+    """the `nccl` (= RCCL) branch of megagta_amd/dist.py has only ever been taken by the driver's 8-GPU run: here the process group is RCCL
+    with ONE rank on the box's GPU, and both exchanges of the path -- the record shards of a sharded build, the contigs of all genes at
+    the end of a sharded search -- run on device tensors through `all_gather_into_tensor`"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rccl1.py"
+    script.write_text(RCCL_WORLD1)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(port)], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "RCCL world 1 ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_config5_ten_genes_over_five_ranks_on_the_hip_path(tmp_path):
+    """BASELINE.json configs[4] in small, on the HIP path: ten genes, `search_dist.py` as FIVE ranks sharing the one GPU over gloo (a box
+    lets at most six processes use its card at once, so not eight; tests/test_dist_gloo.py runs the ten-gene partition over 8 and 4 ranks on the CPU).
+    Fewer ranks than genes: whole genes are dealt to the ranks (heaviest first), every gene is searched by one rank over all its seeds in
+    order, ONE all-gather brings the contigs to rank 0.  Against `megagta search` on the same files: every gene's FASTA byte-identical,
+    in the default mode and with window 1 -- and window 1 against the REFERENCE's `search ... 1` (the gene loop of search.cpp:105-122)."""
+    assert os.path.exists(BIN)
+    d = tmp_path
+    specs = (("rplB", 277), ("nirK", 360), ("nifH", 296), ("rpoB", 240), ("amoA", 180), ("nosZ", 200), ("pmoA", 150), ("dsrA", 220), ("mcrA", 260), ("nxrB", 170))
+    mg = synth.make_metagenome(24000, 150, specs, seed=41, reads_per_genome=1500, genome_len=22000)
+    synth.write_lib_bin(mg.reads, str(d / "reads.lib"))
+    gl = synth.write_gene_models(mg.genes, str(d / "models"))
+    run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
+    run([BIN, "buildgraph", "-k", "44", "-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4",
+         "--num_output_threads", "1", "--read_lib_file", str(d / "reads.lib"), "--output_prefix", str(d / "44")])
+    genes = {l.split()[0]: l.split()[3] for l in open(gl)}
+    assert len(genes) == 10
+    for g, faa in genes.items():
+        with open(d / f"44_{g}_starting_kmers.txt", "wb") as f:
+            f.write(run([BIN, "findstart", faa, str(d / "reads.lib.bin"), "45", "4"]).stdout)
+        assert os.path.getsize(d / f"44_{g}_starting_kmers.txt") > 1000, g
+    pre = str(d / "44")
+    script = os.path.join(ROOT, "megagta_amd", "search_dist.py")
+    for tag, env in (("dflt", {**os.environ, "MEGAGTA_CACHE_WINDOW": "16"}), ("w1", {**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})):
+        run([BIN, "search", pre, gl, pre, str(d / f"one_{tag}"), "20", "0.5", "4"], env=env)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "5",
+                            script, pre, gl, pre, str(d / f"five_{tag}"), "20", "0.5", "4"], capture_output=True, text=True, env={**env, **ONE_GPU})
+        assert r.returncode == 0, r.stderr[-3000:]
+        for g in genes:
+            a, b = (d / f"one_{tag}_raw_contigs_{g}.fasta").read_bytes(), (d / f"five_{tag}_raw_contigs_{g}.fasta").read_bytes()
+            assert a == b and a.count(b">") > 20, (tag, g)
+    if os.path.exists(REF):
+        run([REF, "search", pre, gl, pre, str(d / "ref1"), "20", "0.5", "1"])
+        for g in genes:
+            assert (d / f"five_w1_raw_contigs_{g}.fasta").read_bytes() == (d / f"ref1_raw_contigs_{g}.fasta").read_bytes(), g
+        print("config5 in small: ten genes over five ranks == `megagta search` (window 16 and window 1) == the reference's `search ... 1` (window 1)")
 
 
 def test_split_gene_agreement_fraction(tmp_path):

@@ -60,6 +60,26 @@ def test_buildgraph_1m_reads_vs_reference(big, oracle):
     # sdbg_multi_io.h:83-187; the decoded stream -- bucket sizes, records, multiplicities, tip labels -- is what a reader sees)
 
 
+def test_buildgraph_1m_reads_solid_and_mercy_vs_reference(big, oracle):
+    """stage 1 above toy size (cx1_read2sdbg_s1.cpp:177-951, mercy edges s2.cpp:106-250): `-m 2 --need_mercy` and `-m 3` on the same
+    1 M reads against the reference binary -- edge stream bit-exact, `.counting` byte-identical"""
+    d = big
+    for tag, m, mercy in (("m2mercy", 2, True), ("m3", 3, False)):
+        common = ["-k", "44", "-m", str(m), "--host_mem", "32000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_output_threads", "1",
+                  "--read_lib_file", str(d / "reads.lib")] + (["--need_mercy"] if mercy else [])
+        _, t_ref = _run([REF, "buildgraph", "--output_prefix", str(d / f"ref_{tag}"), "--num_cpu_threads", str(min(64, os.cpu_count() or 8))] + common)
+        _, t_ours = _run([BIN, "buildgraph", "--output_prefix", str(d / f"ours_{tag}"), "--num_cpu_threads", "4"] + common)
+        a, b = oracle.Stream.read(str(d / f"ours_{tag}")).edges(), oracle.Stream.read(str(d / f"ref_{tag}")).edges()
+        print(f"parity 1M buildgraph -m {m}{' --need_mercy' if mercy else ''}: {a.records.size} edges, {a.tips.size // a.words_per_tip} tips; "
+              f"reference {t_ref:.1f} s, ours {t_ours:.1f} s")
+        assert a.records.size == b.records.size > 1_000_000
+        assert a.md5() == b.md5()
+        assert open(d / f"ours_{tag}.counting", "rb").read() == open(d / f"ref_{tag}.counting", "rb").read()
+        for f in os.listdir(d):                                        # (the graphs of this test are not needed again)
+            if f.startswith((f"ref_{tag}.", f"ours_{tag}.")):
+                os.remove(d / f)
+
+
 def test_denovo_1m_reads_vs_reference_one_thread(big):
     d = big
     if not os.path.exists(d / "ours.sdbg_info"):
@@ -79,7 +99,7 @@ def test_denovo_1m_reads_vs_reference_one_thread(big):
     print(f"parity 1M denovo from the reference's {n_files} graph file(s): identical contigs")
 
 
-def test_findstart_and_search_1m_reads_vs_reference(big):
+def test_findstart_and_search_1m_reads_vs_reference(big, oracle):
     d = big
     if not os.path.exists(d / "ours.sdbg_info"):
         pytest.skip("needs test_buildgraph_1m_reads_vs_reference")
@@ -117,3 +137,31 @@ def test_findstart_and_search_1m_reads_vs_reference(big):
               f"{common} as a multiset ({100.0 * common / len(ref):.2f} %); cold (no sharing) equal seed by seed: {cold_pos}; "
               f"reference 1 thread {t_ref:.1f} s, ours default {t_ours:.1f} s, cold {t_cold:.1f} s (both genes); window 1 on {N_SEQ} seeds per gene {t_w1:.1f} s")
         assert common >= 0.97 * len(ref), (g, common, len(ref))
+    # What the default mode IS, seed by seed: the ordered-commit rule (window B, cost term R of the search plan) restated by the oracle
+    # over the same seeds in the same order -- every contig equal, not only counted.  And what the seeds that differ from the
+    # reference's sequential run are: each is the result of the same A* under the window's (smaller) view of the cache; most of them
+    # equal the seed's COLD result (the path the sequential run took from a recent seed's cache entry was not visible yet).
+    from megagta_amd import search_dist
+    og = oracle.Graph(oracle.Stream.read(str(d / "ours")))
+    for g, a in genes.items():
+        seeds = [l.split("\t") for l in open(d / f"s_{g}_starting_kmers.txt").read().splitlines()]
+        window, rate = search_dist.window_and_rate(len(seeds))
+        S = oracle.Searcher(og, oracle.Hmm(a[1]), oracle.Hmm(a[2]), 20, 0.5)
+        S.clear_cache(); S.set_window(window); S.set_cost_rate(rate)
+        t = time.time()
+        want = [S.search(x[3], int(x[7]) - 1, cold=False) for x in seeds]
+        dflt, ref, cold = (seqs(d / f"{n}_raw_contigs_{g}.fasta") for n in ("dflt", "ref1", "cold"))
+        assert [w[0] for w in want] == dflt, g                        # the product's default mode == the oracle's restatement of its rule
+        differ = [i for i, (x, y) in enumerate(zip(dflt, ref)) if x != y]
+        as_cold = sum(1 for i in differ if dflt[i] == cold[i])
+        # the differing seeds' scores next to the sequential run's (oracle, same seeds, window 1 = `search ... 1`, pinned against the
+        # reference's file above): a different view of the cache may only change WHICH admissible path is taken
+        S.clear_cache(); S.set_window(1); S.set_cost_rate(0)
+        seq = [S.search(x[3], int(x[7]) - 1, cold=False) for x in seeds]
+        assert [w[0] for w in seq] == ref, g
+        rel = [abs((want[i][1].real_score + want[i][2].real_score) - (seq[i][1].real_score + seq[i][2].real_score)) /
+               max(1e-9, abs(seq[i][1].real_score + seq[i][2].real_score)) for i in differ]
+        print(f"parity 1M search {g}: default mode (window {window}, rate {rate}) == oracle's ordered-commit restatement on all {len(seeds)} seeds "
+              f"({time.time() - t:.1f} s of oracle time); {len(differ)} seeds differ from `search ... 1`: {as_cold} of them are the seed's cold result, "
+              f"{len(differ) - as_cold} a third path; relative difference of the summed path log-probabilities: median "
+              f"{sorted(rel)[len(rel) // 2] if rel else 0:.2e}, max {max(rel) if rel else 0:.2e}")

@@ -211,50 +211,11 @@ def test_config3_two_genes_multi_k_stagewise_and_contig_multiset(two_gene_inputs
     r = subprocess.run([sys.executable, DRIVER, "-r", str(d / "reads.fa"), "-g", gl, "-k", "30,36,45", "-o", str(out), "-t", "4",
                         "--min-contig-len", "150"], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr + open(out / "log").read()[-2000:]
-    run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
-    lib = str(out / "tmp" / "reads.lib")
-    common = ["-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4", "--num_output_threads", "1",
-              "--read_lib_file", lib]
-    prev = None
-    for k in (29, 35, 44):                                            # the three graphs
-        cmd = [REF, "buildgraph", "-k", str(k), "--output_prefix", str(d / f"ref_{k}")] + common
-        if prev is not None:
-            cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
-        run(cmd)
-        assert oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges().md5() == oracle.Stream.read(str(d / f"ref_{k}")).edges().md5(), k
-        prev = k
-    for k, nxt in ((29, 35), (35, 44)):                               # the contigs of the intermediate k
-        run([REF, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(d / f"ref_{k}"), "-t", "1", "--min_standalone", "400", "--max_tip_len", "150",
-             "--min_contig", str(nxt + 1)])
-        assert (out / f"k{k}" / f"{k}.contigs.fa").read_text() == (d / f"ref_{k}.contigs.fa").read_text(), k
-    genes = {l.split()[0]: l.split()[3] for l in open(gl)}
-    assert set(genes) == {"rplB", "nirK"}
-    n_seeds = {}
-    for gene, faa in genes.items():                                   # the seeds of both genes
-        ref_seeds = run([REF, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")]).stdout.decode().splitlines()
-        ours = (out / "k44" / f"44_{gene}_starting_kmers.txt").read_text().splitlines()
-        assert ours == sorted(ref_seeds) and len(ours) > 64, gene
-        n_seeds[gene] = len(ours)
-    # the reference's one-thread search on OUR graph files and seed files
-    run([REF, "search", str(out / "k44" / "44"), gl, str(out / "k44" / "44"), str(d / "ref1"), "20", "0.5", "1"])
-    # (a) window 1 == the sequential run, byte for byte, both genes in one call
-    run([BIN, "search", str(out / "k44" / "44"), gl, str(out / "k44" / "44"), str(d / "ours_w1"), "20", "0.5", "4"],
-        env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
-    for gene in genes:
-        assert (d / f"ours_w1_raw_contigs_{gene}.fasta").read_text() == (d / f"ref1_raw_contigs_{gene}.fasta").read_text(), gene
-    # (b) the driver's run (window 16 << seeds): same number of records, multiset of contigs against `search ... 1`
-    from collections import Counter
-    for gene in genes:
-        ours, ref = _fasta_seqs(out / "k44" / f"44_raw_contigs_{gene}.fasta"), _fasta_seqs(d / f"ref1_raw_contigs_{gene}.fasta")
-        assert len(ours) == len(ref) == n_seeds[gene]
-        a, b = Counter(ours), Counter(ref)
-        common_n = sum((a & b).values())
-        assert common_n >= 0.95 * len(ref), (gene, common_n, len(ref))
-        assert a == b, (gene, common_n, len(ref))        # on this input the window changes no contig at all (deterministic: same every run)
-        print(f"config3 {gene}: {common_n} of {len(ref)} raw contigs equal `search ... 1` as a multiset (window 16); distinct {len(a)} vs {len(b)}")
-    # the filtered outputs exist for both genes
-    for gene in genes:
-        assert (out / "contigs" / gene / "nucl_merged.fasta").stat().st_size > 0 and (out / "contigs" / gene / "prot_merged.fasta").stat().st_size > 0
+    res = H.stagewise_vs_reference(out, d, gl, oracle, REF, BIN)
+    assert set(res) == {"rplB", "nirK"}
+    for gene, (common_n, n, same) in res.items():
+        assert same, (gene, common_n, n)                 # on this input the window changes no contig at all (deterministic: same every run)
+        print(f"config3 {gene}: {common_n} of {n} raw contigs equal `search ... 1` as a multiset (window 16)")
 
 
 def test_worker_process_and_one_process_per_step_write_identical_artefacts(toy_inputs):
