@@ -44,12 +44,25 @@ mgta_ctx *mgta_ctx_create(int device_id);            /* NULL on failure (see mgt
 void mgta_ctx_destroy(mgta_ctx *);
 /* memory the build may use on the device; 0 = 90 % of what is free (cf. --host_mem/--mem_flag, build_graph.cpp:40-47) */
 int mgta_ctx_set_mem_limit(mgta_ctx *, uint64_t bytes);
+int mgta_ctx_device_memory(mgta_ctx *, uint64_t *free_bytes, uint64_t *total_bytes);   /* of the context's device, now (either may be NULL) */
 /* on: a build also leaves the WHOLE edge stream of its bucket range on the device when memory forces it into several bucket-range
  * passes (each pass is appended to a stream buffer), so that mgta_sdbg_load_resident can hand the graph of a whole-range build to
  * `denovo` / `search` without the disk or host round trip of `<prefix>.sdbg.*` (succinct_dbg.cpp:595-723) at any input size, and
  * mgta_sdbg_export_records_device hands a rank's shard (a bucket sub-range) to the all-gather in one piece.  off (default): only the
  * last pass stays.  Turning it off frees the buffer. */
 int mgta_ctx_keep_stream(mgta_ctx *, int on);
+/* on = 2: as 1, and the records and tip labels of a pass are NOT copied to the host for the sink (it is called with recs = tips = NULL,
+ * counts and large multiplicities as usual): the caller takes the whole stream afterwards with the calls below.  `megagta buildgraph`
+ * in the driver's worker: the graph is packed from the resident stream, the step ends, and a host thread downloads the stream and
+ * writes PREFIX.sdbg.* (sdbg_multi_io.h:83-187) behind the step that follows.
+ * mgta_sdbg_stream_detach: the whole stream of the last build leaves the context (which forgets it); it stays in device memory until
+ * mgta_stream_free.  mgta_stream_download: records (uint16) and tip label words (uint32) into the caller's host memory, from any host
+ * thread (a HIP stream and staging buffers of its own; nothing of the context is touched).  mgta_stream_free: on the context's thread. */
+typedef struct mgta_stream mgta_stream;
+int mgta_sdbg_stream_detach(mgta_ctx *, mgta_stream **out);
+int mgta_stream_sizes(const mgta_stream *, uint64_t *n_recs, uint64_t *n_tip_words);
+int mgta_stream_download(mgta_stream *, uint16_t *recs, uint32_t *tips);
+void mgta_stream_free(mgta_stream *);
 /* frees the grow-only work memory the context keeps between calls (build pool, search pool); a stream left in the build pool by a
  * single-pass build is dropped with it (one kept by mgta_ctx_keep_stream stays) */
 int mgta_ctx_release_scratch(mgta_ctx *);

@@ -7,10 +7,12 @@
 // The kernel and its data structures are in astar_kernel.hpp.  Scores are IEEE fp64, compiled with -ffp-contract=off:
 // path log-probabilities are bit-identical to the x86-64 reference, fval = (int)(10000*(score+2h)) truncates identically.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "astar_kernel.hpp"
 #include "scan.hpp"
@@ -375,6 +377,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             a.gate = gated;
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
+            a.ramp_base = (uint32_t)std::max<uint64_t>(64, slots / 16);              // an eighth of a direction's slots
             if (cache_mode > 0) {
                 MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 128, st));           // (limits are recomputed: a conservative restart of the gate)
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
@@ -394,6 +397,51 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             else if (G == 32) launch_astar<32>(a, (int)blocks, lds_bytes, use_lds, st);
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
+            // MGTA_ASTAR_MONITOR=<seconds>: while the launch runs, a line on stderr every so often -- where the queues are, how many slots
+            // hold a search, the lowest running seed and how far it is, the memory in use.  Copies on a stream of their own: the words are
+            // written by atomics performed at the memory side, so what the copy engine reads is recent.
+            if (const char *me = getenv("MGTA_ASTAR_MONITOR")) {
+                const double every = std::max(1.0, atof(me));
+                hipStream_t ms = nullptr;
+                MGTA_HIP_CHECK(hipStreamCreateWithFlags(&ms, hipStreamNonBlocking));
+                std::vector<long long> h_rs(cache_mode > 0 ? slots : 0);
+                std::vector<unsigned long long> h_rp(cache_mode > 0 ? slots : 0);
+                const auto t_start = std::chrono::steady_clock::now();
+                double next = every;
+                while (hipEventQuery(ev.e[3]) == hipErrorNotReady) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                    if (el < next) continue;
+                    next += every;
+                    unsigned long long q[2] = {0, 0}, pl[8] = {0}, lim[16] = {0};
+                    (void)hipMemcpyAsync(q, d_queue.p, 16, hipMemcpyDeviceToHost, ms);
+                    (void)hipMemcpyAsync(pl, ar.meta.p, 64, hipMemcpyDeviceToHost, ms);
+                    if (cache_mode > 0) {
+                        (void)hipMemcpyAsync(lim, d_start_limit.p, 128, hipMemcpyDeviceToHost, ms);
+                        (void)hipMemcpyAsync(h_rs.data(), d_run_seed.p, slots * 8, hipMemcpyDeviceToHost, ms);
+                        (void)hipMemcpyAsync(h_rp.data(), d_run_progress.p, slots * 8, hipMemcpyDeviceToHost, ms);
+                    }
+                    (void)hipStreamSynchronize(ms);
+                    long long lo = -1, lo_dir = 0, busy = 0, big = -1, big_dir = 0;
+                    unsigned long long lo_prog = 0, big_prog = 0;
+                    for (size_t sl = 0; sl < h_rs.size(); ++sl)
+                        if (h_rs[sl] >= 0) {
+                            ++busy;
+                            const long long d = (long long)((sl / (size_t)spb) & 1);
+                            if (lo < 0 || h_rs[sl] * 2 + d < lo * 2 + lo_dir) { lo = h_rs[sl]; lo_dir = d; lo_prog = h_rp[sl]; }
+                            if (h_rp[sl] > big_prog) { big = h_rs[sl]; big_dir = d; big_prog = h_rp[sl]; }
+                        }
+                    if (big >= 0)
+                        fprintf(stderr, "[astar]          longest running search: seed %lld (direction %lld, start state %d) at >= %llu expansions, k-mer %.45s\n", big, big_dir,
+                                start_state[big], big_prog, kmers + (size_t)big * klen);
+                    const long long q0 = (long long)std::min<unsigned long long>(q[0], todo[0].size()), q1 = (long long)std::min<unsigned long long>(q[1], todo[1].size());
+                    fprintf(stderr, "[astar] %6.0f s: seeds taken %lld + %lld of %zu + %zu; %lld slots hold a search; lowest running seed %lld (direction %lld) at >= %llu "
+                            "expansions%s%.45s; start limits %llu / %llu; pool %.1f GB in use (%.1f GB handed out once), reserve %.2f GB in use, owner %lld; %llu in-place restarts\n",
+                            el, q0, q1, todo[0].size(), todo[1].size(), busy, lo, lo_dir, lo_prog, lo >= 0 ? ", k-mer " : "", lo >= 0 ? kmers + (size_t)lo * klen : "",
+                            lim[0], lim[1], pl[5] / 1e9, pl[0] / 1e9, lim[8] / 1e9, (long long)lim[10] - 1, pl[7]);
+                }
+                (void)hipStreamDestroy(ms);
+            }
             MGTA_HIP_CHECK(hipMemcpyAsync(h_status.data(), d_status.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
             unsigned long long h_pool[8], h_lim[16];                                // bump, stat[0..6]; the gate's words and the reserve's
             uint32_t h_cnt[kNumClasses];

@@ -144,6 +144,7 @@ struct AstarArgs {
                                         // for memory (call_for_memory)
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
+    uint32_t ramp_base;           // ordered launches: searches in flight per direction before any has ended (slow start)
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
                                   // direction at a time, with the whole pool to itself)
 };
@@ -248,8 +249,10 @@ __device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
         turn &= turn - 1;
         if (lane == l) res = pool_alloc_one(P, c);
     }
-    // a chunk another CU may have used: drop whatever this CU's L1 still holds of it (once per chunk, not per poll)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // a chunk another CU may have used: drop whatever this CU's L1 still holds of it.  Once per chunk OBTAINED, never per poll: an
+    // agent-scope acquire empties the CU's caches under every search that runs there, and a batch whose pool was exhausted had two
+    // thousand starved searches asking every iteration (50 M reads, nirK: the one search that could run did 1 500 expansions a second)
+    if (__ballot(res != kNoChunk) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (res != kNoChunk)                                                  // bytes in use
         __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + (int)(res >> kBorrowShift) + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return res;
@@ -599,12 +602,24 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
 // again): first28 << 28 | last28, times in units of 1024 ticks of the 100 MHz clock (~10 us) of the first and the latest call of the
 // episode (calls less than 50 ms apart).  The LEVEL of the call is its age in 10 ms steps: starved searches with fewer than
 // 256 << 2 level expansions give their memory back, so the ones with the least work to lose go first and everybody after 100 ms.
-__device__ __forceinline__ void call_for_memory(const AstarArgs &a) {
+// start_limit[11]: the lowest search (2 * seed + direction, + 1) that has called in this episode.  Any search that has waited for memory
+// beyond its patience calls; a starved search ABOVE the caller gives its memory back (by the level rule above), the caller and
+// everything below it keep theirs: the lowest starved search is always served, so a pool that the searches in flight have outgrown
+// together drains from the top instead of standing still.
+__device__ __forceinline__ void call_for_memory(const AstarArgs &a, long long sid) {
     const unsigned long long now = (__builtin_amdgcn_s_memrealtime() >> 10) & 0xFFFFFFFull, word = ld_agent(&a.start_limit[5]);
     const unsigned long long last = word & 0xFFFFFFFull, first = (word >> 28) & 0xFFFFFFFull;
     const bool going = word != 0ull && ((now - last) & 0xFFFFFFFull) < 5000ull;
+    // the caller's seat ([11] id + 1, [12] when its holder last called): taken by a lower search, refreshed by its holder, and free again
+    // 20 ms after the holder's last call (it was served, or it ended)
+    const unsigned long long cur = ld_agent(&a.start_limit[11]), seen = ld_agent(&a.start_limit[12]);
+    if (!going || cur == 0ull || ((now - seen) & 0xFFFFFFFull) > 2000ull || (unsigned long long)sid + 1ull <= cur) {
+        st_agent(&a.start_limit[11], (unsigned long long)sid + 1ull);
+        st_agent(&a.start_limit[12], now);
+    }
     st_agent(&a.start_limit[5], ((going ? first : now) << 28) | now);
 }
+__device__ __forceinline__ long long memory_caller(const AstarArgs &a) { return (long long)ld_agent(&a.start_limit[11]) - 1ll; }
 __device__ __forceinline__ int memory_call_level(const AstarArgs &a) {          // -1: nobody is calling
     const unsigned long long now = (__builtin_amdgcn_s_memrealtime() >> 10) & 0xFFFFFFFull, word = ld_agent(&a.start_limit[5]);
     const unsigned long long last = word & 0xFFFFFFFull, first = (word >> 28) & 0xFFFFFFFull;
@@ -746,8 +761,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             quit = GX::bcast(quit, 0, gbase);
             if (quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }       // (status stays 0: the pass is run again)
             else if (used <= a.pool.soft_limit) { st = S_START; starved = 0; }
-            else if ((++starved & 255u) == 0u && gl == 0) call_for_memory(a);   // waiting for room is calling for room too (this may be the
-                                                                                 // lowest search of all: the running ones must not sit on what it waits for)
+            else if ((++starved & 255u) == 0u && gl == 0) call_for_memory(a, sid);   // waiting for room is calling for room too (this may be the
+                                                                                      // lowest search of all: the running ones must not sit on what it waits for)
         }
         if (__ballot(st == S_BACKOFF) != 0ull && __ballot(st == S_START || st == S_RUN || st == S_DONE) == 0ull) {
 #pragma unroll
@@ -772,14 +787,28 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     // announce a lower bound of the seed about to be taken BEFORE taking it: whoever sees the queue beyond a seed also
                     // sees a slot that holds it (or its committed paths)
                     st_agent(&a.run_progress[slot], 0ull);
-                    st_agent(&a.run_seed[slot], seed_at(a, dir, ld_agent(&a.queue[dir])));
-                    qi = (long long)__hip_atomic_fetch_add(&a.queue[dir], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long t = ld_agent(&a.queue[dir]);
+                    st_agent(&a.run_seed[slot], seed_at(a, dir, t));
+                    // SLOW START: the searches of a batch's first seconds find the caches empty and are all long ones (50 M reads, nirK:
+                    // 8192 of them outgrew a 140 GB pool together within ten seconds and the batch stood still).  The searches in
+                    // flight per direction start at ramp_base and grow by one with every search that ends, so the memory in use is
+                    // known (and the admission rule above works) before every slot is busy.
+                    const unsigned long long done = ld_agent(&a.start_limit[6 + dir]);
+                    qi = -1;
+                    for (int tries = 0; tries < 4; ++tries) {
+                        if (t >= (unsigned long long)n_todo) { qi = (long long)t; break; }   // nothing left to take: the slot retires
+                        if (t - done >= (unsigned long long)a.ramp_base + done) break;
+                        if (__hip_atomic_compare_exchange_strong(&a.queue[dir], &t, t + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { qi = (long long)t; break; }
+                    }
+                    if (qi < 0) st_agent(&a.run_seed[slot], -1ll);                       // not now: the slot stays idle
                 } else {
                     qi = (long long)atomicAdd(&a.queue[dir], 1ull);
                 }
             }
             qi = GX::bcast(qi, 0, gbase);
-            if (qi >= n_todo) {
+            if (qi < 0) {
+                // (slow start: no seed taken this time)
+            } else if (qi >= n_todo) {
                 st = S_EXIT;
                 if (a.gate && gl == 0) st_agent(&a.run_seed[slot], -1ll);
             } else {
@@ -862,7 +891,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (st == S_RUN && yield_check) {
                 yield_check = false;
                 int level = -1;
-                if (gl == 0) { if (sid == lo) call_for_memory(a); else level = memory_call_level(a); }
+                long long caller = -1;
+                if (gl == 0) {
+                    if (sid == lo) call_for_memory(a, sid);
+                    else {
+                        level = memory_call_level(a);
+                        caller = memory_caller(a);
+                        if (level < 0 || sid <= caller) { call_for_memory(a, sid); level = -1; }   // the lowest starved search so far: it calls, it does not yield
+                    }
+                }
                 level = GX::bcast(level, 0, gbase);
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
@@ -1000,7 +1037,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             // nothing to give, the search keeps its popped node and asks again in the next iteration: memory comes back as other
             // searches end (bounded: after kStarveLimit iterations it gives up with status 2 and is run again by the host)
             bool wait_mem = false;
-            if (!stop && n_nodes + kMaxNew > cap_nodes) {
+            // (a search that is waiting asks again every 8th, later every 64th iteration: thousands of waiting searches asking every
+            // iteration keep the allocator's words -- and the memory channels they live in -- busy for everybody)
+            const bool ask = starved == 0u || (starved & (starved < 1024u ? 7u : 63u)) == 0u;
+            if (!stop && !ask) wait_mem = true;
+            if (!stop && !wait_mem && n_nodes + kMaxNew > cap_nodes) {
                 uint32_t unit = 0;
                 if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && AR.chunk_class(n_levels) < kNumClasses) {
@@ -1411,6 +1452,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (a.gate && gl == 0) {     // the paths are in the cache (atomics, all performed): this search no longer holds anybody back
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&a.run_seed[slot], -1ll);
+                __hip_atomic_fetch_add(&a.start_limit[6 + dir], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (slow start: one more search may be in flight)
             }
             st = S_IDLE;
         }

@@ -63,7 +63,7 @@ int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
 
 int mgta_ctx_keep_stream(mgta_ctx *ctx, int on) {
     if (!ctx) return MGTA_EINVAL;
-    ctx->keep_stream = on ? 1 : 0;
+    ctx->keep_stream = on == 2 ? 2 : on ? 1 : 0;
     if (!on) {
         // after a keep-stream build last_rec / last_tips point INTO the stream buffers: they go with them
         if (ctx->acc_valid) { ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0; }
@@ -80,6 +80,15 @@ int mgta_ctx_release_scratch(mgta_ctx *ctx) {
     ctx->pool.clear();
     ctx->astar.pool.release(); ctx->astar.meta.release();
     if (in_pool) { ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0; }
+    return MGTA_OK;
+}
+
+int mgta_ctx_device_memory(mgta_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!ctx) return MGTA_EINVAL;
+    size_t f = 0, t = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) { mgta::set_error("hipMemGetInfo failed"); return MGTA_EHIP; }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return MGTA_OK;
 }
 

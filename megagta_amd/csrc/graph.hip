@@ -382,6 +382,83 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
     } catch (const HipError &e) { return e.code; }
 }
 
+// ---- the whole edge stream of a keep-stream build, taken out of the context: it stays in device memory until it is freed, and a host
+// thread of its own brings it to the host (`megagta buildgraph` in the worker: the files are written behind the step that already uses
+// the resident graph; per-pass copies into pageable memory cost more than the passes themselves at 50 M reads)
+struct mgta_stream {
+    mgta_ctx *ctx = nullptr;      // (its memory counters outlive the buffers below)
+    int device = 0, k = 0, words_per_tip = 0;
+    mgta::DevBuf rec, tips;
+    uint64_t n_rec = 0, n_tip_words = 0;
+};
+
+int mgta_sdbg_stream_detach(mgta_ctx *ctx, mgta_stream **out) {
+    if (!ctx || !out) { set_error("mgta_sdbg_stream_detach: bad argument"); return MGTA_EINVAL; }
+    if (!ctx->acc_valid) { set_error("mgta_sdbg_stream_detach: the last build did not keep its whole stream (mgta_ctx_keep_stream)"); return MGTA_EINVAL; }
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        auto st = std::make_unique<mgta_stream>();
+        st->ctx = ctx; st->device = ctx->device; st->k = ctx->last_k; st->words_per_tip = ctx->last_words_per_tip;
+        st->n_rec = ctx->acc_n_rec; st->n_tip_words = ctx->acc_n_tips * (uint64_t)ctx->last_words_per_tip;
+        st->rec = std::move(ctx->acc_rec); st->tips = std::move(ctx->acc_tips);
+        ctx->acc_valid = false;
+        ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0;
+        ctx_retain(ctx);
+        *out = st.release();
+        return MGTA_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int mgta_stream_sizes(const mgta_stream *s, uint64_t *n_recs, uint64_t *n_tip_words) {
+    if (!s) { set_error("mgta_stream_sizes: bad argument"); return MGTA_EINVAL; }
+    if (n_recs) *n_recs = s->n_rec;
+    if (n_tip_words) *n_tip_words = s->n_tip_words;
+    return MGTA_OK;
+}
+
+// Any host thread; a HIP stream and two pinned staging buffers of its own; touches nothing of the context.
+int mgta_stream_download(mgta_stream *s, uint16_t *recs, uint32_t *tips) {
+    if (!s || (s->n_rec && !recs) || (s->n_tip_words && !tips)) { set_error("mgta_stream_download: bad argument"); return MGTA_EINVAL; }
+    hipStream_t st = nullptr;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = MGTA_OK;
+    try {
+        MGTA_HIP_CHECK(hipSetDevice(s->device));
+        MGTA_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        const size_t piece = 128ull << 20;
+        for (int i = 0; i < 2; ++i) { MGTA_HIP_CHECK(hipHostMalloc(&stage[i], piece, hipHostMallocDefault)); MGTA_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+        struct Part { const char *src; char *dst; size_t bytes; };
+        const Part parts[2] = {{s->rec.as<char>(), reinterpret_cast<char *>(recs), (size_t)s->n_rec * 2}, {s->tips.as<char>(), reinterpret_cast<char *>(tips), (size_t)s->n_tip_words * 4}};
+        for (const Part &pt : parts) {
+            const size_t n_pieces = (pt.bytes + piece - 1) / piece;
+            auto issue = [&](size_t i) {
+                const size_t len = std::min(piece, pt.bytes - i * piece);
+                MGTA_HIP_CHECK(hipMemcpyAsync(stage[i & 1], pt.src + i * piece, len, hipMemcpyDeviceToHost, st));
+                MGTA_HIP_CHECK(hipEventRecord(ev[i & 1], st));
+            };
+            if (n_pieces) issue(0);
+            for (size_t i = 0; i < n_pieces; ++i) {                     // piece i + 1 crosses the bus while piece i leaves its staging buffer
+                if (i + 1 < n_pieces) issue(i + 1);                     // (its buffer held piece i - 1: copied out in the previous round)
+                MGTA_HIP_CHECK(hipEventSynchronize(ev[i & 1]));
+                memcpy(pt.dst + i * piece, stage[i & 1], std::min(piece, pt.bytes - i * piece));
+            }
+        }
+    } catch (const HipError &e) { rc = e.code; }
+    for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipHostFree(stage[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
+
+void mgta_stream_free(mgta_stream *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    mgta_ctx *c = s->ctx;
+    delete s;
+    ctx_release(c);
+}
+
 int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
     if (!ctx || !out) { set_error("mgta_sdbg_load_resident: bad argument"); return MGTA_EINVAL; }
     if (ctx->last_k == 0 || ctx->last_bucket_lo != 0 || ctx->last_bucket_hi != (uint32_t)MGTA_NUM_BUCKETS || (ctx->last_n_rec && !ctx->last_rec)) {

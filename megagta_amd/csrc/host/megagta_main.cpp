@@ -58,6 +58,7 @@ struct Session {
     std::string graph_prefix;
     std::thread writer;           // PREFIX.sdbg.* of the last buildgraph being written while the next step already runs on the resident graph
     std::string writer_error;     // why that thread failed (set by the thread, read after the join)
+    mgta_stream *stream = nullptr;   // the edge stream that thread downloads from the device (freed on this thread once it has joined)
 };
 static Session g_sess;
 // The graph files of the last buildgraph are complete: called before anything reads them, before the next build, at the end, and by the
@@ -66,6 +67,7 @@ static Session g_sess;
 // happened to be running when the thread hit it.
 static int writer_join() {
     if (g_sess.writer.joinable()) g_sess.writer.join();
+    if (g_sess.stream) { mgta_stream_free(g_sess.stream); g_sess.stream = nullptr; }
     if (g_sess.writer_error.empty()) return 0;
     fprintf(stderr, "    [ERROR] writing the graph files of the last buildgraph failed: %s\n", g_sess.writer_error.c_str());
     fflush(stderr);
@@ -161,9 +163,9 @@ static int sink_collect(void *user, int32_t b0, int32_t b1, const int64_t *count
         s.bucket_large[b] = counts[3 * (b - b0) + 1];
         s.bucket_tips[b] = counts[3 * (b - b0) + 2];
     }
-    s.recs.insert(s.recs.end(), recs, recs + n);
+    if (recs) s.recs.insert(s.recs.end(), recs, recs + n);           // (NULL: the stream stays on the device, mgta_ctx_keep_stream 2)
     s.large.insert(s.large.end(), large, large + nl);
-    s.tips.insert(s.tips.end(), tips, tips + ntw);
+    if (tips) s.tips.insert(s.tips.end(), tips, tips + ntw);
     return 0;
 }
 
@@ -229,12 +231,21 @@ static int main_buildgraph(int argc, char **argv) {
 
     mgta_ctx *ctx = ctx_get();
     graph_drop();
+    const double t_dev = now_s();
     const bool hand_over = g_sess.active && world == 1;
-    if (hand_over) mgta_ctx_keep_stream(ctx, 1);
+    const bool device_stream = hand_over && !getenv("MEGAGTA_SYNC_WRITES");
+    if (hand_over) mgta_ctx_keep_stream(ctx, device_stream ? 2 : 1);
     // --gpu_mem: device budget in bytes.  Unset, a one-shot process takes 64 GB at most: device memory is mapped at ~27 ms/GB
     // (measured: 194 GB cost 5.3 s before the first kernel ran), which outweighs the few extra bucket-range passes of a tighter budget
-    // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  A resident caller (bench, multi-k API) keeps the pool.
-    mgta_ctx_set_mem_limit(ctx, gpu_mem > 0 ? (uint64_t)gpu_mem : (64ull << 30));
+    // (100 M reads: 3 passes in 1.5 s with 194 GB, 10 passes in 2.0 s with 70 GB).  The worker keeps its pool between the builds of a run,
+    // so it pays that once and takes what fits beside the next step's needs: 3/5 of the device (a `denovo` on the graph of 100 M reads
+    // holds ~80 GB; 50 M reads, k = 44: 7 passes of 540 ms under 64 GB).
+    uint64_t budget = gpu_mem > 0 ? (uint64_t)gpu_mem : (64ull << 30);
+    if (gpu_mem <= 0 && g_sess.active) {
+        uint64_t total = 0;
+        if (mgta_ctx_device_memory(ctx, nullptr, &total) == MGTA_OK && total) budget = std::max<uint64_t>(budget, total / 5 * 3);
+    }
+    mgta_ctx_set_mem_limit(ctx, budget);
     std::shared_ptr<EdgeStream> sp = std::make_shared<EdgeStream>();
     EdgeStream &s = *sp;
     s.k = k; s.words_per_tip = (2 * k + 31) / 32;
@@ -247,6 +258,8 @@ static int main_buildgraph(int argc, char **argv) {
     if (hand_over) {                                                     // the graph stays on the device for the step that uses it
         if (mgta_sdbg_load_resident(ctx, &g_sess.graph) != MGTA_OK) die("mgta_sdbg_load_resident: %s", mgta_last_error());
         g_sess.graph_prefix = out_prefix;
+        // the stream leaves the context in one piece: the writer thread below brings it to the host and writes the files
+        if (device_stream && mgta_sdbg_stream_detach(ctx, &g_sess.stream) != MGTA_OK) die("mgta_sdbg_stream_detach: %s", mgta_last_error());
         mgta_ctx_keep_stream(ctx, 0);
     }
     if (min_count > 1 && rank == 0) {                                    // PREFIX.counting (s1_post_proc, cx1_read2sdbg_s1.cpp:923-930); every rank counts all (k+1)-mers
@@ -259,13 +272,22 @@ static int main_buildgraph(int argc, char **argv) {
         fclose(cf);
     }
     ctx_put(ctx);
-    logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
-         (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9);
+    logf("device build: %.1f ms (%d pass%s, %lld sort items, %.3f Gk-mer/s; count %.0f, keys %.0f, sort %.0f, emit %.0f, copy to the host %.0f ms; stage 1 %.0f ms; "
+         "upload + graph hand-over: wall %.2f s)", st.ms_total, st.n_passes, st.n_passes > 1 ? "es" : "",
+         (long long)st.n_items, st.n_kmers / (st.ms_total * 1e-3) / 1e9, st.ms_count, st.ms_gen, st.ms_sort, st.ms_emit, st.ms_d2h, st.ms_stage1, now_s() - t_dev);
     // the files: the run's artefacts, what `--continue` resumes from and what a one-shot process reads.  In the worker the step that
     // follows works on the resident graph, so they are written by a host thread behind it (joined before anything reads them)
-    auto write_files = [sp, out_prefix, world, rank, b_lo, b_hi]() {
-        const EdgeStream &s = *sp;
+    mgta_stream *dev_stream = device_stream ? g_sess.stream : nullptr;
+    auto write_files = [sp, out_prefix, world, rank, b_lo, b_hi, dev_stream]() {
+        EdgeStream &s = *sp;
         double t1 = now_s();
+        if (dev_stream) {                                                // records and tip labels: one download of the whole stream
+            uint64_t nr = 0, nt = 0;
+            mgta_stream_sizes(dev_stream, &nr, &nt);
+            s.recs.resize(nr); s.tips.resize(nt);
+            if (mgta_stream_download(dev_stream, s.recs.data(), s.tips.data()) != MGTA_OK) die("mgta_stream_download: %s", mgta_last_error());
+            logf("edge stream on the host: %.3f s (%llu records)", now_s() - t1, (unsigned long long)nr);
+        }
         if (world == 1) write_sdbg(out_prefix, s);
         else {
             write_sdbg(out_prefix, s, rank, b_lo, b_hi, true);

@@ -2133,11 +2133,14 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             // ---- device -> host
             if (sink) {
                 t_ph.start();
-                h_rec.resize(n_edges); h_large.resize(n_large); h_tips.resize(n_tips * words_per_tip);
+                // keep_stream 2: records and tip labels stay on the device only (the caller takes the whole stream afterwards,
+                // mgta_sdbg_stream_detach / mgta_stream_download); the sink still gets the counts and the large multiplicities
+                const bool to_host = ctx->keep_stream != 2;
+                h_rec.resize(to_host ? n_edges : 0); h_large.resize(n_large); h_tips.resize(to_host ? n_tips * words_per_tip : 0);
                 h_first.resize((size_t)nb * 3);
-                if (n_edges) MGTA_HIP_CHECK(hipMemcpyAsync(h_rec.data(), d_out_rec, n_edges * 2, hipMemcpyDeviceToHost, stream));
+                if (n_edges && to_host) MGTA_HIP_CHECK(hipMemcpyAsync(h_rec.data(), d_out_rec, n_edges * 2, hipMemcpyDeviceToHost, stream));
                 if (n_large) MGTA_HIP_CHECK(hipMemcpyAsync(h_large.data(), d_out_large, n_large * 2, hipMemcpyDeviceToHost, stream));
-                if (n_tips) MGTA_HIP_CHECK(hipMemcpyAsync(h_tips.data(), d_out_tips, n_tips * words_per_tip * 4, hipMemcpyDeviceToHost, stream));
+                if (n_tips && to_host) MGTA_HIP_CHECK(hipMemcpyAsync(h_tips.data(), d_out_tips, n_tips * words_per_tip * 4, hipMemcpyDeviceToHost, stream));
                 MGTA_HIP_CHECK(hipMemcpyAsync(h_first.data(), d_first, (size_t)nb * 3 * 8, hipMemcpyDeviceToHost, stream));
                 S.ms_d2h += t_ph.stop();
                 // bucket boundaries -> counts; untouched entries (-1) are empty buckets
@@ -2157,8 +2160,9 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         }
         S.n_edges += (int64_t)n_edges; S.n_large += (int64_t)n_large; S.n_tips += (int64_t)n_tips;
         if (sink) {
-            int rc = sink(user, (int32_t)b_lo, (int32_t)b_hi, h_items.data(), h_rec.data(), (int64_t)n_edges, h_large.data(),
-                          (int64_t)n_large, h_tips.data(), (int64_t)(n_tips * words_per_tip));
+            const bool to_host = ctx->keep_stream != 2;
+            int rc = sink(user, (int32_t)b_lo, (int32_t)b_hi, h_items.data(), to_host ? h_rec.data() : nullptr, (int64_t)n_edges, h_large.data(),
+                          (int64_t)n_large, to_host ? h_tips.data() : nullptr, (int64_t)(n_tips * words_per_tip));
             if (rc != 0) { set_error("edge sink returned %d", rc); return MGTA_ESINK; }
         }
         b_lo = b_hi;
