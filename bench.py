@@ -538,6 +538,7 @@ def main():
                   "expansions_per_step": float(nexp[0]), "ms_per_step": float(nexp[1]) * 1e3, "cache_mode": "cold (every seed independent)",
                   "lanes_per_search": 8 if max(len(x) for x in seeds) >= 32768 else 16, "searches_in_flight_per_gpu": 16384 if max(len(x) for x in seeds) >= 32768 else 8192,
                   "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"], "searches_grown_in_place": sst[-1]["n_grown"],
+                  "warmup_expansions": w0["n_expansions"],
                   "pool_used_GB": sst[-1]["pool_used"] / 1e9}
         if rank == 0:
             # roofline of the leg: algorithmic bytes per expansion (170 B x (1 + d1 + d1 d2), 510 B unbranched) over time, against

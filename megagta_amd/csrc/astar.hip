@@ -262,7 +262,15 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         a.cache_probe_limit = 256;
         if (cache_mode > 0) {
             for (int d = 0; d < 2; ++d) {
+                // (one entry per DISTINCT node of the result paths.  Up to 1 GB the table holds "every seed a path of its own" twice over;
+                // beyond that the paths of one gene copy's seeds share theirs and an eighth of it is generous -- 2 x 36 GB of tables
+                // took a fifth of the device from nirK's searches at 50 M reads; MGTA_ASTAR_CACHE_DIV overrides the divisor.  An insert
+                // that finds no room is counted: mgta_astar_stats.n_cache_drops, 0 in every run so far)
+                uint64_t div = 8;
+                if (const char *e = getenv("MGTA_ASTAR_CACHE_DIV")) div = (uint64_t)std::max(1, atoi(e));
                 uint64_t want = 2ull * (uint64_t)n * ((uint64_t)hm[d]->M + 64), cap = 1024;
+                const uint64_t gb = (1ull << 30) / sizeof(CacheEnt);                 // tables below 1 GB keep the worst-case size
+                if (want > gb) want = std::max(gb, want / div);
                 while (cap < want) cap <<= 1;
                 while (cap > 1024 && cap * sizeof(CacheEnt) > free_b / 8) cap >>= 1;
                 d_cache[d].alloc(cap * sizeof(CacheEnt), &ctx->live_bytes, &ctx->peak_bytes);
@@ -308,7 +316,9 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // of it is in use, so a small pool costs searches in flight, not failures.
             const uint64_t n_search = (uint64_t)work * 2;
             // (graphs of billions of edges: the searches run longer, the 8 MB that serve a 2 M-read graph starved nirK's at 100 M reads)
-            const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : (n_search >= (1ull << 20) || g->dev.size > (3ll << 30)) ? (16ull << 20) : (8ull << 20);
+            // (round 4, multi-k graphs of 50 M reads and more: the first-of-their-gene-copy searches of nirK reach 1-4 M nodes, 150-500 MB
+            // each, and how many of them run side by side is what the first minutes of such a batch cost: 24 MB per slot there too)
+            const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : (n_search >= (1ull << 20) || g->dev.size > (3ll << 30)) ? (n_search >= (1ull << 21) ? (24ull << 20) : (16ull << 20)) : (8ull << 20);
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
                                                  : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
@@ -373,13 +383,22 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                 a.pool.stack = w + 16 + 4 * kNumClasses;
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
-            a.pool.soft_limit = dyn / 2;
+            // admission: no new search starts while this much is in use.  A search that is admitted goes on growing -- the cold searches
+            // of a batch's first minute a hundredfold -- so ordered batches stop admitting at a third: what is in flight then has room
+            // to triple.  (In the steady state of a batch a few hundred MB are in use and neither limit is ever met.)
+            a.pool.soft_limit = gated ? dyn / 3 : dyn / 2;
             a.gate = gated;
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             a.ramp_base = (uint32_t)std::max<uint64_t>(64, slots / 16);              // an eighth of a direction's slots
+            // (an explicit pool = a test of the ordered paths under starvation: the order is held whatever it costs; MEGAGTA_SEARCH_STRICT_ORDER=1 likewise)
+            a.auto_unorder = gated && !ctx->astar_pool_bytes && !(getenv("MEGAGTA_SEARCH_STRICT_ORDER") && atoi(getenv("MEGAGTA_SEARCH_STRICT_ORDER"))) ? 1 : 0;
             if (cache_mode > 0) {
                 MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 128, st));           // (limits are recomputed: a conservative restart of the gate)
+                if (ST.order_abandoned) {                                            // (a batch that gave its order up resumes without one)
+                    const unsigned long long one = 1;
+                    MGTA_HIP_CHECK(hipMemcpyAsync(d_start_limit.as<unsigned long long>() + 14, &one, 8, hipMemcpyHostToDevice, st));
+                }
                 d_run_seed.alloc(slots * 8); d_run_progress.alloc(slots * 8);
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_seed.p, 0xFF, slots * 8, st));
                 MGTA_HIP_CHECK(hipMemsetAsync(d_run_progress.p, 0, slots * 8, st));
@@ -460,6 +479,17 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             ST.pool_used = std::max<uint64_t>(ST.pool_used, slots * slot_bytes + h_pool[6]);   // base arenas + most ever handed out at once
             ST.reserve_bytes = reserve;
             ST.reserve_used = std::max<uint64_t>(ST.reserve_used, h_lim[9]);
+            ST.n_cache_drops += (int64_t)h_lim[13];
+            if (h_lim[14] && !ST.order_abandoned) {
+                ST.order_abandoned = 1;
+                fprintf(stderr, "[megagta_amd] search: the searches in flight outgrew their pool (%.1f GB, %llu requests refused): the batch of %lld seeds gave up the ORDER of its "
+                        "cache sharing from there on -- every path is seen by every search as soon as it is found, as in the reference's multi-thread search "
+                        "(search.cpp:182-189); which of several equally good paths a later seed takes depends on timing.  MEGAGTA_SEARCH_STRICT_ORDER=1 holds the order.\n",
+                        pool_bytes / 1e9, h_pool[2], (long long)n);
+            }
+            if (gated && h_lim[13])
+                fprintf(stderr, "[megagta_amd] search: %llu path entries found no room in the shared cache (%.1f GB per direction): later seeds may have searched "
+                        "where they could have followed a path -- which ones depends on timing\n", h_lim[13], d_cache[0].bytes / 1e9);
             size_t left = 0, starved_out = 0;
             for (int d = 0; d < 2; ++d) {
                 std::vector<int64_t> again;

@@ -31,6 +31,16 @@ constexpr uint32_t lds_heap_slots(int G) { return G >= 16 ? 72u : 40u; }
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+// PAGES.  A level (or hash table) of more than 8 MB is not one chunk but 8 MB pages named by a small table: late in a batch the memory
+// that is free sits in the lists of the sizes the ended searches used, and a search that needs its next 64 MB in one piece waits for
+// ever next to 80 GB of free 1-16 MB chunks (50 M reads, nirK: 141.7 GB handed out once, 55 GB in use, a thousand searches waiting and
+// only the reserve's owner moving).  With pages nothing larger than 8 MB is ever asked for, so whatever the large searches give back
+// serves the next ones; an access into a paged level costs one more (cached) load of the table entry.
+constexpr int kPageClass = 11;                 // 4 KB << 11 = 8 MB (2 MB pages: every search beyond 32 k nodes paid the extra load -- rplB at 50 M
+                                               // reads 60 -> 81 s; with 8 MB only searches beyond ~200 k nodes do, and they are the ones that
+                                               // used to wait for 16 MB ... 1 GB pieces)
+constexpr int kPageLog = kPageClass + kUnitLog;
+constexpr uint32_t kPagedBit = 1u << 30;       // in a level's word / the hash table's word: the chunk named is the page TABLE (uint32 per page)
 constexpr uint32_t kStarveLimit = 1u << 15;    // iterations a search waits for memory before it gives up (about a second)
 constexpr uint32_t kMaxNew = 132;              // children one expansion can open (64 codons x {match, insert} + delete), rounded up
 
@@ -145,6 +155,12 @@ struct AstarArgs {
     uint32_t n_slots;
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t ramp_base;           // ordered launches: searches in flight per direction before any has ended (slow start)
+    int auto_unorder;             // ordered launches: when the searches in flight have outgrown the pool (thousands of refused requests) the
+                                  // batch gives up the ORDER, not the searches: start_limit[14] is set, from then on every path is visible
+                                  // to every search as soon as it is inserted and no seed waits at the gate -- the reference's multi-thread
+                                  // behaviour (search.cpp:182-189).  Holding the order there means thousands of long searches waiting for
+                                  // each other's memory while the seeds behind them wait for their progress (50 M reads, nirK on the multi-k
+                                  // graph: 79 000 of 300 000 seeds taken after 150 s; without the order the 300 000 end in 94 s).
     uint32_t active_slots;        // search slots per workgroup that take seeds (all of them; 1 in the last-resort pass: one search per
                                   // direction at a time, with the whole pool to itself)
 };
@@ -254,13 +270,13 @@ __device__ __forceinline__ uint32_t pool_alloc(const PoolDev &P, int c) {
     // thousand starved searches asking every iteration (50 M reads, nirK: the one search that could run did 1 500 expansions a second)
     if (__ballot(res != kNoChunk) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (res != kNoChunk)                                                  // bytes in use
-        __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + (int)(res >> kBorrowShift) + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&P.stat[4], 1ull << (c + (int)((res >> kBorrowShift) & 3u) + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return res;
 }
 // The caller has issued pool_release_fence() since its last store into the chunk.
 __device__ __forceinline__ void pool_free(const PoolDev &P, int c, uint32_t unit) {
     const int lane = lane_id();
-    c += (int)(unit >> kBorrowShift);                                 // a borrowed chunk goes back to its own list
+    c += (int)((unit >> kBorrowShift) & 3u);                          // a borrowed chunk goes back to its own list
     unit &= kUnitMask;
     if (P.reserve_bytes != 0ull && ((unsigned long long)unit << kUnitLog) >= P.reserve_off) return;   // the reserve is reset as a whole by its owner
     __hip_atomic_fetch_sub(&P.stat[4], 1ull << (c + kUnitLog), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -316,6 +332,59 @@ __device__ __forceinline__ void reserve_release(const PoolDev &P) {
     st_agent(&P.rbump[2], 0ull);
 }
 
+// One piece of the pool for lane 0 of a search: from the lists / the bump pointer, else (the lowest running search) from the reserve.
+__device__ __forceinline__ uint32_t chunk_alloc(const PoolDev &P, int c, bool use_reserve) {
+    uint32_t u = pool_alloc(P, c);
+    if (u == kNoChunk && use_reserve) u = reserve_alloc(P, c);
+    return u;
+}
+__device__ __forceinline__ int page_table_class(int c) {               // the table of a level of class c > kPageClass: 4 bytes per page
+    const int tl = c - kPageClass + 2 - kUnitLog;
+    return tl > 0 ? tl : 0;
+}
+// A level of class c: one chunk up to 2 MB, else a page table + pages.  All or nothing (what was obtained goes back when a page is
+// missing: the caller waits and asks again).  Returns the word to keep (kPagedBit set for a paged level) or kNoChunk.
+__device__ __forceinline__ uint32_t level_alloc(const PoolDev &P, int c, bool use_reserve) {
+    if (c <= kPageClass) return chunk_alloc(P, c, use_reserve);
+    const int tc = page_table_class(c);
+    const uint32_t tab = chunk_alloc(P, tc, use_reserve);
+    if (tab == kNoChunk) return kNoChunk;
+    uint32_t *pt = reinterpret_cast<uint32_t *>(P.base + ((uint64_t)(tab & kUnitMask) << kUnitLog));
+    const uint32_t n_pages = 1u << (c - kPageClass);
+    for (uint32_t p = 0; p < n_pages; ++p) {
+        const uint32_t u = chunk_alloc(P, kPageClass, use_reserve);
+        if (u == kNoChunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pool_release_fence();
+            for (uint32_t q = 0; q < p; ++q) pool_free(P, kPageClass, pt[q]);
+            pool_free(P, tc, tab);
+            return kNoChunk;
+        }
+        pt[p] = u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the other lanes of the search read the table through this CU's L1
+    return tab | kPagedBit;
+}
+// (the caller has issued pool_release_fence() since its last store into the level)
+__device__ __forceinline__ void level_free(const PoolDev &P, int c, uint32_t word) {
+    if (!(word & kPagedBit)) { pool_free(P, c, word); return; }
+    const uint32_t tab = word & ~kPagedBit;
+    const uint32_t *pt = reinterpret_cast<const uint32_t *>(P.base + ((uint64_t)(tab & kUnitMask) << kUnitLog));
+    const uint32_t n_pages = 1u << (c - kPageClass);
+    for (uint32_t p = 0; p < n_pages; ++p) pool_free(P, kPageClass, pt[p]);
+    pool_free(P, page_table_class(c), tab);
+}
+// bytes of the pool proper (not the reserve) a level holds
+__device__ __forceinline__ unsigned long long level_pool_bytes(const PoolDev &P, int c, uint32_t word) {
+    auto in_pool = [&](uint32_t u) { return P.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < P.reserve_off; };
+    if (!(word & kPagedBit)) return in_pool(word) ? 1ull << (c + (int)((word >> kBorrowShift) & 3u) + kUnitLog) : 0ull;
+    const uint32_t *pt = reinterpret_cast<const uint32_t *>(P.base + ((uint64_t)(word & kUnitMask) << kUnitLog));
+    unsigned long long b = 0;
+    for (uint32_t p = 0; p < (1u << (c - kPageClass)); ++p) if (in_pool(pt[p])) b += 1ull << (kPageClass + (int)((pt[p] >> kBorrowShift) & 3u) + kUnitLog);
+    return b;
+}
+
 // ---- growable arrays of one search ---------------------------------------------------------------------------------------------
 // Element i lives in level l = 0 for i < B0, else 1 + floor(log2(i / B0)); level l >= 1 covers [B0 << (l-1), B0 << l).  Every level
 // is one chunk of the pool (level 0: the slot's own base arena), so the array grows without moving anything.
@@ -328,7 +397,13 @@ struct Grow {
         const uint32_t hi = i >> log_b0;
         const int level = hi ? 32 - __builtin_clz(hi) : 0;
         const uint32_t off = level ? i - (1u << (log_b0 + level - 1)) : i;
-        return pool + ((uint64_t)(seg[level] & kUnitMask) << kUnitLog) + ((uint64_t)off << ELEM_LOG);
+        const uint32_t word = seg[level];
+        const uint64_t ob = (uint64_t)off << ELEM_LOG;
+        if (word & kPagedBit) {                                        // (elements never straddle a page: 16 / 64 / 128-byte units)
+            const uint32_t pg = reinterpret_cast<const uint32_t *>(pool + ((uint64_t)(word & kUnitMask) << kUnitLog))[ob >> kPageLog];
+            return pool + ((uint64_t)(pg & kUnitMask) << kUnitLog) + (ob & ((1ull << kPageLog) - 1ull));
+        }
+        return pool + ((uint64_t)(word & kUnitMask) << kUnitLog) + ob;
     }
     __device__ __forceinline__ int chunk_class(int level) const { return ELEM_LOG + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
 };
@@ -496,10 +571,11 @@ __device__ __forceinline__ void touch_done(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 // closed set + open_hash: every lane of the group probes the same key (one request)
-__device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask, uint64_t key, bool &found, uint32_t &val) {
+template <class At>
+__device__ __forceinline__ uint32_t hash_find(const At &at, uint32_t hmask, uint64_t key, bool &found, uint32_t &val) {
     uint32_t i = (uint32_t)mix64(key) & hmask;
     while (true) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(tab + i);
+        const uint4 v = *reinterpret_cast<const uint4 *>(at(i));
         const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
         if (k == 0) { found = false; val = kNone; return i; }
         if (k == key) { found = true; val = v.z; return i; }
@@ -509,6 +585,7 @@ __device__ __forceinline__ uint32_t hash_find(const HashEnt *tab, uint32_t hmask
 __device__ __forceinline__ void hash_put(HashEnt *tab, uint32_t i, uint64_t key, uint32_t val, int32_t fval = 0) {
     *reinterpret_cast<uint4 *>(tab + i) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), val, (uint32_t)fval);
 }
+constexpr uint32_t kHashPerPageLog = kPageLog - 4;                     // 16-byte entries of one page
 
 // child descriptor cached for `key` and visible to seed `seed`, or -1
 __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
@@ -549,6 +626,7 @@ __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64
         }
         i = (i + 1) & cmask;
     }
+    __hip_atomic_fetch_add(&a.start_limit[13], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no room: counted, reported by the host
 }
 
 // the cost term of the sharing rule: c expansions delay a path's visibility by c / rate seeds (rate > 0) or c * |rate| seeds (rate < 0)
@@ -734,13 +812,20 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     HashEnt *hash = base_hash;
     uint32_t hmask = 2 * B0 - 1;
     int hclass = base_hclass;
-    uint32_t hunit = 0;                                               // chunk of the current table once it has left the base arena
+    uint32_t hunit = 0;                                               // chunk of the current table once it has left the base arena (kPagedBit: its page table)
+    // entry i of the current table: in one chunk (`hash`), or -- a table of more than 2 MB -- in the page its table names
+    auto hat = [&](uint32_t i) -> HashEnt * {
+        if (!(hunit & kPagedBit)) return hash + i;
+        const uint32_t pg = reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(hunit & kUnitMask) << kUnitLog))[i >> kHashPerPageLog];
+        return reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(pg & kUnitMask) << kUnitLog)) + (i & ((1u << kHashPerPageLog) - 1u));
+    };
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
     bool yield_check = false;                                         // ordered launch: starved for long -- give the memory back unless this is the lowest running seed
     bool lowest_check = false;                                        // ordered launch: waiting for memory -- is this the lowest running search (the reserve's owner)?
     bool use_reserve = false;                                         // this IS the lowest running search: what the pool cannot give it comes from the reserve
+    bool order_off = a.free_share != 0;                               // paths are shared without an order (asked for, or the batch gave its order up: start_limit[14])
     uint32_t prog_floor = 0;                                          // expansions already announced for this seed before it started again in place
     bool have_curr = false;                                           // the node to expand is already popped (the search was waiting for memory)
     int32_t goal = -1, inter = 0, cur = 0;
@@ -840,7 +925,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 bool scan = __ballot(st == S_WAIT && need_scan) != 0ull;
                 if (!scan) {
                     long long lim = 0, quit = 0;
-                    if (lane == 0) { lim = (long long)ld_agent(&a.start_limit[dir]); quit = (long long)ld_agent(&a.start_limit[4]); }
+                    if (lane == 0) {
+                        lim = (long long)ld_agent(&a.start_limit[dir]); quit = (long long)ld_agent(&a.start_limit[4]);
+                        if (a.auto_unorder && ld_agent(&a.start_limit[14]) != 0ull) lim = 0x7FFFFFFFFFFFFFFFll;   // the order is off: nobody waits
+                    }
                     lim = __shfl(lim, 0, 64);
                     quit = __shfl(quit, 0, 64);
                     if (st == S_WAIT && quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }   // the pass has given up and is run again
@@ -890,25 +978,21 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
             if (st == S_RUN && yield_check) {
                 yield_check = false;
+                // Only the lowest RUNNING search calls (when its reserve is used up as well), and only its call makes the others give
+                // their memory back.  A search that is merely starved WAITS with what it holds: what it has computed is kept, memory comes
+                // back as others end, and the lowest running search -- served by the reserve -- always ends.  (Letting every starved
+                // search call was measured on nirK at 50 M reads: 205 000 searches started again in place within six minutes, each one
+                // throwing away hundreds of thousands of expansions.)
                 int level = -1;
-                long long caller = -1;
-                if (gl == 0) {
-                    if (sid == lo) call_for_memory(a, sid);
-                    else {
-                        level = memory_call_level(a);
-                        caller = memory_caller(a);
-                        if (level < 0 || sid <= caller) { call_for_memory(a, sid); level = -1; }   // the lowest starved search so far: it calls, it does not yield
-                    }
-                }
+                if (gl == 0) { if (sid == lo) call_for_memory(a, sid); else level = memory_call_level(a); }
                 level = GX::bcast(level, 0, gbase);
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
                     // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
                     unsigned long long own = 0;                                       // (what it holds of the pool proper: the reserve is not in `used`)
-                    auto in_pool = [&](uint32_t u) { return a.pool.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < a.pool.reserve_off; };
-                    for (int l = 1; l < n_levels; ++l) if (in_pool(seg[l])) own += 1ull << (AR.chunk_class(l) + (int)(seg[l] >> kBorrowShift) + kUnitLog);
-                    for (int l = 1; l < h_levels; ++l) if (in_pool(hseg[l])) own += 1ull << (H.ar.chunk_class(l) + (int)(hseg[l] >> kBorrowShift) + kUnitLog);
-                    if (hclass > base_hclass && in_pool(hunit)) own += 1ull << (hclass + (int)(hunit >> kBorrowShift) + kUnitLog);
+                    for (int l = 1; l < n_levels; ++l) own += level_pool_bytes(a.pool, AR.chunk_class(l), seg[l]);
+                    for (int l = 1; l < h_levels; ++l) own += level_pool_bytes(a.pool, H.ar.chunk_class(l), hseg[l]);
+                    if (hclass > base_hclass) own += level_pool_bytes(a.pool, hclass, hunit);
                     unsigned long long used = 0;
                     if (gl == 0) used = ld_agent(&a.pool.stat[4]);
                     used = GX::bcast(used, 0, gbase);
@@ -923,12 +1007,12 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
                         pool_release_fence();
                         if (gl == 0) {
-                            for (int l = 1; l < n_levels; ++l) pool_free(a.pool, AR.chunk_class(l), seg[l]);
-                            for (int l = 1; l < h_levels; ++l) pool_free(a.pool, H.ar.chunk_class(l), hseg[l]);
-                            if (hclass > base_hclass) pool_free(a.pool, hclass, hunit);
+                            for (int l = 1; l < n_levels; ++l) level_free(a.pool, AR.chunk_class(l), seg[l]);
+                            for (int l = 1; l < h_levels; ++l) level_free(a.pool, H.ar.chunk_class(l), hseg[l]);
+                            if (hclass > base_hclass) level_free(a.pool, hclass, hunit);
                         }
                     }
-                    n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+                    n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
                     if (use_reserve) {   // (it took the reserve as the lowest running search and a lower one has started since)
                         if (gl == 0) reserve_release(a.pool);
                         use_reserve = false;
@@ -945,10 +1029,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         // ================= start node (hmm_graph_search.h:132-189)
         if (st == S_START) {
             n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1; cap_heap = 2 * B0; h_levels = 1;
-            hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
             use_reserve = false; lowest_check = false; yield_check = false;
+            if (a.auto_unorder && !order_off) {
+                int off = 0;
+                if (gl == 0) off = ld_agent(&a.start_limit[14]) != 0ull;
+                order_off = GX::bcast(off, 0, gbase) != 0;
+            }
             for (uint32_t i = (uint32_t)gl; i <= hmask; i += G) hash_put(hash, i, 0ull, 0u);
             const char *km = a.kmers + seed * a.klen;
             const int n_aa = a.klen / 3;
@@ -1000,12 +1089,12 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 while (n_heap > 0) {
                     const HeapEnt top = H.get(0);
                     // (the node's edge needs no line of its own any more: the node carries where its Forward lands)
-                    const uint32_t t0 = touch(hash + ((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node));
+                    const uint32_t t0 = touch(hat((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node));
                     H.remove_top(n_heap);
                     touch_done(t0, t1, t1);
                     --n_heap;
                     bool found;
-                    hs = hash_find(hash, hmask, top.key, found, hval);
+                    hs = hash_find(hat, hmask, top.key, found, hval);
                     if (found && (hval >> 31)) continue;                               // closed
                     cur = (int32_t)top.node;
                     hkey = top.key;
@@ -1024,8 +1113,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         ok = 1; goal = inter; stop = true;
                     } else {
                         if (gl == 0) {                                                 // closed.insert (:272); the entry keeps its node and fval
-                            if (hfound) hash[hs].val = hval | 0x80000000u;
-                            else hash_put(hash, hs, hkey, hval | 0x80000000u);
+                            if (hfound) hat(hs)->val = hval | 0x80000000u;
+                            else hash_put(hat(hs), 0u, hkey, hval | 0x80000000u);
                         }
                         n_closed++;
                         if (better) { inter = cur; inter_val = cv; }                   // :274-277
@@ -1045,10 +1134,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 uint32_t unit = 0;
                 if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && AR.chunk_class(n_levels) < kNumClasses) {
-                    if (gl == 0) {
-                        unit = pool_alloc(a.pool, AR.chunk_class(n_levels));
-                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, AR.chunk_class(n_levels));
-                    }
+                    if (gl == 0) unit = level_alloc(a.pool, AR.chunk_class(n_levels), use_reserve);
                     unit = GX::bcast(unit, 0, gbase);
                     if (unit == kNoChunk) break;
                     if (gl == 0) seg[n_levels] = unit;
@@ -1062,10 +1148,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 uint32_t unit = 0;
                 const uint32_t need = heap_slots_needed(n_heap + kMaxNew);
                 while (need > cap_heap && h_levels < kMaxLevels && H.ar.chunk_class(h_levels) < kNumClasses) {
-                    if (gl == 0) {
-                        unit = pool_alloc(a.pool, H.ar.chunk_class(h_levels));
-                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, H.ar.chunk_class(h_levels));
-                    }
+                    if (gl == 0) unit = level_alloc(a.pool, H.ar.chunk_class(h_levels), use_reserve);
                     unit = GX::bcast(unit, 0, gbase);
                     if (unit == kNoChunk) break;
                     if (gl == 0) hseg[h_levels] = unit;
@@ -1078,30 +1161,39 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             while (!stop && !wait_mem && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
                 uint32_t unit = kNoChunk;
                 if (hclass + 1 < kNumClasses && hmask < 0x7FFFFFFFu) {
-                    if (gl == 0) {
-                        unit = pool_alloc(a.pool, hclass + 1);
-                        if (unit == kNoChunk && use_reserve) unit = reserve_alloc(a.pool, hclass + 1);
-                    }
+                    if (gl == 0) unit = level_alloc(a.pool, hclass + 1, use_reserve);
                     unit = GX::bcast(unit, 0, gbase);
                 }
                 if (unit == kNoChunk) { wait_mem = true; break; }
-                HashEnt *nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(unit & kUnitMask) << kUnitLog));
+                // entry j of the NEW table (one chunk, or pages named by its table)
+                HashEnt *const nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(unit & kUnitMask) << kUnitLog));
+                const bool npaged = (unit & kPagedBit) != 0u;
+                auto nat = [&](uint32_t j) -> HashEnt * {
+                    if (!npaged) return nt + j;
+                    const uint32_t pg = reinterpret_cast<const uint32_t *>(nt)[j >> kHashPerPageLog];
+                    return reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(pg & kUnitMask) << kUnitLog)) + (j & ((1u << kHashPerPageLog) - 1u));
+                };
                 const uint32_t nmask = hmask * 2 + 1;
-                for (uint64_t i = (uint64_t)gl; i <= nmask; i += G) hash_put(nt, (uint32_t)i, 0ull, 0u);
+                for (uint64_t p0 = 0; p0 <= nmask; p0 += (1ull << kHashPerPageLog)) {   // cleared page by page (one table look-up per page)
+                    HashEnt *pg = nat((uint32_t)p0);
+                    const uint64_t cnt = (uint64_t)nmask + 1 - p0 < (1ull << kHashPerPageLog) ? (uint64_t)nmask + 1 - p0 : (1ull << kHashPerPageLog);
+                    for (uint64_t i = (uint64_t)gl; i < cnt; i += G) hash_put(pg, (uint32_t)i, 0ull, 0u);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (uint64_t i0 = 0; i0 <= hmask; i0 += G) {                          // every lane moves one entry; slots are claimed at the L2
                     const uint64_t i = i0 + gl;
                     if (i <= hmask) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(hash + i);
+                        const uint4 v = *reinterpret_cast<const uint4 *>(hat((uint32_t)i));
                         const unsigned long long k = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
                         if (k != 0ull) {
                             uint32_t j = (uint32_t)mix64(k) & nmask;
                             while (true) {
+                                HashEnt *e = nat(j);
                                 unsigned long long expect = 0ull;
-                                if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&nt[j].key), &expect, k, __ATOMIC_RELAXED,
+                                if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&e->key), &expect, k, __ATOMIC_RELAXED,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                    __hip_atomic_store(&nt[j].val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_store(&nt[j].fval, (int32_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&e->val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&e->fval, (int32_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     break;
                                 }
                                 j = (j + 1) & nmask;
@@ -1113,7 +1205,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new table was filled behind this CU's L1
                 if (hclass > base_hclass) {
                     pool_release_fence();
-                    if (gl == 0) pool_free(a.pool, hclass, hunit);
+                    if (gl == 0) level_free(a.pool, hclass, hunit);
                 }
                 if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 hash = nt; hmask = nmask; ++hclass; hunit = unit;
@@ -1124,6 +1216,14 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 have_curr = !first;
                 // the lowest running search does not wait: the reserve is there for it (a scan of the slot table: asked early, then rarely)
                 if (a.gate && !use_reserve && a.pool.reserve_bytes != 0ull && (starved & 1023u) == 8u) lowest_check = true;
+                if (a.auto_unorder && !order_off && (starved & 63u) == 1u) {
+                    int off = 0;
+                    if (gl == 0) {
+                        off = ld_agent(&a.start_limit[14]) != 0ull;
+                        if (!off && ld_agent(&a.pool.stat[1]) > 4096ull) { st_agent(&a.start_limit[14], 1ull); off = 1; }
+                    }
+                    order_off = GX::bcast(off, 0, gbase) != 0;
+                }
                 // when every search in flight waits, nobody ends and nothing comes back: a search gives up after a wait in proportion
                 // to the work it would lose (a quarter of its expansions so far in iterations, 2^8 .. 2^17), so the young ones free
                 // their memory for the others within milliseconds and the ones that have run for seconds wait for seconds
@@ -1144,7 +1244,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // term_nodes.find(curr) (hmm_graph_search.h:212,279): child recorded by an earlier seed, or -1
                 int cached = -1;
                 if (a.window > 0) {
-                    if (gl == 0) cached = cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), seed);
+                    if (gl == 0) cached = cache_lookup(a, dir, make_key(curr.node_id, curr.state_no, cst), order_off ? 0x7FFFFFFFFFFFll : (long long)seed);
                     cached = GX::bcast(cached, 0, gbase);
                 }
                 const int cached_st = cached >= 0 ? (cached >> 9) : -1;
@@ -1152,6 +1252,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 n_expanded++;
                 if (a.gate && a.cost_rate != 0 && (n_expanded & 63) == 0 && gl == 0 && n_expanded > prog_floor)
                     __hip_atomic_store(&a.run_progress[slot], (unsigned long long)n_expanded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.auto_unorder && !order_off && (n_expanded & 255u) == 0u) {
+                    int off = 0;
+                    if (gl == 0) off = ld_agent(&a.start_limit[14]) != 0ull;
+                    order_off = GX::bcast(off, 0, gbase) != 0;
+                }
 
                 // ---- children (node_enumerator.h:131-244)
                 double mt, it, dt;
@@ -1169,7 +1274,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 };
                 // the probes of one expansion are independent: their first loads are issued together, then resolved, then the fvals of
                 // the open-list entries they found are fetched together (three dependent round trips instead of six)
-                auto ld_slot = [&](uint32_t ii) { return *reinterpret_cast<const uint4 *>(hash + ii); };
+                auto ld_slot = [&](uint32_t ii) { return *reinterpret_cast<const uint4 *>(hat(ii)); };
                 auto resolve = [&](uint64_t key, uint32_t ii, uint4 v, int &old_fval) -> uint32_t {     // open-list node recorded for `key` (+ its fval), kNone = none
                     while (true) {
                         const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
@@ -1206,8 +1311,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     he.key = key; he.fval = fval; he.node = node;
                     if (!first) {
                         bool found; uint32_t val;
-                        const uint32_t hs = hash_find(hash, hmask, key, found, val);
-                        if (gl == 0) hash_put(hash, hs, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
+                        const uint32_t hs = hash_find(hat, hmask, key, found, val);
+                        if (gl == 0) hash_put(hat(hs), 0u, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
                         if (!found) ++n_keys;
                         n_opened++;
                     }
@@ -1422,7 +1527,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     const ANode par = load_node(node_at((uint32_t)nd.parent));
                     if (a.window > 0 && gl == 0)
                         cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
-                                     a.free_share ? 0 : seed + a.window + cost_term(a.cost_rate, n_expanded), nd.em_state);
+                                     order_off ? 0 : seed + a.window + cost_term(a.cost_rate, n_expanded), nd.em_state);
                     nd = par;
                 }
                 if (gl == 0) {
@@ -1439,12 +1544,12 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
                 pool_release_fence();
                 if (gl == 0) {
-                    for (int l = 1; l < n_levels; ++l) pool_free(a.pool, AR.chunk_class(l), seg[l]);
-                    for (int l = 1; l < h_levels; ++l) pool_free(a.pool, H.ar.chunk_class(l), hseg[l]);
-                    if (hclass > base_hclass) pool_free(a.pool, hclass, hunit);
+                    for (int l = 1; l < n_levels; ++l) level_free(a.pool, AR.chunk_class(l), seg[l]);
+                    for (int l = 1; l < h_levels; ++l) level_free(a.pool, H.ar.chunk_class(l), hseg[l]);
+                    if (hclass > base_hclass) level_free(a.pool, hclass, hunit);
                 }
             }
-            n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass;
+            n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
             if (use_reserve) {           // the reserve's owner ends: all of it is free for the next lowest search
                 if (gl == 0) reserve_release(a.pool);
                 use_reserve = false;

@@ -423,10 +423,10 @@ static int main_search(int argc, char **argv) {
         fclose(out);
         mgta_hmm_free(fw); mgta_hmm_free(rv);
         logf("Done %s: time %.4lf (%lld expansions, %.1f ms on device; %lld searches grew in place, %lld run again, %lld resumed passes, pool %.1f of %.1f GB, "
-             "reserve %.2f of %.1f GB; largest search %lld nodes / %lld expansions)",
+             "reserve %.2f of %.1f GB; largest search %lld nodes / %lld expansions%s)",
              gene.name.c_str(), now_s() - tg, (long long)st.n_expansions, st.ms_total, (long long)st.n_grown, (long long)st.n_retries, (long long)st.n_resumes,
              st.pool_used / 1e9, st.pool_bytes / 1e9, st.reserve_used / 1e9, st.reserve_bytes / 1e9, (long long)st.max_search_nodes,
-             (long long)st.max_search_expansions);
+             (long long)st.max_search_expansions, st.order_abandoned ? "; the searches outgrew the pool: paths shared WITHOUT an order from there on" : "");
     };
     // the genes of the list one after the other (search.cpp:124).  MEGAGTA_SEARCH_LANES=2 searches two genes side by side on one
     // graph, each batch on its own context (stream + work memory) and half of the CUs (mgta_astar_batch_on): measured and NOT the
