@@ -308,6 +308,21 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             if (attempt == 3) blocks = 2;
             blocks = std::max<int64_t>(2, blocks + (blocks & 1));
             const uint64_t slots = (uint64_t)blocks * spb;
+            // the two directions share the workgroups by the work their seeds promise: a forward search from model position s has
+            // M - s - (k+1)/3 columns to cover, a reverse one s (50 M reads, rplB: with halves the reverse searches were done after 35 s
+            // and their half of the device idled for the other 36 s); between a quarter and three quarters each
+            double w_dir[2] = {0, 0};
+            for (int d = 0; d < 2; ++d)
+                for (int64_t sd : todo[d]) {
+                    const double cols = d == 0 ? (double)(hm[0]->M - start_state[sd] - klen / 3) : (double)start_state[sd];
+                    w_dir[d] += std::max(1.0, cols);
+                }
+            int64_t blocks0 = (int64_t)std::llround((double)blocks * w_dir[0] / std::max(1.0, w_dir[0] + w_dir[1]));
+            blocks0 = std::max<int64_t>(std::max<int64_t>(1, blocks / 4), std::min<int64_t>(blocks - std::max<int64_t>(1, blocks / 4), blocks0));
+            if (todo[0].empty()) blocks0 = 1;
+            if (todo[1].empty()) blocks0 = blocks - 1;
+            if (getenv("MGTA_ASTAR_EVEN_SPLIT")) blocks0 = blocks / 2;
+            a.blocks_dir0 = (uint32_t)blocks0;
             // pool = the slots' base arenas + what the searches grow into (+ the reserve).  Device memory beyond the first ~24 GB of a
             // process costs 20-90 ms/GB to obtain (profiles/r02/vmm_probe.log), so the pool follows the job: at least 4 GB; 24 MB per
             // search in flight (196 GB for a full grid) for independent searches -- at 100 M reads they average 29 k expansions
@@ -446,7 +461,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                     for (size_t sl = 0; sl < h_rs.size(); ++sl)
                         if (h_rs[sl] >= 0) {
                             ++busy;
-                            const long long d = (long long)((sl / (size_t)spb) & 1);
+                            const long long d = sl >= (size_t)a.blocks_dir0 * (size_t)spb ? 1 : 0;
                             if (lo < 0 || h_rs[sl] * 2 + d < lo * 2 + lo_dir) { lo = h_rs[sl]; lo_dir = d; lo_prog = h_rp[sl]; }
                             if (h_rp[sl] > big_prog) { big = h_rs[sl]; big_dir = d; big_prog = h_rp[sl]; }
                         }

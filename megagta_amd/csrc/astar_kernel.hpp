@@ -153,6 +153,8 @@ struct AstarArgs {
                                         // refresh by a waiting wave, [4] the pass has given up (no further seed is taken), [5] the call
                                         // for memory (call_for_memory)
     uint32_t n_slots;
+    uint32_t blocks_dir0;         // workgroups [0, blocks_dir0) search direction 0 (the k-mer, forward model), the rest direction 1: split by the work the
+                                  // seeds' model positions promise (a forward search covers M - s columns, a reverse one s), not in halves
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t ramp_base;           // ordered launches: searches in flight per direction before any has ended (slow start)
     int auto_unorder;             // ordered launches: when the searches in flight have outgrown the pool (thousands of refused requests) the
@@ -650,14 +652,15 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long head = seed_at(a, dir, hq);
     long long bound = head + a.window - 1;
-    const uint32_t n_dir = a.n_slots / 2;                             // this direction's slots: workgroups 2b + dir
+    const uint32_t s0 = a.blocks_dir0 * SPB;                          // this direction's slots: [0, s0) or [s0, n_slots)
+    const uint32_t n_dir = dir ? a.n_slots - s0 : s0, first = dir ? s0 : 0u;
     for (uint32_t t0 = 0; t0 < n_dir; t0 += 256) {
         long long js[4];
         unsigned long long pr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t t = t0 + u * 64 + (uint32_t)lane;
-            const uint32_t sl = (2 * (t / SPB) + (uint32_t)dir) * SPB + t % SPB;
+            const uint32_t sl = first + t;
             js[u] = -1; pr[u] = 0;
             if (t < n_dir) {
                 js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -719,7 +722,7 @@ __device__ __forceinline__ long long lowest_running(const AstarArgs &a, int lane
             const uint32_t sl = t0 + u * 64 + (uint32_t)lane;
             js[u] = -1;
             if (sl < a.n_slots) js[u] = __hip_atomic_fetch_add(&a.run_seed[sl], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (js[u] >= 0) js[u] = js[u] * 2 + (long long)((sl / SPB) & 1u);      // workgroup 2b + dir
+            if (js[u] >= 0) js[u] = js[u] * 2 + (long long)(sl >= a.blocks_dir0 * SPB ? 1u : 0u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * kLdsHeapSlots * sizeof(HeapEnt));
     double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + 2 * kMaxLevels * sizeof(uint32_t)));
 
-    const int dir = blockIdx.x & 1;
+    const int dir = blockIdx.x < a.blocks_dir0 ? 0 : 1;
     HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
     hv.tab = dir ? a.hm[1].tab : a.hm[0].tab; hv.M = dir ? a.hm[1].M : a.hm[0].M; hv.A = dir ? a.hm[1].A : a.hm[0].A;
     hv.col_fwd = dir ? a.hm[1].col_fwd : a.hm[0].col_fwd; hv.col_enum = dir ? a.hm[1].col_enum : a.hm[0].col_enum;
