@@ -72,9 +72,24 @@ class Context:
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 
-    def keep_stream(self, on: bool = True):
-        """whole-range builds leave their whole edge stream on the device, also when they take several memory-bound passes"""
+    def keep_stream(self, on=True):
+        """whole-range builds leave their whole edge stream on the device, also when they take several memory-bound passes.  on = 2: and the
+        records / tip labels of a pass are not copied to the host for the sink (`detach_stream` brings the whole stream over afterwards)"""
         check(self._L.mgta_ctx_keep_stream(self.h, int(on)), "mgta_ctx_keep_stream")
+
+    def detach_stream(self) -> tuple[np.ndarray, np.ndarray]:
+        """the whole edge stream of the last keep-stream build: taken out of the context (mgta_sdbg_stream_detach), downloaded in one piece
+        (mgta_stream_download) and freed -> (records uint16, tip label words uint32)"""
+        h = C.c_void_p()
+        check(self._L.mgta_sdbg_stream_detach(self.h, C.byref(h)), "mgta_sdbg_stream_detach")
+        try:
+            nr, nt = C.c_uint64(), C.c_uint64()
+            check(self._L.mgta_stream_sizes(h, C.byref(nr), C.byref(nt)), "mgta_stream_sizes")
+            recs, tips = np.empty(nr.value, dtype=np.uint16), np.empty(nt.value, dtype=np.uint32)
+            check(self._L.mgta_stream_download(h, recs.ctypes.data, tips.ctypes.data), "mgta_stream_download")
+        finally:
+            self._L.mgta_stream_free(h)
+        return recs, tips
 
     def release_scratch(self):
         """free the work memory kept between calls (build pool, search pool)"""
@@ -112,9 +127,9 @@ class Context:
         def sink(user, b0, b1, bc, r, nr, lg, nl, tp, ntw):
             nb = b1 - b0
             counts[b0:b1] = np.ctypeslib.as_array(bc, shape=(nb * 3,)).reshape(nb, 3)
-            recs.append(np.ctypeslib.as_array(r, shape=(nr,)).copy() if nr else np.zeros(0, np.uint16))
+            recs.append(np.ctypeslib.as_array(r, shape=(nr,)).copy() if nr and r else np.zeros(0, np.uint16))     # (NULL: keep_stream(2))
             large.append(np.ctypeslib.as_array(lg, shape=(nl,)).copy() if nl else np.zeros(0, np.uint16))
-            tips.append(np.ctypeslib.as_array(tp, shape=(ntw,)).copy() if ntw else np.zeros(0, np.uint32))
+            tips.append(np.ctypeslib.as_array(tp, shape=(ntw,)).copy() if ntw and tp else np.zeros(0, np.uint32))
             return 0
 
         cb = _lib.EDGE_SINK(sink) if collect else C.cast(None, _lib.EDGE_SINK)

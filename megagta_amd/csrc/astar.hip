@@ -63,7 +63,7 @@ void launch_astar(const mgta::AstarArgs &a, int blocks, size_t lds_bytes, bool u
     MGTA_HIP_CHECK(hipGetLastError());
 }
 template <int G> size_t lds_fixed() {
-    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::Grp<G>::kLdsHeap * sizeof(mgta::HeapEnt) + 2 * mgta::kMaxLevels * sizeof(uint32_t));
+    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::Grp<G>::kLdsHeap * sizeof(mgta::HeapEnt) + mgta::kPtWords * sizeof(uint32_t));
 }
 }  // namespace
 

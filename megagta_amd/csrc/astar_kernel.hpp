@@ -24,23 +24,26 @@ constexpr int kAstarWaves = 8;                 // waves per workgroup (one workg
 constexpr int kAstarThreads = kAstarWaves * 64;
 constexpr uint32_t kNone = 0x7FFFFFFFu;
 constexpr int kMaxKmer = 160;
-constexpr int kMaxLevels = 20;                 // levels of a growable array (level l >= 1 doubles the capacity)
 // heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels); with 8 lanes per search (twice the
 // searches per workgroup) the root block and four child blocks, so that the HMM tables of a 360-column model still fit beside them
 constexpr uint32_t lds_heap_slots(int G) { return G >= 16 ? 72u : 40u; }
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
-// PAGES.  A level (or hash table) of more than 8 MB is not one chunk but 8 MB pages named by a small table: late in a batch the memory
-// that is free sits in the lists of the sizes the ended searches used, and a search that needs its next 64 MB in one piece waits for
-// ever next to 80 GB of free 1-16 MB chunks (50 M reads, nirK: 141.7 GB handed out once, 55 GB in use, a thousand searches waiting and
-// only the reserve's owner moving).  With pages nothing larger than 8 MB is ever asked for, so whatever the large searches give back
-// serves the next ones; an access into a paged level costs one more (cached) load of the table entry.
-constexpr int kPageClass = 11;                 // 4 KB << 11 = 8 MB (2 MB pages: every search beyond 32 k nodes paid the extra load -- rplB at 50 M
-                                               // reads 60 -> 81 s; with 8 MB only searches beyond ~200 k nodes do, and they are the ones that
-                                               // used to wait for 16 MB ... 1 GB pieces)
+// PAGES.  Beyond its base arena a search's node array, heap and hash table grow ONE 2 MB PAGE AT A TIME; the pages of an array are named
+// by a small table (the first 16 in LDS, the rest in a 4 KB chunk).  Rounds 2-3 doubled every array with ever larger chunks from per-size
+// free lists: late in a batch the free memory sat in the lists of the sizes the ended searches had used, and a search that needed its
+// next 64 MB ... 1 GB in one piece waited for ever next to 80 GB of free 1-16 MB chunks (50 M reads, nirK: 141.7 GB handed out once, 55 GB
+// in use, a thousand searches waiting, only the reserve's owner moving).  Paged LEVELS (a table per level, all or nothing) cured that and
+// brought a livelock instead: thousands of searches taking 20 of the 64 pages they needed, failing, giving them back (100 M reads: the
+// whole device at 250 expansions a second).  With one page per step every page that comes back lets some search go on, nothing is ever
+// asked for and returned again, a search holds what it uses plus at most a page per array, and there is one size of chunk: no
+// fragmentation at all.  The hash table grows by LINEAR HASHING (Litwin 1980): buckets of one page each, split one at a time.
+constexpr int kPageClass = 9;                  // 4 KB << 9 = 2 MB
 constexpr int kPageLog = kPageClass + kUnitLog;
-constexpr uint32_t kPagedBit = 1u << 30;       // in a level's word / the hash table's word: the chunk named is the page TABLE (uint32 per page)
+constexpr int kLdsPages = 16;                  // pages of an array named in LDS (32 MB); beyond: a 4 KB table chunk (1024 pages = 2 GB per array)
+constexpr int kMaxPages = 1024;
+constexpr int kPtWords = 3 * kLdsPages + 4;    // LDS words per search: three page tables + the three table chunks' units (+ 1 spare)
 constexpr uint32_t kStarveLimit = 1u << 15;    // iterations a search waits for memory before it gives up (about a second)
 constexpr uint32_t kMaxNew = 132;              // children one expansion can open (64 codons x {match, insert} + delete), rounded up
 
@@ -340,77 +343,31 @@ __device__ __forceinline__ uint32_t chunk_alloc(const PoolDev &P, int c, bool us
     if (u == kNoChunk && use_reserve) u = reserve_alloc(P, c);
     return u;
 }
-__device__ __forceinline__ int page_table_class(int c) {               // the table of a level of class c > kPageClass: 4 bytes per page
-    const int tl = c - kPageClass + 2 - kUnitLog;
-    return tl > 0 ? tl : 0;
-}
-// A level of class c: one chunk up to 2 MB, else a page table + pages.  All or nothing (what was obtained goes back when a page is
-// missing: the caller waits and asks again).  Returns the word to keep (kPagedBit set for a paged level) or kNoChunk.
-__device__ __forceinline__ uint32_t level_alloc(const PoolDev &P, int c, bool use_reserve) {
-    if (c <= kPageClass) return chunk_alloc(P, c, use_reserve);
-    const int tc = page_table_class(c);
-    const uint32_t tab = chunk_alloc(P, tc, use_reserve);
-    if (tab == kNoChunk) return kNoChunk;
-    uint32_t *pt = reinterpret_cast<uint32_t *>(P.base + ((uint64_t)(tab & kUnitMask) << kUnitLog));
-    const uint32_t n_pages = 1u << (c - kPageClass);
-    for (uint32_t p = 0; p < n_pages; ++p) {
-        const uint32_t u = chunk_alloc(P, kPageClass, use_reserve);
-        if (u == kNoChunk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pool_release_fence();
-            for (uint32_t q = 0; q < p; ++q) pool_free(P, kPageClass, pt[q]);
-            pool_free(P, tc, tab);
-            return kNoChunk;
-        }
-        pt[p] = u;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                // the other lanes of the search read the table through this CU's L1
-    return tab | kPagedBit;
-}
-// (the caller has issued pool_release_fence() since its last store into the level)
-__device__ __forceinline__ void level_free(const PoolDev &P, int c, uint32_t word) {
-    if (!(word & kPagedBit)) { pool_free(P, c, word); return; }
-    const uint32_t tab = word & ~kPagedBit;
-    const uint32_t *pt = reinterpret_cast<const uint32_t *>(P.base + ((uint64_t)(tab & kUnitMask) << kUnitLog));
-    const uint32_t n_pages = 1u << (c - kPageClass);
-    for (uint32_t p = 0; p < n_pages; ++p) pool_free(P, kPageClass, pt[p]);
-    pool_free(P, page_table_class(c), tab);
-}
-// bytes of the pool proper (not the reserve) a level holds
-__device__ __forceinline__ unsigned long long level_pool_bytes(const PoolDev &P, int c, uint32_t word) {
-    auto in_pool = [&](uint32_t u) { return P.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < P.reserve_off; };
-    if (!(word & kPagedBit)) return in_pool(word) ? 1ull << (c + (int)((word >> kBorrowShift) & 3u) + kUnitLog) : 0ull;
-    const uint32_t *pt = reinterpret_cast<const uint32_t *>(P.base + ((uint64_t)(word & kUnitMask) << kUnitLog));
-    unsigned long long b = 0;
-    for (uint32_t p = 0; p < (1u << (c - kPageClass)); ++p) if (in_pool(pt[p])) b += 1ull << (kPageClass + (int)((pt[p] >> kBorrowShift) & 3u) + kUnitLog);
-    return b;
-}
-
 // ---- growable arrays of one search ---------------------------------------------------------------------------------------------
-// Element i lives in level l = 0 for i < B0, else 1 + floor(log2(i / B0)); level l >= 1 covers [B0 << (l-1), B0 << l).  Every level
-// is one chunk of the pool (level 0: the slot's own base arena), so the array grows without moving anything.
+// Element i < base_n lives in the slot's base arena, element base_n + j in page j >> (kPageLog - ELEM_LOG) of the array.
 template <int ELEM_LOG>
-struct Grow {
-    const uint32_t *seg;          // LDS: chunk (4 KB units) of every level
+struct PageArr {
+    char *slot_base;              // the slot's base arena ...
+    uint32_t base_off;            // ... and where the array's part of it begins
+    uint32_t base_n;              // elements there
+    const uint32_t *pt;           // LDS: units of the first kLdsPages pages
+    const uint32_t *gt;           // LDS word: unit of the 4 KB chunk that names the pages from kLdsPages on
     char *pool;
-    int log_b0;
-    __device__ __forceinline__ char *at(uint32_t i) const {
-        const uint32_t hi = i >> log_b0;
-        const int level = hi ? 32 - __builtin_clz(hi) : 0;
-        const uint32_t off = level ? i - (1u << (log_b0 + level - 1)) : i;
-        const uint32_t word = seg[level];
-        const uint64_t ob = (uint64_t)off << ELEM_LOG;
-        if (word & kPagedBit) {                                        // (elements never straddle a page: 16 / 64 / 128-byte units)
-            const uint32_t pg = reinterpret_cast<const uint32_t *>(pool + ((uint64_t)(word & kUnitMask) << kUnitLog))[ob >> kPageLog];
-            return pool + ((uint64_t)(pg & kUnitMask) << kUnitLog) + (ob & ((1ull << kPageLog) - 1ull));
-        }
-        return pool + ((uint64_t)(word & kUnitMask) << kUnitLog) + ob;
+    static constexpr int kPerPageLog = kPageLog - ELEM_LOG;
+    __device__ __forceinline__ char *page(uint32_t g) const {
+        const uint32_t u = g < (uint32_t)kLdsPages ? pt[g] : reinterpret_cast<const uint32_t *>(pool + ((uint64_t)(*gt & kUnitMask) << kUnitLog))[g];
+        return pool + ((uint64_t)(u & kUnitMask) << kUnitLog);
     }
-    __device__ __forceinline__ int chunk_class(int level) const { return ELEM_LOG + log_b0 + (level > 0 ? level - 1 : 0) - kUnitLog; }
+    __device__ __forceinline__ char *at(uint32_t i) const {        // (elements never straddle a page: 16 / 64 / 128-byte units)
+        if (i < base_n) return slot_base + (base_off + (i << ELEM_LOG));
+        const uint32_t j = i - base_n;
+        return page(j >> kPerPageLog) + ((uint64_t)(j & ((1u << kPerPageLog) - 1u)) << ELEM_LOG);
+    }
 };
-using NodeArr = Grow<6>;
-using HeapArr = Grow<4>;
+using NodeArr = PageArr<6>;
+using HeapArr = PageArr<4>;
+constexpr uint32_t kHashPerPageLog = kPageLog - 4;                     // 16-byte entries of one page (= one bucket of the paged table)
+constexpr uint32_t kHashPerPage = 1u << kHashPerPageLog;
 __device__ __forceinline__ ANode load_node(const ANode *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     union { uint4 v[4]; ANode n; } u;
@@ -572,22 +529,10 @@ __device__ __forceinline__ void touch_done(uint32_t a, uint32_t b, uint32_t c) {
     asm volatile("" :: "v"(a), "v"(b), "v"(c));
 }
 
-// closed set + open_hash: every lane of the group probes the same key (one request)
-template <class At>
-__device__ __forceinline__ uint32_t hash_find(const At &at, uint32_t hmask, uint64_t key, bool &found, uint32_t &val) {
-    uint32_t i = (uint32_t)mix64(key) & hmask;
-    while (true) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(at(i));
-        const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        if (k == 0) { found = false; val = kNone; return i; }
-        if (k == key) { found = true; val = v.z; return i; }
-        i = (i + 1) & hmask;
-    }
-}
+// closed set + open_hash (the probes are in the kernel: hfirst / hfind)
 __device__ __forceinline__ void hash_put(HashEnt *tab, uint32_t i, uint64_t key, uint32_t val, int32_t fval = 0) {
     *reinterpret_cast<uint4 *>(tab + i) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), val, (uint32_t)fval);
 }
-constexpr uint32_t kHashPerPageLog = kPageLog - 4;                     // 16-byte entries of one page
 
 // child descriptor cached for `key` and visible to seed `seed`, or -1
 __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_t key, int64_t seed) {
@@ -752,11 +697,11 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     using GX = Grp<G>;
     constexpr int GROUPS = GX::kGroups;
     constexpr uint32_t SPB = kAstarWaves * GROUPS;
-    extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][level tables: nodes, heap][HMM tables]
+    extern __shared__ __align__(16) unsigned char s_mem[];            // [heap tops][page tables: nodes, heap, hash][HMM tables]
     HeapEnt *const s_heap = reinterpret_cast<HeapEnt *>(s_mem);
     constexpr uint32_t kLdsHeapSlots = GX::kLdsHeap;
     uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * kLdsHeapSlots * sizeof(HeapEnt));
-    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + 2 * kMaxLevels * sizeof(uint32_t)));
+    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + kPtWords * sizeof(uint32_t)));
 
     const int dir = blockIdx.x < a.blocks_dir0 ? 0 : 1;
     HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
@@ -783,45 +728,40 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     const int64_t n_todo = dir ? a.n_todo[1] : a.n_todo[0];
     const int64_t *todo = dir ? a.todo[1] : a.todo[0];
 
-    // this slot's base arena: B0 nodes (64 B), 2 B0 heap slots (16 B), 2 B0 hash entries (16 B)
-    uint32_t *const seg = s_seg + (size_t)lslot * 2 * kMaxLevels, *const hseg = seg + kMaxLevels;
+    // this slot's base arena: B0 nodes (64 B), 2 B0 heap slots (16 B), 2 B0 hash entries (16 B); its page tables in LDS
+    uint32_t *const pt_nodes = s_seg + (size_t)lslot * kPtWords, *const pt_heap = pt_nodes + kLdsPages, *const pt_hash = pt_heap + kLdsPages,
+                    *const gt_words = pt_hash + kLdsPages;             // [0] nodes, [1] heap, [2] hash: unit of the array's table chunk (pages >= kLdsPages)
     const int log_b0 = a.log_b0;
     const uint32_t B0 = 1u << log_b0;
-    const int base_hclass = 5 + log_b0 - kUnitLog;
     char *const slot_base = a.pool.base + a.base_off + (uint64_t)slot * a.slot_bytes;
-    HashEnt *const base_hash = reinterpret_cast<HashEnt *>(slot_base + ((uint64_t)96 << log_b0));
-    if (gl == 0) {
-        seg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes) >> kUnitLog);
-        hseg[0] = (uint32_t)((a.base_off + (uint64_t)slot * a.slot_bytes + ((uint64_t)64 << log_b0)) >> kUnitLog);
-    }
-    wave_lds_fence();
+    auto base_hash_ptr = [&]() { return reinterpret_cast<HashEnt *>(slot_base + (96u << log_b0)); };   // (computed where it is used: a register less)
+#define base_hash (base_hash_ptr())
+    const uint32_t hmask0 = 2 * B0 - 1;                                // the base arena's table
     Heap<G> H;
     H.lds = s_heap + (size_t)lslot * kLdsHeapSlots;
-    H.ar.seg = hseg; H.ar.pool = a.pool.base; H.ar.log_b0 = log_b0 + 1;
+    H.ar.slot_base = slot_base; H.ar.base_off = 64u << log_b0; H.ar.base_n = 2 * B0; H.ar.pt = pt_heap; H.ar.gt = gt_words + 1; H.ar.pool = a.pool.base;
     H.gl = gl; H.gbase = gbase;
     NodeArr AR;
-    AR.seg = seg; AR.pool = a.pool.base; AR.log_b0 = log_b0;
+    AR.slot_base = slot_base; AR.base_off = 0u; AR.base_n = B0; AR.pt = pt_nodes; AR.gt = gt_words; AR.pool = a.pool.base;
     auto node_at = [&](uint32_t i) { return reinterpret_cast<ANode *>(AR.at(i)); };
 
     // ---- per-search state (uniform inside a group)
     int st = S_IDLE;
     bool need_scan = false;
     uint32_t spins = 0;
-    long long last_lim = -1;                                          // the start limit when this wave last looked (gate progress)
+    uint32_t last_lim = 0xFFFFFFFFu;                                  // (low word of) the start limit when this wave last looked (gate progress)
     long long seed = -1;
-    int64_t sid = 0;
-    uint32_t n_nodes = 0, n_heap = 0, n_keys = 0, cap_nodes = B0, cap_heap = 2 * B0;
-    int n_levels = 1, h_levels = 1;
-    HashEnt *hash = base_hash;
-    uint32_t hmask = 2 * B0 - 1;
-    int hclass = base_hclass;
-    uint32_t hunit = 0;                                               // chunk of the current table once it has left the base arena (kPagedBit: its page table)
-    // entry i of the current table: in one chunk (`hash`), or -- a table of more than 2 MB -- in the page its table names
-    auto hat = [&](uint32_t i) -> HashEnt * {
-        if (!(hunit & kPagedBit)) return hash + i;
-        const uint32_t pg = reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(hunit & kUnitMask) << kUnitLog))[i >> kHashPerPageLog];
-        return reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(pg & kUnitMask) << kUnitLog)) + (i & ((1u << kHashPerPageLog) - 1u));
-    };
+#define sid (seed * 2 + dir)                                          /* the search's id: computed, not kept (registers) */
+    uint32_t n_nodes = 0, n_heap = 0, n_keys = 0;
+    uint32_t np_nodes = 0, np_heap = 0;                               // pages of the node array / the heap: capacity = base arena + pages
+#define cap_nodes (B0 + (np_nodes << NodeArr::kPerPageLog))
+#define cap_heap (2 * B0 + (np_heap << HeapArr::kPerPageLog))
+    // the hash table: the base arena's (hp_pages == 0: hmask0 + 1 entries, linear probing), or hp_pages = (1 << hL) + hp buckets of one
+    // page each (linear hashing: a key's bucket is its hash modulo 2^hL, modulo 2^(hL+1) where that bucket has been split already;
+    // linear probing inside the bucket, starting from other bits of the hash)
+    uint32_t hp_pages = 0, hp = 0;
+    int hL = 0;
+    uint32_t own_pages = 0;                                           // pages (and table chunks) held of the pool proper, not of the reserve
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
@@ -837,6 +777,71 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     ANode curr;
     curr.score = curr.real_score = curr.max_score = 0; curr.node_id = 0; curr.parent = -1; curr.fval = 0;
     curr.state_no = curr.length = curr.negative_count = 0; curr.em_state = 0; curr.fwd_r = 0; curr.fwd_hint = kFdNone; curr.pad = 0;
+
+    auto hpage = [&](uint32_t b) -> HashEnt * {
+        const uint32_t u = b < (uint32_t)kLdsPages ? pt_hash[b] : reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b];
+        return reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(u & kUnitMask) << kUnitLog));
+    };
+    // where the probe sequence of `key` starts: table / bucket, first index; the sequence wraps inside `pmask`
+    auto hfirst = [&](uint64_t key, uint32_t &s) -> HashEnt * {
+        const uint64_t h = mix64(key);
+        if (hp_pages == 0u) { s = (uint32_t)h & hmask0; return base_hash; }
+        uint32_t b = (uint32_t)h & ((1u << hL) - 1u);
+        if (b < hp) b = (uint32_t)h & ((2u << hL) - 1u);
+        s = (uint32_t)(h >> 32) & (kHashPerPage - 1u);
+        return hpage(b);
+    };
+    auto hfind = [&](uint64_t key, bool &found, uint32_t &val) -> HashEnt * {     // every lane of the group probes the same key (one request)
+        uint32_t i;
+        HashEnt *const tab = hfirst(key, i);
+        const uint32_t pmask = hp_pages ? kHashPerPage - 1u : hmask0;
+        while (true) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tab + i);
+            const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            if (k == 0) { found = false; val = kNone; return tab + i; }
+            if (k == key) { found = true; val = v.z; return tab + i; }
+            i = (i + 1) & pmask;
+        }
+    };
+    // lane 0: page g of an array (named in LDS below kLdsPages, else in the array's table chunk, obtained with the first such page)
+    auto in_pool = [&](uint32_t u) { return a.pool.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < a.pool.reserve_off; };
+    // lane 0: page g of an array (named in LDS below kLdsPages, else in the array's table chunk, obtained with the first such page).
+    // 0 = no memory now, 1 = a page of the reserve, 2 = a page of the pool
+    auto take_page = [&](uint32_t *pt, uint32_t *gtw, uint32_t g) -> int {
+        if (g >= (uint32_t)kMaxPages) return 0;
+        if (g == (uint32_t)kLdsPages) {                                // the table chunk first
+            const uint32_t t = chunk_alloc(a.pool, 0, use_reserve);
+            if (t == kNoChunk) return 0;
+            *gtw = t;
+        }
+        const uint32_t u = chunk_alloc(a.pool, kPageClass, use_reserve);
+        if (u == kNoChunk) {
+            if (g == (uint32_t)kLdsPages) { pool_free(a.pool, 0, *gtw); }
+            return 0;
+        }
+        if (g < (uint32_t)kLdsPages) pt[g] = u;
+        else reinterpret_cast<uint32_t *>(a.pool.base + ((uint64_t)(*gtw & kUnitMask) << kUnitLog))[g] = u;
+        return in_pool(u) ? 2 : 1;
+    };
+    // (every lane) after lane 0 has written a page table: LDS words are fenced, a table chunk's line may sit in this CU's L1 from an earlier
+    // look-up of a neighbouring entry
+    auto tables_written = [&](uint32_t g) {
+        wave_lds_fence();
+        if (g >= (uint32_t)kLdsPages) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    };
+    auto free_pages = [&](const uint32_t *pt, const uint32_t *gtw, uint32_t n) {   // lane 0, after pool_release_fence()
+        for (uint32_t g = 0; g < n; ++g)
+            pool_free(a.pool, kPageClass, g < (uint32_t)kLdsPages ? pt[g] : reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(*gtw & kUnitMask) << kUnitLog))[g]);
+        if (n > (uint32_t)kLdsPages) pool_free(a.pool, 0, *gtw);
+    };
+    // everything beyond the base arena goes back to the pool (every lane of the group calls; lane 0 does it)
+    auto release_all = [&]() {
+        if (np_nodes | np_heap | hp_pages) {
+            pool_release_fence();
+            if (gl == 0) { free_pages(pt_nodes, gt_words, np_nodes); free_pages(pt_heap, gt_words + 1, np_heap); free_pages(pt_hash, gt_words + 2, hp_pages); }
+        }
+        np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0; own_pages = 0;
+    };
 
     PROF_DECL
     while (true) {
@@ -901,7 +906,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (a.gate && gl == 0) st_agent(&a.run_seed[slot], -1ll);
             } else {
                 seed = todo[qi];
-                sid = seed * 2 + dir;
                 prog_floor = 0;
                 if (a.gate) {
                     if (gl == 0) st_agent(&a.run_seed[slot], (long long)seed);
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     lim = __shfl(lim, 0, 64);
                     quit = __shfl(quit, 0, 64);
                     if (st == S_WAIT && quit) { if (gl == 0) st_agent(&a.run_seed[slot], -1ll); st = S_EXIT; }   // the pass has given up and is run again
-                    if (lim != last_lim) { last_lim = lim; spins = 0; }     // the searches ahead are getting on: a long queue is not a hang
+                    if ((uint32_t)lim != last_lim) { last_lim = (uint32_t)lim; spins = 0; }     // the searches ahead are getting on: a long queue is not a hang
                     if (st == S_WAIT && lim >= seed) st = S_START;
                     if (__ballot(st == S_WAIT) != 0ull) {
                         int refresh = 0;
@@ -992,10 +996,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
                     // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
-                    unsigned long long own = 0;                                       // (what it holds of the pool proper: the reserve is not in `used`)
-                    for (int l = 1; l < n_levels; ++l) own += level_pool_bytes(a.pool, AR.chunk_class(l), seg[l]);
-                    for (int l = 1; l < h_levels; ++l) own += level_pool_bytes(a.pool, H.ar.chunk_class(l), hseg[l]);
-                    if (hclass > base_hclass) own += level_pool_bytes(a.pool, hclass, hunit);
+                    const unsigned long long own = (unsigned long long)own_pages << kPageLog;   // (what it holds of the pool proper: the reserve is not in `used`)
                     unsigned long long used = 0;
                     if (gl == 0) used = ld_agent(&a.pool.stat[4]);
                     used = GX::bcast(used, 0, gbase);
@@ -1007,15 +1008,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         if (gl == 0) st_agent(&a.start_limit[4], 1ull);                // no further seed is taken: the pass is going to be run again
                     }
                 } else if (level >= 0 && (uint64_t)n_expanded < (256ull << (2 * level))) {
-                    if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
-                        pool_release_fence();
-                        if (gl == 0) {
-                            for (int l = 1; l < n_levels; ++l) level_free(a.pool, AR.chunk_class(l), seg[l]);
-                            for (int l = 1; l < h_levels; ++l) level_free(a.pool, H.ar.chunk_class(l), hseg[l]);
-                            if (hclass > base_hclass) level_free(a.pool, hclass, hunit);
-                        }
-                    }
-                    n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
+                    release_all();
                     if (use_reserve) {   // (it took the reserve as the lowest running search and a lower one has started since)
                         if (gl == 0) reserve_release(a.pool);
                         use_reserve = false;
@@ -1031,8 +1024,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         PROF(1)
         // ================= start node (hmm_graph_search.h:132-189)
         if (st == S_START) {
-            n_nodes = 0; n_heap = 0; n_keys = 0; cap_nodes = B0; n_levels = 1; cap_heap = 2 * B0; h_levels = 1;
-            hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
+            n_nodes = 0; n_heap = 0; n_keys = 0;
+            np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0; own_pages = 0;
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
             use_reserve = false; lowest_check = false; yield_check = false;
@@ -1041,7 +1034,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (gl == 0) off = ld_agent(&a.start_limit[14]) != 0ull;
                 order_off = GX::bcast(off, 0, gbase) != 0;
             }
-            for (uint32_t i = (uint32_t)gl; i <= hmask; i += G) hash_put(hash, i, 0ull, 0u);
+            for (uint32_t i = (uint32_t)gl; i <= hmask0; i += G) hash_put(base_hash, i, 0ull, 0u);
             const char *km = a.kmers + seed * a.klen;
             const int n_aa = a.klen / 3;
             const int sstate = forward ? a.start_state[seed] : (M - a.start_state[seed] - n_aa);   // :73
@@ -1086,18 +1079,21 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (!first && !have_curr) {
                 // pop until a node that is not closed (hmm_graph_search.h:243-257)
                 bool have = false;
-                uint32_t hs = 0, hval = kNone;
+                HashEnt *hs = nullptr;
+                uint32_t hval = kNone;
                 uint64_t hkey = 0;
                 bool hfound = false;
                 while (n_heap > 0) {
                     const HeapEnt top = H.get(0);
                     // (the node's edge needs no line of its own any more: the node carries where its Forward lands)
-                    const uint32_t t0 = touch(hat((uint32_t)mix64(top.key) & hmask)), t1 = touch(node_at(top.node));
+                    uint32_t ts;
+                    HashEnt *const tb = hfirst(top.key, ts);
+                    const uint32_t t0 = touch(tb + ts), t1 = touch(node_at(top.node));
                     H.remove_top(n_heap);
                     touch_done(t0, t1, t1);
                     --n_heap;
                     bool found;
-                    hs = hash_find(hat, hmask, top.key, found, hval);
+                    hs = hfind(top.key, found, hval);
                     if (found && (hval >> 31)) continue;                               // closed
                     cur = (int32_t)top.node;
                     hkey = top.key;
@@ -1116,8 +1112,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         ok = 1; goal = inter; stop = true;
                     } else {
                         if (gl == 0) {                                                 // closed.insert (:272); the entry keeps its node and fval
-                            if (hfound) hat(hs)->val = hval | 0x80000000u;
-                            else hash_put(hat(hs), 0u, hkey, hval | 0x80000000u);
+                            if (hfound) hs->val = hval | 0x80000000u;
+                            else hash_put(hs, 0u, hkey, hval | 0x80000000u);
                         }
                         n_closed++;
                         if (better) { inter = cur; inter_val = cv; }                   // :274-277
@@ -1133,85 +1129,104 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             // iteration keep the allocator's words -- and the memory channels they live in -- busy for everybody)
             const bool ask = starved == 0u || (starved & (starved < 1024u ? 7u : 63u)) == 0u;
             if (!stop && !ask) wait_mem = true;
-            if (!stop && !wait_mem && n_nodes + kMaxNew > cap_nodes) {
-                uint32_t unit = 0;
-                if (n_levels == 1 && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (n_nodes + kMaxNew > cap_nodes && n_levels < kMaxLevels && AR.chunk_class(n_levels) < kNumClasses) {
-                    if (gl == 0) unit = level_alloc(a.pool, AR.chunk_class(n_levels), use_reserve);
-                    unit = GX::bcast(unit, 0, gbase);
-                    if (unit == kNoChunk) break;
-                    if (gl == 0) seg[n_levels] = unit;
-                    cap_nodes = B0 << n_levels;
-                    ++n_levels;
-                }
-                wave_lds_fence();
-                if (n_nodes + kMaxNew > cap_nodes) wait_mem = true;
+            if (!stop && !wait_mem && n_nodes + kMaxNew > cap_nodes) {                 // one more page of nodes
+                if ((np_nodes | np_heap | hp_pages) == 0u && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int got = 0;
+                if (gl == 0) got = take_page(pt_nodes, gt_words, np_nodes);
+                got = GX::bcast(got, 0, gbase);
+                tables_written(np_nodes);
+                if (got) { ++np_nodes; own_pages += got == 2 ? 1u : 0u; }
+                else wait_mem = true;
             }
-            if (!stop && !wait_mem && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {
-                uint32_t unit = 0;
+            if (!stop && !wait_mem && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {    // pages of heap slots (a new block level can ask for several)
                 const uint32_t need = heap_slots_needed(n_heap + kMaxNew);
-                while (need > cap_heap && h_levels < kMaxLevels && H.ar.chunk_class(h_levels) < kNumClasses) {
-                    if (gl == 0) unit = level_alloc(a.pool, H.ar.chunk_class(h_levels), use_reserve);
-                    unit = GX::bcast(unit, 0, gbase);
-                    if (unit == kNoChunk) break;
-                    if (gl == 0) hseg[h_levels] = unit;
-                    cap_heap = (2 * B0) << h_levels;
-                    ++h_levels;
+                if ((np_nodes | np_heap | hp_pages) == 0u && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (need > cap_heap) {                                              // (what was obtained is kept: the next attempt goes on from there)
+                    int got = 0;
+                    if (gl == 0) got = take_page(pt_heap, gt_words + 1, np_heap);
+                    got = GX::bcast(got, 0, gbase);
+                    tables_written(np_heap);
+                    if (!got) { wait_mem = true; break; }
+                    ++np_heap; own_pages += got == 2 ? 1u : 0u;
                 }
-                wave_lds_fence();
-                if (need > cap_heap) wait_mem = true;
             }
-            while (!stop && !wait_mem && (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask + 1) {
-                uint32_t unit = kNoChunk;
-                if (hclass + 1 < kNumClasses && hmask < 0x7FFFFFFFu) {
-                    if (gl == 0) unit = level_alloc(a.pool, hclass + 1, use_reserve);
-                    unit = GX::bcast(unit, 0, gbase);
+            // the hash table: out of the base arena into one bucket when that is half full; then a third full on average (the buckets not yet
+            // split in the current round hold up to twice the average): one bucket is split per step
+            while (!stop && !wait_mem && (hp_pages == 0u ? (uint64_t)(n_keys + kMaxNew) * 2 > (uint64_t)hmask0 + 1
+                                                         : (uint64_t)(n_keys + kMaxNew) * 3 > (uint64_t)hp_pages * kHashPerPage)) {
+                if ((np_nodes | np_heap | hp_pages) == 0u && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool first_bucket = hp_pages == 0u;
+                const uint32_t b_old = hp, b_new = hp_pages;                           // the bucket that is split, the bucket it splits into
+                // lane 0: the new page(s).  uA takes the place of the split bucket (or is the first bucket), uB is the new bucket
+                uint32_t uA = kNoChunk, uB = kNoChunk, tnew = kNoChunk;
+                if (gl == 0 && b_new < (uint32_t)kMaxPages) {
+                    bool ok_t = true;
+                    if (b_new == (uint32_t)kLdsPages) { tnew = chunk_alloc(a.pool, 0, use_reserve); ok_t = tnew != kNoChunk; }
+                    if (ok_t) {
+                        uA = chunk_alloc(a.pool, kPageClass, use_reserve);
+                        if (uA != kNoChunk && !first_bucket) {
+                            uB = chunk_alloc(a.pool, kPageClass, use_reserve);
+                            if (uB == kNoChunk) { pool_free(a.pool, kPageClass, uA); uA = kNoChunk; }
+                        }
+                        if (uA == kNoChunk && tnew != kNoChunk) { pool_free(a.pool, 0, tnew); tnew = kNoChunk; }
+                    }
                 }
-                if (unit == kNoChunk) { wait_mem = true; break; }
-                // entry j of the NEW table (one chunk, or pages named by its table)
-                HashEnt *const nt = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(unit & kUnitMask) << kUnitLog));
-                const bool npaged = (unit & kPagedBit) != 0u;
-                auto nat = [&](uint32_t j) -> HashEnt * {
-                    if (!npaged) return nt + j;
-                    const uint32_t pg = reinterpret_cast<const uint32_t *>(nt)[j >> kHashPerPageLog];
-                    return reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(pg & kUnitMask) << kUnitLog)) + (j & ((1u << kHashPerPageLog) - 1u));
-                };
-                const uint32_t nmask = hmask * 2 + 1;
-                for (uint64_t p0 = 0; p0 <= nmask; p0 += (1ull << kHashPerPageLog)) {   // cleared page by page (one table look-up per page)
-                    HashEnt *pg = nat((uint32_t)p0);
-                    const uint64_t cnt = (uint64_t)nmask + 1 - p0 < (1ull << kHashPerPageLog) ? (uint64_t)nmask + 1 - p0 : (1ull << kHashPerPageLog);
-                    for (uint64_t i = (uint64_t)gl; i < cnt; i += G) hash_put(pg, (uint32_t)i, 0ull, 0u);
-                }
+                uA = GX::bcast(uA, 0, gbase); uB = GX::bcast(uB, 0, gbase);
+                if (uA == kNoChunk) { wait_mem = true; break; }
+                HashEnt *const pa = reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(uA & kUnitMask) << kUnitLog));
+                HashEnt *const pb = first_bucket ? pa : reinterpret_cast<HashEnt *>(a.pool.base + ((uint64_t)(uB & kUnitMask) << kUnitLog));
+                for (uint32_t i = (uint32_t)gl; i < kHashPerPage; i += G) { hash_put(pa, i, 0ull, 0u); if (!first_bucket) hash_put(pb, i, 0ull, 0u); }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (uint64_t i0 = 0; i0 <= hmask; i0 += G) {                          // every lane moves one entry; slots are claimed at the L2
-                    const uint64_t i = i0 + gl;
-                    if (i <= hmask) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(hat((uint32_t)i));
+                const HashEnt *const src = first_bucket ? base_hash : hpage(b_old);
+                const uint32_t n_src = first_bucket ? hmask0 + 1u : kHashPerPage;
+                for (uint32_t i0 = 0; i0 < n_src; i0 += G) {                           // every lane moves one entry; slots are claimed at the L2
+                    const uint32_t i = i0 + (uint32_t)gl;
+                    if (i < n_src) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
                         const unsigned long long k = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
                         if (k != 0ull) {
-                            uint32_t j = (uint32_t)mix64(k) & nmask;
+                            const uint64_t h = mix64(k);
+                            HashEnt *const dst = (!first_bucket && (((uint32_t)h >> hL) & 1u)) ? pb : pa;
+                            uint32_t j = (uint32_t)(h >> 32) & (kHashPerPage - 1u);
                             while (true) {
-                                HashEnt *e = nat(j);
                                 unsigned long long expect = 0ull;
-                                if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&e->key), &expect, k, __ATOMIC_RELAXED,
+                                if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&dst[j].key), &expect, k, __ATOMIC_RELAXED,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                    __hip_atomic_store(&e->val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_store(&e->fval, (int32_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&dst[j].val, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&dst[j].fval, (int32_t)v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     break;
                                 }
-                                j = (j + 1) & nmask;
+                                j = (j + 1) & (kHashPerPage - 1u);
                             }
                         }
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new table was filled behind this CU's L1
-                if (hclass > base_hclass) {
-                    pool_release_fence();
-                    if (gl == 0) level_free(a.pool, hclass, hunit);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new pages were filled behind this CU's L1
+                // the tables: bucket b_old -> uA, bucket b_new -> uB; the old page goes back
+                int delta = 0;
+                if (!first_bucket) pool_release_fence();
+                if (gl == 0) {
+                    auto put = [&](uint32_t b, uint32_t u) {
+                        if (b < (uint32_t)kLdsPages) pt_hash[b] = u;
+                        else reinterpret_cast<uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b] = u;
+                    };
+                    if (tnew != kNoChunk) gt_words[2] = tnew;
+                    if (first_bucket) { put(0u, uA); delta = in_pool(uA) ? 1 : 0; }
+                    else {
+                        const uint32_t u_old = b_old < (uint32_t)kLdsPages ? pt_hash[b_old]
+                                             : reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b_old];
+                        put(b_old, uA); put(b_new, uB);
+                        delta = (in_pool(uA) ? 1 : 0) + (in_pool(uB) ? 1 : 0) - (in_pool(u_old) ? 1 : 0);
+                        pool_free(a.pool, kPageClass, u_old);
+                    }
+                    __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (gl == 0) __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hash = nt; hmask = nmask; ++hclass; hunit = unit;
+                delta = GX::bcast(delta, 0, gbase);
+                own_pages = (uint32_t)((int)own_pages + delta);
+                tables_written(b_new);
+                if (first_bucket) { hp_pages = 1; hL = 0; hp = 0; }
+                else { ++hp_pages; ++hp; if (hp == (1u << hL)) { ++hL; hp = 0; } }
             }
 
             have_curr = false;
@@ -1277,14 +1292,17 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 };
                 // the probes of one expansion are independent: their first loads are issued together, then resolved, then the fvals of
                 // the open-list entries they found are fetched together (three dependent round trips instead of six)
-                auto ld_slot = [&](uint32_t ii) { return *reinterpret_cast<const uint4 *>(hat(ii)); };
+                const uint32_t pmask = hp_pages ? kHashPerPage - 1u : hmask0;         // probe sequences wrap inside the table / the bucket
+                auto ld_first = [&](uint64_t key, uint32_t &ii) { HashEnt *const t = hfirst(key, ii); return *reinterpret_cast<const uint4 *>(t + ii); };
                 auto resolve = [&](uint64_t key, uint32_t ii, uint4 v, int &old_fval) -> uint32_t {     // open-list node recorded for `key` (+ its fval), kNone = none
+                    const HashEnt *t = nullptr;                                       // (the table / bucket is looked up again only when the first entry is another key's)
                     while (true) {
                         const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
                         if (k == 0) return kNone;
                         if (k == key) { old_fval = (int)v.w; return v.z & kNone; }
-                        ii = (ii + 1) & hmask;
-                        v = ld_slot(ii);
+                        if (!t) { uint32_t dummy; t = hfirst(key, dummy); }
+                        ii = (ii + 1) & pmask;
+                        v = *reinterpret_cast<const uint4 *>(t + ii);
                     }
                 };
                 ANode cd;                                                              // delete child (:218-244), same in every lane
@@ -1303,9 +1321,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (del && !first) del = admissible(cd.length, cd.negative_count, cd.real_score);
                 const bool probe_d = del && !first;
                 const uint64_t key_d = make_key(cd.node_id, cd.state_no, ST_D);
-                const uint32_t slot_d = (uint32_t)mix64(key_d) & hmask;
+                uint32_t slot_d = 0;
                 uint4 vd = make_uint4(0, 0, 0, 0);
-                if (probe_d) vd = ld_slot(slot_d);
+                if (probe_d) vd = ld_first(key_d, slot_d);
 
                 // ---- commit in the reference's order: open_hash[next] = next (:331) and open.push (:335), codon by codon
                 // (ascending (first edge, second edge), then third edge), match before insert, delete last
@@ -1314,8 +1332,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     he.key = key; he.fval = fval; he.node = node;
                     if (!first) {
                         bool found; uint32_t val;
-                        const uint32_t hs = hash_find(hat, hmask, key, found, val);
-                        if (gl == 0) hash_put(hat(hs), 0u, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
+                        HashEnt *const hs = hfind(key, found, val);
+                        if (gl == 0) hash_put(hs, 0u, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
                         if (!found) ++n_keys;
                         n_opened++;
                     }
@@ -1418,10 +1436,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                                 open_m = open_m && admissible(cm.length, cm.negative_count, cm.real_score);
                                 open_i = open_i && admissible(cin.length, cin.negative_count, cin.real_score);
                                 const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
-                                const uint32_t slot_m = (uint32_t)mix64(key_m) & hmask, slot_i = (uint32_t)mix64(key_i) & hmask;
+                                uint32_t slot_m = 0, slot_i = 0;
                                 uint4 vm = make_uint4(0, 0, 0, 0), vi = vm;
-                                if (open_m) vm = ld_slot(slot_m);
-                                if (open_i) vi = ld_slot(slot_i);
+                                if (open_m) vm = ld_first(key_m, slot_m);
+                                if (open_i) vi = ld_first(key_i, slot_i);
                                 uint32_t om = kNone, oi = kNone;
                                 int old_m = 0, old_i = 0;
                                 if (open_m) om = resolve(key_m, slot_m, vm, old_m);
@@ -1544,15 +1562,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 a.status[sid] = status;
             }
             // everything above the base arena goes back to the pool
-            if (n_levels > 1 || h_levels > 1 || hclass > base_hclass) {
-                pool_release_fence();
-                if (gl == 0) {
-                    for (int l = 1; l < n_levels; ++l) level_free(a.pool, AR.chunk_class(l), seg[l]);
-                    for (int l = 1; l < h_levels; ++l) level_free(a.pool, H.ar.chunk_class(l), hseg[l]);
-                    if (hclass > base_hclass) level_free(a.pool, hclass, hunit);
-                }
-            }
-            n_levels = 1; cap_nodes = B0; h_levels = 1; cap_heap = 2 * B0; hash = base_hash; hmask = 2 * B0 - 1; hclass = base_hclass; hunit = 0;
+            release_all();
             if (use_reserve) {           // the reserve's owner ends: all of it is free for the next lowest search
                 if (gl == 0) reserve_release(a.pool);
                 use_reserve = false;
@@ -1568,6 +1578,10 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         PROF(9)
     }
     PROF_FLUSH
+#undef base_hash
+#undef sid
+#undef cap_nodes
+#undef cap_heap
 }
 
 }  // namespace mgta

@@ -231,3 +231,29 @@ def test_forward_of_minus_edge_before_first_plain_symbol_of_its_line(ctx, oracle
             nxt = next((x for x in range(e, og.size) if W(x) == c - 4), None)
             needed += nxt is not None and (og.forward(e) >> 6) < (og.forward(nxt) >> 6)
     assert needed >= 1
+
+
+def test_stream_kept_on_the_device_only_and_downloaded_in_one_piece(ctx, golden_dir):
+    """mgta_ctx_keep_stream(ctx, 2) + mgta_sdbg_stream_detach / mgta_stream_download (what `megagta buildgraph` does in the driver's
+    worker): a build forced into several bucket-range passes hands the sink counts and large multiplicities only, the graph is packed from
+    the resident stream, and the stream downloaded afterwards is the one an ordinary build hands over pass by pass"""
+    from megagta_amd import api
+    packed, start = readlib.load_for_build(os.path.join(golden_dir, "ragged", "reads.lib"))
+    rd = ctx.upload_reads(packed, start)
+    want = ctx.build_sdbg(rd, 29)
+    try:
+        ctx.set_mem_limit(6 << 20)                                     # several passes
+        ctx.keep_stream(2)
+        got = ctx.build_sdbg(rd, 29)
+        assert got.stats["n_passes"] > 1 and got.records.size == 0 and got.tips.size == 0      # nothing crossed the bus pass by pass
+        assert np.array_equal(got.bucket_items, want.bucket_items) and np.array_equal(got.large, want.large)
+        g = api.Graph(ctx, None, 29)                                   # packed from the resident stream
+        assert g.size == want.records.size
+        recs, tips = ctx.detach_stream()
+        assert np.array_equal(recs, want.records) and np.array_equal(tips, want.tips)
+        with pytest.raises(api.MegaGtaError):                          # the context has forgotten the stream
+            ctx.detach_stream()
+        g.free()
+    finally:
+        ctx.keep_stream(False)
+        ctx.set_mem_limit(0)
