@@ -10,9 +10,9 @@
 //     reference's order); the top levels sit in LDS; a pop reads log2(G) levels of sibling PAIRS per memory round trip;
 //   * closed set + open_hash: one open-addressing table, empty = key 0;
 //   * node pool, heap and hash table GROW IN PLACE (PoolST / HashMapST of the reference have no bound: pool_st.h:43,
-//     hash_table_st.h:559-568): node index -> (level, offset) with level l >= 1 covering [B0 << (l-1), B0 << l), one chunk per
-//     level drawn from a device-side pool (bump pointer + per-size free lists); the hash table is re-hashed into a table of
-//     twice the size when half full.  Nothing is ever re-run; a search fails (status 2) only when the pool itself is exhausted.
+//     hash_table_st.h:559-568): beyond the slot's base arena one 2 MB page at a time from a device-side pool (bump pointer + one free
+//     list of pages); the hash table by linear hashing, one page-sized bucket split per step.  Nothing is ever re-run for lack of a
+//     LARGE piece of memory; what happens when the pool itself runs dry is described at AstarArgs / in astar.hip.
 #pragma once
 #include "common.hpp"
 #include "device_utils.hpp"

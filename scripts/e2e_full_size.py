@@ -50,6 +50,31 @@ try:
     import threading
     done = threading.Event()
 
+    def janitor():
+        """the box's scratch disk holds 84 GB and a 100 M-read run writes more (reads.fa 16 GB, the library 4 GB, three graphs of 12-13 GB,
+        11 GB of intermediate contigs, 10 GB of raw + 10 GB of filtered contigs): what no later step reads is removed as the run passes it --
+        reads.fa once the library is built, a k's graph files once the next k is being built (its contigs stay)"""
+        log = d + "/out/log"
+        gone = set()
+        while not done.wait(5):
+            try:
+                txt = open(log, errors="replace").read()
+            except OSError:
+                continue
+            for mark, paths in (("Building sdbg for k = 29", [d + "/reads.fa"]), ("Building sdbg for k = 35", [d + "/out/k29/29.sdbg"]),
+                                ("Building sdbg for k = 44", [d + "/out/k35/35.sdbg"])):
+                if mark in txt and mark not in gone:
+                    gone.add(mark)
+                    freed = 0
+                    for pth in paths:
+                        for f in ([pth] if os.path.isfile(pth) else [os.path.join(os.path.dirname(pth), x) for x in os.listdir(os.path.dirname(pth)) if x.startswith(os.path.basename(pth) + ".")]):
+                            try:
+                                freed += os.path.getsize(f); os.remove(f)
+                            except OSError:
+                                pass
+                    print(f"  janitor: '{mark}' reached, {freed / 1e9:.1f} GB of files no later step reads removed", flush=True)
+    threading.Thread(target=janitor, daemon=True).start()
+
     def heartbeat():                                                    # (a line a minute: a silent call is taken to be hung)
         while not done.wait(60):
             print(f"  driver running: {time.time() - t:.0f} s", flush=True)

@@ -1,10 +1,11 @@
 """Parity above toy size: 1 M reads x 150 bp (rplB + nirK, 500 genomes, 53 M edges), every stage of the hot path against the REFERENCE
 BINARY run on the same box on the same files (oracle/_ref/megagta; about a minute and a half of its time):
-  buildgraph  edge stream bit-exact
+  buildgraph  edge stream bit-exact, with `-m 1`, `-m 2 --need_mercy` and `-m 3` (stage 1: stream + `.counting`)
   denovo      contigs byte-identical to the reference's one-thread run
   findstart   the same seed lines
-  search      the default mode of `megagta search` (ordered-commit window + cost term) against the reference's sequential `search ... 1`
-              on 5000 + 1000 seeds: equal as multisets up to a measured, asserted fraction; window 1 on a prefix of the seeds byte-identical
+  search      window 1 on a prefix of the seeds byte-identical to the reference's sequential `search ... 1`; the default mode of `megagta search`
+              (ordered-commit window + cost term) on 5000 + 1000 seeds EQUAL, seed by seed, to the oracle's restatement of that rule, the oracle's
+              sequential run equal to the reference's `search ... 1` on the same seeds, and the seeds on which the two differ classified
 The size-only class of bug (a dispatch of more than 2^32 work-items, 32-bit edge ids) needs 100 M reads and is covered by bench.py's
 sampled membership leg; this test is the largest reference-compared input."""
 import hashlib
