@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <parallel/algorithm>
 #include <atomic>
 #include <map>
 #include <memory>
@@ -613,7 +614,8 @@ static int main_findstart(int argc, char **argv) {
     if (seeds.size() >= (1ull << 32)) die("findstart: too many hits (%zu)", seeds.size());
     std::vector<uint32_t> order(seeds.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    // (a total order -- ties broken by the scan index -- so the parallel sort gives the one result; 36 M hits at 100 M reads: 9 s on one thread)
+    __gnu_parallel::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         const Seed &x = seeds[a], &y = seeds[b];
         if (x.w[0] != y.w[0]) return x.w[0] < y.w[0];
         if (x.w[1] != y.w[1]) return x.w[1] < y.w[1];
