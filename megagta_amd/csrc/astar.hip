@@ -402,6 +402,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // of a batch's first minute a hundredfold -- so ordered batches stop admitting at a third: what is in flight then has room
             // to triple.  (In the steady state of a batch a few hundred MB are in use and neither limit is ever met.)
             a.pool.soft_limit = gated ? dyn / 3 : dyn / 2;
+            if (const char *e = getenv("MGTA_ASTAR_SOFT_DIV")) a.pool.soft_limit = dyn / (uint64_t)std::max(1, atoi(e));   // (experiments)
             a.gate = gated;
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
