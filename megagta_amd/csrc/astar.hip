@@ -292,7 +292,11 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         // direction at a time with everything).  The reference has no such limit to hit: PoolST / HashMapST grow until the host is out of
         // memory (pool_st.h:43, hash_table_st.h:559-568).
         const bool gated = cache_mode > 0 && !free_share;
-        const int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 12;
+        // base arena of a slot: 8192 nodes (1 MB with its heap slots and hash table; round 3: 4096).  Beyond it a search takes 2 MB pages -- three
+        // at least --, and how many searches may be in flight is decided by the bytes they hold: with 4096 nodes the searches of 5-50 k nodes,
+        // the bulk of a 2 M-read run, held 6 MB each where they used 1.5 (reads -> contigs there: 21.0 s with 4096, 17.1 s with 8192 / 16384)
+        int log_b0 = ctx->astar_log_b0 ? ctx->astar_log_b0 : 13;
+        if (const char *e = getenv("MGTA_ASTAR_LOG_B0")) { const int v = atoi(e); if (!ctx->astar_log_b0 && v >= 7 && v <= 20) log_b0 = v; }   // (experiments)
         const uint64_t slot_bytes = 128ull << log_b0;                               // per node of the base arena: 64 B + 2 heap slots + 2 hash entries of 16 B
         AstarArenas &ar = ctx->astar;
         for (int attempt = 0; attempt < 4; ++attempt) {
@@ -398,10 +402,10 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                 a.pool.stack = w + 16 + 4 * kNumClasses;
             }
             a.base_off = 0; a.slot_bytes = slot_bytes; a.log_b0 = log_b0;
-            // admission: no new search starts while this much is in use.  A search that is admitted goes on growing -- the cold searches
-            // of a batch's first minute a hundredfold -- so ordered batches stop admitting at a third: what is in flight then has room
-            // to triple.  (In the steady state of a batch a few hundred MB are in use and neither limit is ever met.)
-            a.pool.soft_limit = gated ? dyn / 3 : dyn / 2;
+            // admission: no new search starts while half of the pool is in use.  (A third, while the arrays still doubled: what is in flight
+            // goes on growing, the cold searches of a batch's first minute a hundredfold.  With pages an overcommitted pool only makes
+            // searches wait for the next page that comes back, and a third cost the 2 M-read run 4 of its 21 s.)
+            a.pool.soft_limit = dyn / 2;
             if (const char *e = getenv("MGTA_ASTAR_SOFT_DIV")) a.pool.soft_limit = dyn / (uint64_t)std::max(1, atoi(e));   // (experiments)
             a.gate = gated;
             a.free_share = free_share;

@@ -761,7 +761,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     // linear probing inside the bucket, starting from other bits of the hash)
     uint32_t hp_pages = 0, hp = 0;
     int hL = 0;
-    uint32_t own_pages = 0;                                           // pages (and table chunks) held of the pool proper, not of the reserve
     uint32_t n_closed = 0, n_expanded = 0, n_opened = 0;     // (a search of 2^32 expansions would run for a day)
     int status = 1, partial = 0, ok = 0;
     uint32_t starved = 0;                                             // iterations this search has waited for memory
@@ -840,7 +839,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             pool_release_fence();
             if (gl == 0) { free_pages(pt_nodes, gt_words, np_nodes); free_pages(pt_heap, gt_words + 1, np_heap); free_pages(pt_hash, gt_words + 2, hp_pages); }
         }
-        np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0; own_pages = 0;
+        np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0;
     };
 
     PROF_DECL
@@ -862,8 +861,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             for (int z = 0; z < 4; ++z) __builtin_amdgcn_s_sleep(127);
         }
         bool admit = true;
+        unsigned long long used = 0;
         if (st == S_IDLE) {       // admission: searches in flight are bounded by the memory they hold, not only by the number of slots
-            unsigned long long used = 0;
             if (gl == 0) {
                 used = ld_agent(&a.pool.stat[4]);
                 if (used > ld_agent(&a.pool.stat[5])) __hip_atomic_fetch_max(&a.pool.stat[5], used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -890,7 +889,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     qi = -1;
                     for (int tries = 0; tries < 4; ++tries) {
                         if (t >= (unsigned long long)n_todo) { qi = (long long)t; break; }   // nothing left to take: the slot retires
-                        if (t - done >= (unsigned long long)a.ramp_base + done) break;
+                        // (only while the memory in use says the searches are long ones: a batch of short searches -- 2 M reads: 19.2 s
+                        // instead of 15.5 s behind the ramp -- fills its slots at once)
+                        if (t - done >= (unsigned long long)a.ramp_base + done && used * 16ull >= a.pool.soft_limit) break;
                         if (__hip_atomic_compare_exchange_strong(&a.queue[dir], &t, t + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { qi = (long long)t; break; }
                     }
                     if (qi < 0) st_agent(&a.run_seed[slot], -1ll);                       // not now: the slot stays idle
@@ -996,7 +997,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (sid == lo) {
                     // nobody is ahead of this search.  When everything the pool has handed out is its own, waiting cannot help: the pass
                     // gives up and the host starts the batch again with more room (or reports that one search does not fit the device)
-                    const unsigned long long own = (unsigned long long)own_pages << kPageLog;   // (what it holds of the pool proper: the reserve is not in `used`)
+                    // (an upper bound of what it holds of the pool proper -- the reserve's pages are not in `used` --: a search that holds
+                    // everything that is handed out cannot be helped by waiting)
+                    const unsigned long long own = (unsigned long long)(np_nodes + np_heap + hp_pages) << kPageLog;
                     unsigned long long used = 0;
                     if (gl == 0) used = ld_agent(&a.pool.stat[4]);
                     used = GX::bcast(used, 0, gbase);
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         // ================= start node (hmm_graph_search.h:132-189)
         if (st == S_START) {
             n_nodes = 0; n_heap = 0; n_keys = 0;
-            np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0; own_pages = 0;
+            np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0;
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
             use_reserve = false; lowest_check = false; yield_check = false;
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (gl == 0) got = take_page(pt_nodes, gt_words, np_nodes);
                 got = GX::bcast(got, 0, gbase);
                 tables_written(np_nodes);
-                if (got) { ++np_nodes; own_pages += got == 2 ? 1u : 0u; }
+                if (got) ++np_nodes;
                 else wait_mem = true;
             }
             if (!stop && !wait_mem && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {    // pages of heap slots (a new block level can ask for several)
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     got = GX::bcast(got, 0, gbase);
                     tables_written(np_heap);
                     if (!got) { wait_mem = true; break; }
-                    ++np_heap; own_pages += got == 2 ? 1u : 0u;
+                    ++np_heap;
                 }
             }
             // the hash table: out of the base arena into one bucket when that is half full; then a third full on average (the buckets not yet
@@ -1204,7 +1207,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the new pages were filled behind this CU's L1
                 // the tables: bucket b_old -> uA, bucket b_new -> uB; the old page goes back
-                int delta = 0;
                 if (!first_bucket) pool_release_fence();
                 if (gl == 0) {
                     auto put = [&](uint32_t b, uint32_t u) {
@@ -1212,18 +1214,15 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         else reinterpret_cast<uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b] = u;
                     };
                     if (tnew != kNoChunk) gt_words[2] = tnew;
-                    if (first_bucket) { put(0u, uA); delta = in_pool(uA) ? 1 : 0; }
+                    if (first_bucket) put(0u, uA);
                     else {
                         const uint32_t u_old = b_old < (uint32_t)kLdsPages ? pt_hash[b_old]
                                              : reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b_old];
                         put(b_old, uA); put(b_new, uB);
-                        delta = (in_pool(uA) ? 1 : 0) + (in_pool(uB) ? 1 : 0) - (in_pool(u_old) ? 1 : 0);
                         pool_free(a.pool, kPageClass, u_old);
                     }
                     __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                delta = GX::bcast(delta, 0, gbase);
-                own_pages = (uint32_t)((int)own_pages + delta);
                 tables_written(b_new);
                 if (first_bucket) { hp_pages = 1; hL = 0; hp = 0; }
                 else { ++hp_pages; ++hp; if (hp == (1u << hL)) { ++hL; hp = 0; } }
