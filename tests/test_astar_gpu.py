@@ -268,8 +268,9 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
         kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
         seen_yield, seen_resume, seen_reserve, sizes = False, False, False, []
         # (pools in KB; a search that outgrows its base arena holds three 2 MB pages at least -- nodes, heap slots, hash bucket -- so the
-        # small pools serve one or two searches at a time, through the reserve, resumed passes and the one-search-at-a-time last resort)
-        for (window, rate), pools in (((8, 0), (4096, 16384, 262144)), ((64, 4), (16384,))):
+        # small pools serve one or two searches at a time, through the reserve, resumed passes and the one-search-at-a-time last resort:
+        # 4 MB cannot hold one grown search = the loud error; 8 and 12 MB finish after two and one resumed passes; 16 MB needs none)
+        for (window, rate), pools in (((8, 0), (4096, 8192, 12288, 16384)), ((64, 4), (16384,))):
             want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
             assert st0["n_retries"] == 0
             try:

@@ -4,7 +4,7 @@ BINARY run on the same box on the same files (oracle/_ref/megagta; about a minut
   denovo      contigs byte-identical to the reference's one-thread run
   findstart   the same seed lines
   search      window 1 on a prefix of the seeds byte-identical to the reference's sequential `search ... 1`; the default mode of `megagta search`
-              (ordered-commit window + cost term) on 2000 + 800 seeds EQUAL, seed by seed, to the oracle's restatement of that rule, the oracle's
+              (ordered-commit window + cost term) on 1200 + 500 seeds EQUAL, seed by seed, to the oracle's restatement of that rule, the oracle's
               sequential run equal to the reference's `search ... 1` on the same seeds, and the seeds on which the two differ classified
 The size-only class of bug (a dispatch of more than 2^32 work-items, 32-bit edge ids) needs 100 M reads and is covered by bench.py's
 sampled membership leg; this test is the largest reference-compared input."""
@@ -105,7 +105,7 @@ def test_findstart_and_search_1m_reads_vs_reference(big, oracle):
     if not os.path.exists(d / "ours.sdbg_info"):
         pytest.skip("needs test_buildgraph_1m_reads_vs_reference")
     genes = {l.split()[0]: l.split() for l in open(d / "models" / "gene_list.txt")}
-    n_take = {"rplB": 2000, "nirK": 800}
+    n_take = {"rplB": 1200, "nirK": 500}
     for g, a in genes.items():
         r_ref, t_ref = _run([REF, "findstart", a[3], str(d / "reads.lib.bin"), "45", "16"])
         r_ours, t_ours = _run([BIN, "findstart", a[3], str(d / "reads.lib.bin"), "45", "4"])
