@@ -26,6 +26,7 @@ import argparse
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -208,7 +209,8 @@ def write_fasta_fast(reads: np.ndarray, path: str) -> None:
     rec.tofile(path)
 
 
-def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,36,45", n_large: int = 0, large_deadline: float = 0.0) -> dict:
+def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,36,45", n_large: int = 0, large_deadline: float = 0.0,
+            hard_stop: float = 0.0) -> dict:
     """reads.fa -> contigs/<gene>/{nucl,prot}_merged.fasta through megagta.py, wall seconds.  Two read sets of their own (the same
     model as the build leg's, 15x coverage each: a prefix of the 100 M reads would be a 0.3x sample of 50 000 genomes with next to
     nothing to assemble): `n_ours` reads for our driver run, and `n_ref` reads on which the reference binary runs behind the same driver
@@ -231,8 +233,21 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             fa, gl, names = sets[n]
             od = os.path.join(tmp, "out_" + tag)
             t = time.time()
-            r = subprocess.run([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env={**os.environ, **(env or {})})
+            # (last resort: the driver's call of bench.py ends at 600 s and the CPU baselines come after this leg -- a run that would carry the
+            # leg beyond `hard_stop` is ended, with its process group, and the line goes out without it)
+            p = subprocess.Popen([sys.executable, DRIVER, "-r", fa, "-g", gl, "-k", klist, "-o", od, "-c", "1"] + extra,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env={**os.environ, **(env or {})}, start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=max(5.0, hard_stop - time.time()) if hard_stop else None)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.communicate()
+                shutil.rmtree(od, ignore_errors=True)
+                raise TimeoutError(f"megagta.py ({tag}, {n} reads) was still running when the bench run was {time.time() - _T0:.0f} s old: ended, not measured")
+            r = subprocess.CompletedProcess(p.args, p.returncode, None, err)
             dt = time.time() - t
             if os.environ.get("MEGAGTA_E2E_LOG_DIR"):                   # the driver's own log (per-step times), for profiles/
                 with open(os.path.join(os.environ["MEGAGTA_E2E_LOG_DIR"], f"e2e_{tag}.log"), "w") as f:
@@ -256,22 +271,27 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                                            "note": "MEGAGTA_CACHE_WINDOW=-1: every search sees whatever paths are in the cache when it looks, as the "
                                                    "reference's multi-thread `search` does; which of several equally scored paths a seed takes depends on timing"}
         if n_ref > 0 and os.path.exists(REF):
-            # the reference binary behind the same driver.  Its best thread count is found on the small set (16 / 32 / 64; every core was
-            # 3.7x slower than 32 in round 2), then it runs ONCE on the SAME files as ours above: one equal-work ratio, nothing else
+            # the reference binary behind the same driver.  Its best thread count is found on the small set (16 / 32; every core was
+            # 3.7x slower than 32 in round 2, 64 threads 1.2x slower in round 4), then it runs ONCE on the SAME files as ours above: one equal-work ratio, nothing else
             sweep = {}
             forced = os.environ.get("MEGAGTA_E2E_REF_THREADS")          # (one-off runs at sizes where the sweep does not fit the call)
-            for threads in ([] if forced else sorted({min(cores, 16), min(cores, 32), min(cores, 64)})):
-                dtr, _ = run(n_ref, f"ref_small_t{threads}", ["--bin", REF, "-t", str(threads)])
-                sweep[threads] = dtr
-                note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
-            best_t = int(forced) if forced else min(sweep, key=sweep.get)
-            if sweep:
-                out["reference_thread_sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
-            dtr, ncr = run(n_ours, f"ref_t{best_t}", ["--bin", REF, "-t", str(best_t)])
+            best_t = int(forced) if forced else 0
+            try:
+                for threads in ([] if forced else sorted({min(cores, 16), min(cores, 32)})):     # (64 threads and every core were slower than 32 in every sweep of rounds 2-4)
+                    dtr, _ = run(n_ref, f"ref_small_t{threads}", ["--bin", REF, "-t", str(threads)])
+                    sweep[threads] = dtr
+                    note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
+                if sweep:
+                    best_t = min(sweep, key=sweep.get)
+                    out["reference_thread_sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
+                dtr, ncr = run(n_ours, f"ref_t{best_t}", ["--bin", REF, "-t", str(best_t)])
+            except TimeoutError as e:
+                out["reference"] = {"reads": n_ours, "threads": best_t, "cut_off": str(e)}
+                return out
             note(f"e2e reference, {best_t} threads: {n_ours} reads in {dtr:.1f} s")
             out["reference"] = {"reads": n_ours, "seconds": dtr, "threads": best_t, "reads_per_s": n_ours / dtr, "contigs": ncr,
                                 "note": "the reference binary behind the same driver on the SAME files as `ours`; thread count = the best of "
-                                        "16 / 32 / 64 on the small set"}
+                                        "16 / 32 on the small set"}
             out["speedup_same_sample"] = dtr / dt
             if "ours_unordered_cache" in out:
                 out["speedup_same_sample_unordered_cache"] = dtr / out["ours_unordered_cache"]["seconds"]
@@ -280,7 +300,11 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             if time.time() > large_deadline:
                 out["ours_large"] = {"reads": n_large, "skipped": "the bench run was %.0f s old when this leg was due: not started" % (time.time() - _T0)}
             else:
-                dtl, ncl = run(n_large, "ours_large", ["-t", str(min(cores, 16))])
+                try:
+                    dtl, ncl = run(n_large, "ours_large", ["-t", str(min(cores, 16))])
+                except TimeoutError as e:
+                    out["ours_large"] = {"reads": n_large, "cut_off": str(e)}
+                    return out
                 note(f"e2e ours: {n_large} reads in {dtl:.1f} s")
                 out["ours_large"] = {"reads": n_large, "seconds": dtl, "reads_per_s": n_large / dtl, "contigs": ncl,
                                      "note": "megagta.py -k %s on %d reads, default mode, ours only (the reference was not run at this size)" % (klist, n_large)}
@@ -683,7 +707,7 @@ def main():
                     time.sleep(8 if args.reads > 20_000_000 else 1)
                     note("e2e leg ...")
                     out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}", n_large=args.e2e_large_reads,
-                                         large_deadline=_T0 + 400.0)     # (the leg takes ~100 s and the CPU baselines ~45 s: the whole run stays under ten minutes)
+                                         large_deadline=_T0 + 340.0, hard_stop=_T0 + 520.0)     # (the leg takes ~100 s and the CPU baselines ~45 s after it: the driver's call ends at 600 s)
                     note("e2e leg done")
                 except Exception as e:                                   # the bench line must not die with a leg
                     out["e2e"] = {"error": str(e)[-600:]}
