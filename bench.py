@@ -707,7 +707,7 @@ def main():
                     time.sleep(8 if args.reads > 20_000_000 else 1)
                     note("e2e leg ...")
                     out["e2e"] = e2e_leg(gene_specs, args.e2e_reads, args.e2e_ref_reads, f"cuda:{local_rank}", n_large=args.e2e_large_reads,
-                                         large_deadline=_T0 + 340.0, hard_stop=_T0 + 520.0)     # (the leg takes ~100 s and the CPU baselines ~45 s after it: the driver's call ends at 600 s)
+                                         large_deadline=_T0 + 350.0, hard_stop=_T0 + 520.0)     # (the leg takes ~100 s and the CPU baselines ~45 s after it: the driver's call ends at 600 s)
                     note("e2e leg done")
                 except Exception as e:                                   # the bench line must not die with a leg
                     out["e2e"] = {"error": str(e)[-600:]}
