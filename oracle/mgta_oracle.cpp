@@ -887,7 +887,9 @@ Node *highest_score(Node *inter) {
 }
 
 // astarSearch (core loop), hmm_graph_search.h:191-343
-Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache, AstarOut &out) {
+// `lookup` = term_nodes.find (:212,279): the child recorded for a key, or null
+template <class Lookup>
+Node *astar_with(Searcher &S, const Hmm &hm, Node *start, bool forward, const Lookup &lookup, AstarOut &out) {
     out = AstarOut();
     if (start->state_no >= hm.M) { out.ok = true; return start; }           // :193-197
     static const double log2v = std::log(2);
@@ -895,10 +897,7 @@ Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache,
     std::unordered_set<Key, KeyHash> closed;
     std::unordered_map<Key, Node *, KeyHash> open_hash;
     std::vector<Node> kids;
-    auto cached_child = [&](const Node &n) -> const Key * {
-        auto it = cache.find(key_of(n));
-        return it == cache.end() ? nullptr : &it->second;
-    };
+    auto cached_child = [&](const Node &n) -> const Key * { return lookup(key_of(n)); };
     enumerate(S, hm, *start, forward, cached_child(*start), kids);         // :212-233: no pruning / dedup here
     if (start->node_id != -1) out.expanded++;
     for (Node &nx : kids) { Node *p = S.alloc(); *p = nx; open.push(p); }
@@ -944,6 +943,13 @@ Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache,
     return highest_score(inter);
 }
 
+Node *astar(Searcher &S, const Hmm &hm, Node *start, bool forward, Cache &cache, AstarOut &out) {
+    return astar_with(S, hm, start, forward, [&](const Key &k) -> const Key * {
+        auto it = cache.find(k);
+        return it == cache.end() ? nullptr : &it->second;
+    }, out);
+}
+
 // partialResultFromGoal, hmm_graph_search.h:83-110
 std::string path_string(Searcher &S, int dir, Node *goal) {
     std::string s;
@@ -984,7 +990,7 @@ inline int dna_sym(char c) {  // dna_map, hmm_graph_search.h:54-58  (N -> 3 i.e.
 }
 
 // astarSearch (start-node set-up), hmm_graph_search.h:132-189
-Node *astar_from_kmer(Searcher &S, int dir, int starting_state, const std::string &kmer, AstarOut &out) {
+Node *start_from_kmer(Searcher &S, int dir, int starting_state, const std::string &kmer) {
     const Hmm &hm = *S.hm[dir];
     bool forward = dir == 0;
     int k = S.g->k;
@@ -1011,7 +1017,10 @@ Node *astar_from_kmer(Searcher &S, int dir, int starting_state, const std::strin
     st->score = sc;
     st->real_score = rs;
     st->node_id = g_index_edge(*S.g, seq.data());
-    return astar(S, hm, st, forward, S.cache[dir], out);
+    return st;
+}
+Node *astar_from_kmer(Searcher &S, int dir, int starting_state, const std::string &kmer, AstarOut &out) {
+    return astar(S, *S.hm[dir], start_from_kmer(S, dir, starting_state, kmer), dir == 0, S.cache[dir], out);
 }
 
 void fill_result(orc_astar_result *r, const AstarOut &o, const Node *goal) {
@@ -1583,6 +1592,63 @@ int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, or
     if ((int64_t)out.size() + 1 > cap) return -2;
     memcpy(contig, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
+}
+
+
+// MODEL of speculative execution of the SEQUENTIAL sharing rule (window 1 = `search ... 1`): search i runs against the paths committed by
+// the seeds <= i - lag (what a device with `lag` searches in flight would show it), logs the keys it looked up and MISSED, and is valid
+// iff none of those keys has been committed by a seed in (i - lag, i) -- then its run is, look-up by look-up, the sequential one.  An
+// invalid search runs again against everything below it.  Counts what the scheme costs; the committed paths are always the sequential ones.
+// stats[0] searches, [1] without a missed look-up (never invalid), [2] invalid, [3] expansions of the speculative runs, [4] of the sequential
+// runs, [5] of the re-runs (= sequential runs of the invalid ones), [6] largest re-run, [7] speculative result differs from the sequential one,
+// [8] expansions of the invalid speculative runs (thrown away)
+int64_t orc_spec_model(orc_searcher *s, const char *kmers, const int32_t *start_state, int64_t n, int64_t lag, int64_t *stats) {
+    const int klen = s->g->k + 1;
+    struct Ent { Key child; int64_t owner; };
+    std::unordered_map<Key, Ent, KeyHash> tab[2];
+    for (int q = 0; q < 9; ++q) stats[q] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        std::string kmer(kmers + i * klen, kmers + (i + 1) * klen);
+        for (auto &c : kmer) c = (char)tolower(c);
+        for (int dir = 0; dir < 2; ++dir) {
+            const int st0 = dir == 0 ? start_state[i] : s->hm[1]->M - start_state[i] - klen / 3;
+            std::vector<Key> missed;
+            AstarOut o;
+            Node *g = astar_with(*s, *s->hm[dir], start_from_kmer(*s, dir, st0, kmer), dir == 0, [&](const Key &k) -> const Key * {
+                auto it = tab[dir].find(k);
+                if (it != tab[dir].end() && it->second.owner <= i - lag) return &it->second.child;
+                missed.push_back(k);
+                return nullptr;
+            }, o);
+            bool invalid = false;
+            for (const Key &k : missed) if (tab[dir].count(k)) { invalid = true; break; }
+            std::vector<std::pair<Key, Key>> path;
+            for (Node *p = g; p && p->from; p = p->from) path.push_back({key_of(*p->from), key_of(*p)});
+            stats[0]++; stats[3] += o.expanded;
+            if (missed.empty()) stats[1]++;
+            if (invalid) {
+                stats[2]++; stats[8] += o.expanded;
+                s->release();
+                AstarOut o2;
+                Node *g2 = astar_with(*s, *s->hm[dir], start_from_kmer(*s, dir, st0, kmer), dir == 0, [&](const Key &k) -> const Key * {
+                    auto it = tab[dir].find(k);
+                    return it == tab[dir].end() ? nullptr : &it->second.child;
+                }, o2);
+                std::vector<std::pair<Key, Key>> path2;
+                for (Node *p = g2; p && p->from; p = p->from) path2.push_back({key_of(*p->from), key_of(*p)});
+                if (!(path2.size() == path.size() && std::equal(path.begin(), path.end(), path2.begin(), [](const std::pair<Key, Key> &a, const std::pair<Key, Key> &b) {
+                        return a.first == b.first && a.second == b.second; }))) stats[7]++;
+                path.swap(path2);
+                stats[4] += o2.expanded; stats[5] += o2.expanded;
+                stats[6] = std::max<int64_t>(stats[6], o2.expanded);
+            } else {
+                stats[4] += o.expanded;
+            }
+            for (auto &pc : path) tab[dir].emplace(pc.first, Ent{pc.second, i});
+            s->release();
+        }
+    }
+    return 0;
 }
 
 // main_assemble (assembler.cpp:98-167) on a loaded graph; the graph's validity bits are consumed.  Returns the FASTA text

@@ -19,7 +19,9 @@ if "--bin" in a:
     time.sleep(float(os.environ.get("STAND_IN_REF_SECONDS", "0")))
 for g in genes:
     os.makedirs(os.path.join(out, "contigs", g), exist_ok=True)
-    open(os.path.join(out, "contigs", g, "nucl_merged.fasta"), "w").write(">c0\nACGT\n>c1\nACGT\n")
+    # (the stand-in "reference" writes one contig of its own: three of its four are the ones "ours" writes -- twice ACGT counts twice)
+    extra = ">c2\nTTTT\n>c3\nACGT\n" if "--bin" in a and os.environ.get("STAND_IN_REF_EXTRA") else ""
+    open(os.path.join(out, "contigs", g, "nucl_merged.fasta"), "w").write(">c0\nACGT\n>c1\nacgt\n" + extra)
 '''
 
 
@@ -68,3 +70,54 @@ def test_e2e_leg_skips_the_large_run_when_late_and_ends_a_run_at_the_hard_stop(m
     assert "seconds" in out["ours"] and "seconds" in out["ours_unordered_cache"]
     assert "cut_off" in out["reference"] and "ended, not measured" in out["reference"]["cut_off"]
     assert "ours_large" not in out and "speedup_same_sample" not in out
+
+
+def test_e2e_leg_compares_the_contigs_of_the_two_runs_not_their_number(monkeypatch, tmp_path):
+    bench = _stand_ins(monkeypatch, tmp_path)
+    out = bench.e2e_leg((("rplB", 10), ("nirK", 12)), 100, 50, "cpu", hard_stop=time.time() + 60)
+    assert out["contigs_equal_fraction"] == {"rplB": 1.0, "nirK": 1.0}                  # same sequences (case does not count)
+    monkeypatch.setenv("STAND_IN_REF_EXTRA", "1")
+    out = bench.e2e_leg((("rplB", 10),), 100, 50, "cpu", hard_stop=time.time() + 60)
+    # the reference holds ACGT x 3 + TTTT; ours ACGT x 2: two of its four contigs are matched (a multiset, not a set)
+    assert out["reference"]["contigs"] == {"rplB": 4} and out["contigs_equal_fraction"] == {"rplB": 0.5}
+    assert out["contigs_equal_fraction_ours_ordered_vs_unordered"] == {"rplB": 1.0}
+
+
+def test_search_cpu_baseline_keeps_the_thread_counts_that_survive(monkeypatch, tmp_path):
+    """the reference's `search` can die of its own race (unlocked find against a rehash): the run that crashed costs its own number only"""
+    import subprocess
+    import bench
+    from megagta_amd import synth
+    ref = tmp_path / "ref.py"
+    ref.write_text(r"""#!%s
+import os, signal, sys
+a = sys.argv[1:]
+if a[0] == "findstart":
+    for i in range(40):
+        print("dump_gene_name\tdump_seq_name\tdump\t" + "ACGT" * 11 + "A\ttrue\t1\tx\t%%d" %% (i + 1))
+elif a[0] == "search":
+    if a[-1] == "16":
+        os.kill(os.getpid(), signal.SIGSEGV)
+    sys.stderr.write("Done rplB: time %%s\n" %% {"12": "2.0", "32": "1.0"}.get(a[-1], "3.0"))
+""" % sys.executable)
+    ref.chmod(0o755)
+    probe = tmp_path / "probe"
+    probe.write_text("#!/bin/sh\necho 'seed 0 closed 100 x'\necho 'seed 1 closed 50 x'\n")
+    probe.chmod(0o755)
+    monkeypatch.setattr(bench, "REF", str(ref))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "oracle" / "_ref")
+    os.replace(probe, tmp_path / "oracle" / "_ref" / "probe")
+
+    def fake_models(genes, d):
+        os.makedirs(d, exist_ok=True)
+        p = os.path.join(d, "gene_list.txt")
+        open(p, "w").write("rplB f r a\n")
+        return p
+
+    monkeypatch.setattr(synth, "write_gene_models", fake_models)
+    monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    sb = bench.search_cpu_baseline(str(tmp_path), "g", "lib", [object()], 44, 64, n_seeds=10)
+    assert sb["cores"] == 32 and sb["seconds"] == 1.0 and set(sb["seconds_by_threads"]) == {12, 32}
+    assert list(sb["crashed_by_threads"]) == [16] and "signal 11" in sb["crashed_by_threads"][16]
+    assert sb["expansions"] == 150 + 2 * 10 and sb["value"] == 170.0
