@@ -82,6 +82,14 @@ int mgta_sort_plan(uint64_t n_items, int words_per_key, uint32_t bucket_begin, u
  * of (seed order, B, expansions_per_seed) only, never of timing. */
 int mgta_ctx_set_search_cost_rate(mgta_ctx *, int expansions_per_seed);   /* < 0 (down to -64): seeds per expansion, i.e. the path is
                                                                             * seen from seed j + B + c_j * |value| on */
+/* The same with a CONCAVE cost term: c_j expansions delay the path of seed j by cost(c_j) = c_j / expansions_per_seed seeds while
+ * c_j <= knee_expansions and by knee / expansions_per_seed + (c_j - knee) / expansions_per_seed_beyond seeds beyond (knee 0 = one rate;
+ * expansions_per_seed_beyond >= expansions_per_seed >= 1).  The first search of a gene copy on a large graph runs for millions of
+ * expansions: with one rate its path stayed invisible for as many seeds and every seed of that copy among them explored the copy cold
+ * again; beyond the knee the delay grows slowly, the seeds right behind an ordinary search still start without waiting for it.  The
+ * result is a function of (seed order, B, the three numbers) only.  (The reference has no such rule: its threads share term_nodes by
+ * timing, search.cpp:182-189; B = 1 without a cost term is its one-thread run.) */
+int mgta_ctx_set_search_cost_curve(mgta_ctx *, int expansions_per_seed, uint64_t knee_expansions, int expansions_per_seed_beyond);
 /* Work memory of the searches.  The reference's node pool, open list and hash maps grow without bound (pool_st.h:43,
  * hash_table_st.h:559-568); here every search slot owns a base arena of 1 << log2_base_nodes nodes (0 = default 12; 7..20) and a search
  * that outgrows it takes further chunks from a device-side pool of pool_bytes (0 = sized from the number of searches in flight), its

@@ -86,6 +86,7 @@ SYMBOLS = {
     "mgta_sdbg_load_files": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "mgta_sdbg_invalid_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgta_ctx_set_search_cost_rate": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgta_ctx_set_search_cost_curve": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int]),
     "mgta_ctx_set_search_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "mgta_ctx_device_memory": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mgta_ctx_keep_stream": (C.c_int, [C.c_void_p, C.c_int]),

@@ -266,14 +266,26 @@ class SeedResult:
         return self.left + kmer.lower() + self.right
 
 
+def _set_cost(ctx: "Context", cost_rate) -> None:
+    """cost_rate: an int (mgta_ctx_set_search_cost_rate) or (rate, knee, rate beyond the knee) (mgta_ctx_set_search_cost_curve)"""
+    if isinstance(cost_rate, (tuple, list)):
+        rate, knee, rate2 = (int(x) for x in cost_rate)
+        if knee:
+            check(ctx._L.mgta_ctx_set_search_cost_curve(ctx.h, rate, knee, rate2), "mgta_ctx_set_search_cost_curve")
+            return
+        cost_rate = rate
+    check(ctx._L.mgta_ctx_set_search_cost_rate(ctx.h, int(cost_rate)), "mgta_ctx_set_search_cost_rate")
+
+
 def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str], start_states, prune_len: int = 20,
-                 low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate: int = 0) -> tuple[list[SeedResult], dict]:
+                 low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate=0) -> tuple[list[SeedResult], dict]:
     """Batched HMM-guided A* (mgta_astar_batch).  start_states[i] = model position - 1 (search.cpp:157).
     cache_mode = B >= 1 shares paths between seeds: seed j's path (c_j expansions) is seen by the seeds >= j + B + c_j // cost_rate
-    (cost_rate 0: no cost term; B = 1 then is the reference's sequential run; cost_rate < 0: j + B + c_j * |cost_rate|).
+    (cost_rate 0: no cost term; B = 1 then is the reference's sequential run; cost_rate < 0: j + B + c_j * |cost_rate|;
+    cost_rate = (rate, knee, rate2): c_j // rate up to `knee` expansions, knee // rate + (c_j - knee) // rate2 beyond).
     cache_mode = -1: no ordering at all (timing-dependent, the reference's multi-thread behaviour)."""
     ctx = graph.ctx
-    check(ctx._L.mgta_ctx_set_search_cost_rate(ctx.h, int(cost_rate)), "mgta_ctx_set_search_cost_rate")
+    _set_cost(ctx, cost_rate)
     klen = graph.k + 1
     n = len(kmers)
     for s in kmers:
@@ -300,11 +312,11 @@ def astar_search(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str
 
 
 def astar_search_packed(graph: "Graph", fwd: DeviceHmm, rev: DeviceHmm, kmers: list[str], start_states, prune_len: int = 20,
-                        low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate: int = 0, want_sides: bool = False):
+                        low_cov_penalty: float = 0.5, cache_mode: int = 0, cost_rate=0, want_sides: bool = False):
     """astar_search with the results in flat arrays (mgta_astar_batch_packed): -> (contigs uint8[total], offsets int64[n + 1], stats[, sides]);
     contig i = contigs[offsets[i]:offsets[i + 1]] = left + lower-cased k-mer + right.  No Python work per seed."""
     ctx = graph.ctx
-    check(ctx._L.mgta_ctx_set_search_cost_rate(ctx.h, int(cost_rate)), "mgta_ctx_set_search_cost_rate")
+    _set_cost(ctx, cost_rate)
     klen = graph.k + 1
     n = len(kmers)
     if any(len(s) < klen for s in kmers):

@@ -259,6 +259,8 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         DevBuf d_cache[2], d_run_seed, d_run_progress, d_start_limit;
         a.window = cache_mode;
         a.cost_rate = cache_mode > 0 && !free_share ? ctx->search_cost_rate : 0;
+        a.cost_knee = a.cost_rate > 0 ? ctx->search_cost_knee : 0;
+        a.cost_rate2 = a.cost_knee ? ctx->search_cost_rate2 : 0;
         a.cache_probe_limit = 256;
         if (cache_mode > 0) {
             for (int d = 0; d < 2; ++d) {

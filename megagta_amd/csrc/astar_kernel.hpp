@@ -142,6 +142,12 @@ struct AstarArgs {
     // become visible to them any more, however soon it ends.
     int window;
     int cost_rate;
+    // the cost term is CONCAVE: c expansions delay a path by c / cost_rate seeds up to cost_knee expansions and by 1 / cost_rate2 seeds per
+    // expansion beyond (cost_knee = 0: one rate throughout).  A first-of-its-gene-copy search of millions of expansions then stays
+    // invisible for tens of thousands of seeds instead of millions -- with one rate every later seed of that copy explored it cold again --
+    // while the seeds right behind an ordinary search still start without waiting for it.
+    unsigned long long cost_knee;
+    int cost_rate2;
     int free_share;               // 1 = every path is visible to every search from the moment it is inserted (the reference's multi-thread
                                   // behaviour: fastest, but the result depends on timing); no gate
     int gate;                     // 1 = seeds start in order behind the commit frontier (the normal shared-cache launch);
@@ -577,8 +583,13 @@ __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64
 }
 
 // the cost term of the sharing rule: c expansions delay a path's visibility by c / rate seeds (rate > 0) or c * |rate| seeds (rate < 0)
-__device__ __forceinline__ long long cost_term(int rate, unsigned long long c) {
-    return rate > 0 ? (long long)(c / (unsigned)rate) : rate < 0 ? (long long)(c * (unsigned)(-rate)) : 0ll;
+__device__ __forceinline__ long long cost_term(const AstarArgs &a, unsigned long long c) {
+    const int rate = a.cost_rate;
+    if (rate > 0) {
+        if (a.cost_knee != 0ull && c > a.cost_knee) return (long long)(a.cost_knee / (unsigned)rate + (c - a.cost_knee) / (unsigned)a.cost_rate2);
+        return (long long)(c / (unsigned)rate);
+    }
+    return rate < 0 ? (long long)(c * (unsigned)(-rate)) : 0ll;
 }
 // Highest seed that may start now: no unfinished search can still become visible to it (see AstarArgs::window).  Every lane of
 // the WAVE calls it and returns the same value; start_limit keeps the maximum ever computed (the bound only grows).  The table
@@ -615,7 +626,7 @@ __device__ __forceinline__ long long start_bound(const AstarArgs &a, int dir, in
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (js[u] >= 0) {
-                const long long b = js[u] + a.window - 1 + cost_term(a.cost_rate, pr[u]);
+                const long long b = js[u] + a.window - 1 + cost_term(a, pr[u]);
                 bound = b < bound ? b : bound;
             }
     }
@@ -1547,7 +1558,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     const ANode par = load_node(node_at((uint32_t)nd.parent));
                     if (a.window > 0 && gl == 0)
                         cache_insert(a, dir, make_key(par.node_id, par.state_no, par.em_state >> 9),
-                                     order_off ? 0 : seed + a.window + cost_term(a.cost_rate, n_expanded), nd.em_state);
+                                     order_off ? 0 : seed + a.window + cost_term(a, n_expanded), nd.em_state);
                     nd = par;
                 }
                 if (gl == 0) {

@@ -75,6 +75,8 @@ struct mgta_ctx {
     uint64_t astar_pool_bytes = 0;   // device memory the searches may grow into (0 = auto)
     int search_share_num = 1, search_share_den = 1;   // share of the CUs a search batch of this context takes (mgta_ctx_set_search_share)
     int search_cost_rate = 0;    // shared-cache searches: a path found with c expansions becomes visible c / rate seeds later (0 = no cost term)
+    uint64_t search_cost_knee = 0;   // ... up to this many expansions, and 1 / search_cost_rate2 seeds per expansion beyond (0 = one rate)
+    int search_cost_rate2 = 0;
     int force_lsd_tiles = 0;     // segment-local sort: LSD passes over every digit, no finish by comparison
     uint64_t live_bytes = 0, peak_bytes = 0;
     int num_cus = 256;

@@ -58,6 +58,18 @@ int mgta_ctx_set_full_lsd(mgta_ctx *ctx, int on) {
 int mgta_ctx_set_search_cost_rate(mgta_ctx *ctx, int expansions_per_seed) {
     if (!ctx || expansions_per_seed < -64) return MGTA_EINVAL;
     ctx->search_cost_rate = expansions_per_seed;
+    ctx->search_cost_knee = 0; ctx->search_cost_rate2 = 0;
+    return MGTA_OK;
+}
+
+int mgta_ctx_set_search_cost_curve(mgta_ctx *ctx, int expansions_per_seed, uint64_t knee_expansions, int expansions_per_seed_beyond) {
+    if (!ctx || expansions_per_seed < 1 || (knee_expansions != 0 && expansions_per_seed_beyond < expansions_per_seed)) {
+        mgta::set_error("mgta_ctx_set_search_cost_curve: rate >= 1, and beyond the knee a rate >= the first one (the delay is concave in the expansions)");
+        return MGTA_EINVAL;
+    }
+    ctx->search_cost_rate = expansions_per_seed;
+    ctx->search_cost_knee = knee_expansions;
+    ctx->search_cost_rate2 = knee_expansions ? expansions_per_seed_beyond : 0;
     return MGTA_OK;
 }
 

@@ -338,6 +338,8 @@ static mgta_hmm *upload_hmm(mgta_ctx *ctx, const std::string &path) {
 // overrides (search_dist.py::window_and_rate is the same table for the multi-GPU ranks; `megagta searchplan N` prints it, tests compare)
 // an integer from the environment: unset or empty = not given; anything that is not an integer is refused (search_dist.py::_env_int is the
 // same rule for the multi-GPU ranks, so that one environment means one mode on both paths)
+constexpr long long kDefaultCostKnee = 0;        // expansions up to which the cost term runs at the plan's rate ...
+constexpr int kDefaultCostRate2 = 0;             // ... and the expansions per seed beyond (0: no knee)
 static bool env_int_strict(const char *name, int *out) {
     const char *e = getenv(name);
     if (!e || !*e) return false;
@@ -347,7 +349,7 @@ static bool env_int_strict(const char *name, int *out) {
     *out = (int)std::max(-1000000000l, std::min(1000000000l, v));
     return true;
 }
-static void search_plan(size_t ns, int *window, int *rate) {
+static void search_plan(size_t ns, int *window, int *rate, long long *knee, int *rate2) {
     int cache_window = -2;                          // < -1 = choose per gene; -1 = no ordering at all (timing-dependent, like the reference's OMP run)
     env_int_strict("MEGAGTA_CACHE_WINDOW", &cache_window);
     int cost_rate = 0;                              // MEGAGTA_CACHE_COST_RATE: see mgta_ctx_set_search_cost_rate (> 0: expansions per seed, < 0: seeds
@@ -356,6 +358,12 @@ static void search_plan(size_t ns, int *window, int *rate) {
     *window = cache_window >= -1 ? cache_window : ns < 32768 ? 1024 : ns < 65536 ? 2048 : ns < 196608 ? 4096 : 8192;
     // (window 1 without an explicit rate = the reference's sequential run: no cost term; window 0 / -1 ignore it)
     *rate = cost_rate_set ? cost_rate : *window == 1 ? 0 : (ns < 65536 ? 4 : ns < 393216 ? 2 : 1);
+    // the cost term's knee (MEGAGTA_CACHE_COST_KNEE expansions) and its rate beyond (MEGAGTA_CACHE_COST_RATE2): see mgta_ctx_set_search_cost_curve
+    int k_env = 0, r2_env = 0;
+    const bool knee_set = env_int_strict("MEGAGTA_CACHE_COST_KNEE", &k_env), r2_set = env_int_strict("MEGAGTA_CACHE_COST_RATE2", &r2_env);
+    *knee = knee_set ? std::max(0, k_env) : kDefaultCostKnee;
+    *rate2 = r2_set ? r2_env : kDefaultCostRate2;
+    if (*rate < 1 || *knee <= 0 || *rate2 <= *rate) { *knee = 0; *rate2 = 0; }           // (one rate throughout)
 }
 
 static int main_search(int argc, char **argv) {
@@ -416,9 +424,13 @@ static int main_search(int argc, char **argv) {
         //  from ~400 k seeds on one seed per expansion: 414 k seeds (10 M-read graph) 8192 + 1 12.7 s; 400 k seeds of rplB on the 100 M-read
         //  graph (profiles/r03/sweep_window_400k_100M.log): 8192 + 2 26.8 s, 8192 + 1 22.1 / 22.2 / 25.3 s, 4096 + 1 21.9 s, unordered 15.9 s
         const size_t ns = kmers.size();
-        int window = 0, rate = 0;
-        search_plan(ns, &window, &rate);
-        if (mgta_ctx_set_search_cost_rate(ctx, rate) != MGTA_OK) die("MEGAGTA_CACHE_COST_RATE must be >= -64");
+        int window = 0, rate = 0, rate2 = 0;
+        long long knee = 0;
+        search_plan(ns, &window, &rate, &knee, &rate2);
+        if ((knee ? mgta_ctx_set_search_cost_curve(ctx, rate, (uint64_t)knee, rate2) : mgta_ctx_set_search_cost_rate(ctx, rate)) != MGTA_OK)
+            die("MEGAGTA_CACHE_COST_RATE must be >= -64 (%s)", mgta_last_error());
+        logf("sharing rule: window %d, cost term %d expansions per seed%s", window, rate,
+             knee ? (" up to " + std::to_string(knee) + " expansions, " + std::to_string(rate2) + " beyond").c_str() : "");
         if (mgta_astar_batch_on(ctx, g, fw, rv, flat.data(), start.data(), (int64_t)kmers.size(), prune, pen, window, sink_contig, &fo, &st) != MGTA_OK)
             die("mgta_astar_batch: %s", mgta_last_error());
         fclose(out);
@@ -884,9 +896,10 @@ static int dispatch(int argc, char **argv) {
     }
     if (sub == "searchplan") {   // <n_seeds>...: the window and cost term `search` would take for batches of that many seeds (host only)
         for (int i = 2; i < argc; ++i) {
-            int window = 0, rate = 0;
-            search_plan((size_t)atoll(argv[i]), &window, &rate);
-            printf("%s %d %d\n", argv[i], window, rate);
+            int window = 0, rate = 0, rate2 = 0;
+            long long knee = 0;
+            search_plan((size_t)atoll(argv[i]), &window, &rate, &knee, &rate2);
+            printf("%s %d %d %lld %d\n", argv[i], window, rate, knee, rate2);
         }
         return 0;
     }

@@ -69,13 +69,28 @@ def write_fasta(path: str, gene: str, contigs, offsets) -> None:
             f.write(b"\n")
 
 
-def window_and_rate(n_seeds: int) -> tuple[int, int]:
-    """as `megagta search` (csrc/host/megagta_main.cpp): the ordered-commit window and the cost term by the number of seeds the batch
-    holds; MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE override (any integer >= -64 for the rate: < 0 = seeds per expansion)"""
+DEFAULT_COST_KNEE, DEFAULT_COST_RATE2 = 0, 0      # (kDefaultCostKnee / kDefaultCostRate2 of csrc/host/megagta_main.cpp)
+
+
+def search_plan(n_seeds: int) -> tuple[int, int, int, int]:
+    """as `megagta search` (csrc/host/megagta_main.cpp::search_plan): the ordered-commit window and the cost term (rate, knee, rate beyond
+    the knee; knee 0 = one rate) by the number of seeds the batch holds; MEGAGTA_CACHE_WINDOW / MEGAGTA_CACHE_COST_RATE /
+    MEGAGTA_CACHE_COST_KNEE / MEGAGTA_CACHE_COST_RATE2 override (any integer >= -64 for the rate: < 0 = seeds per expansion)"""
     w, r = _env_int("MEGAGTA_CACHE_WINDOW"), _env_int("MEGAGTA_CACHE_COST_RATE")
     window = w if w is not None and w >= -1 else 1024 if n_seeds < 32768 else 2048 if n_seeds < 65536 else 4096 if n_seeds < 196608 else 8192
     rate = r if r is not None else 0 if window == 1 else (4 if n_seeds < 65536 else 2 if n_seeds < 393216 else 1)     # window 1 = the sequential run: no cost term
-    return window, rate
+    k, r2 = _env_int("MEGAGTA_CACHE_COST_KNEE"), _env_int("MEGAGTA_CACHE_COST_RATE2")
+    knee = max(0, k) if k is not None else DEFAULT_COST_KNEE
+    rate2 = r2 if r2 is not None else DEFAULT_COST_RATE2
+    if rate < 1 or knee <= 0 or rate2 <= rate:
+        knee, rate2 = 0, 0
+    return window, rate, knee, rate2
+
+
+def window_and_rate(n_seeds: int):
+    """(window, cost) for api.astar_search: cost = the rate, or (rate, knee, rate2) when the plan has a knee"""
+    window, rate, knee, rate2 = search_plan(n_seeds)
+    return window, ((rate, knee, rate2) if knee else rate)
 
 
 def _env_int(name: str):

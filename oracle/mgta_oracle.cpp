@@ -784,6 +784,7 @@ struct Searcher {
     // windowed warm mode: the path seed j found with c_j expansions is seen by the seeds >= j + window + c_j / cost_rate (cost_rate 0:
     // no cost term; window 1 then == the reference's sequential sharing)
     int window = 1, cost_rate = 0;
+    int64_t cost_knee = 0; int cost_rate2 = 0;                 // concave cost term: c / rate up to the knee, knee / rate + (c - knee) / rate2 beyond (knee 0: one rate)
     int64_t seed_counter = 0;
     struct Pending { int64_t seed; int dir; Key parent, child; int em; int64_t visible_from; };
     std::vector<Pending> pending;
@@ -1552,7 +1553,8 @@ orc_searcher *orc_searcher_new(const orc_graph *g, const orc_hmm *fwd, const orc
 void orc_searcher_free(orc_searcher *s) { s->release(); delete s; }
 void orc_searcher_clear_cache(orc_searcher *s) { s->cache[0].clear(); s->cache[1].clear(); s->pending.clear(); s->seed_counter = 0; }
 void orc_searcher_set_window(orc_searcher *s, int window) { s->window = window < 1 ? 1 : window; }
-void orc_searcher_set_cost_rate(orc_searcher *s, int rate) { s->cost_rate = rate; }   // < 0: the cost term is c * |rate| (see the header)
+void orc_searcher_set_cost_rate(orc_searcher *s, int rate) { s->cost_rate = rate; s->cost_knee = 0; s->cost_rate2 = 0; }   // < 0: the cost term is c * |rate| (see the header)
+void orc_searcher_set_cost_curve(orc_searcher *s, int rate, int64_t knee, int rate2) { s->cost_rate = rate; s->cost_knee = knee; s->cost_rate2 = knee ? rate2 : 0; }
 
 int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, orc_astar_result *right, orc_astar_result *left,
                         char *contig, int64_t cap) {
@@ -1584,7 +1586,9 @@ int64_t orc_search_seed(orc_searcher *s, const char *kmer_c, int start_state, or
     for (auto &p : s->pending)
         if (p.visible_from < 0) {
             const int64_t c = p.dir == 0 ? o1.expanded : o2.expanded;
-            p.visible_from = p.seed + s->window + (s->cost_rate > 0 ? c / s->cost_rate : s->cost_rate < 0 ? c * (int64_t)(-s->cost_rate) : 0);
+            const int64_t cost = s->cost_rate > 0 ? (s->cost_knee > 0 && c > s->cost_knee ? s->cost_knee / s->cost_rate + (c - s->cost_knee) / s->cost_rate2 : c / s->cost_rate)
+                                                  : s->cost_rate < 0 ? c * (int64_t)(-s->cost_rate) : 0;
+            p.visible_from = p.seed + s->window + cost;
         }
     s->release();
     s->seed_counter++;

@@ -113,6 +113,8 @@ void orc_searcher_set_window(orc_searcher *, int window);
 /* cost term of the sharing rule: the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j / rate; 0 = none;
  * rate < 0: by the seeds >= j + window + c_j * |rate| */
 void orc_searcher_set_cost_rate(orc_searcher *, int rate);
+/* concave cost term (mgta_ctx_set_search_cost_curve): c / rate seeds up to `knee` expansions, knee / rate + (c - knee) / rate2 beyond */
+void orc_searcher_set_cost_curve(orc_searcher *, int rate, int64_t knee, int rate2);
 /* one seed = HMMGraphSearch::search [hmm_graph_search.h:60-81]; kmer is lower/upper-case ACGT of
  * length k+1; contig receives "<left><kmer><right>" (lower case).  Returns contig length or <0. */
 int64_t orc_search_seed(orc_searcher *, const char *kmer, int start_state, orc_astar_result *right,

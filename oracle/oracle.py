@@ -66,6 +66,7 @@ def lib():
         "orc_searcher_new": (vp, [vp, vp, vp, i32, dbl]), "orc_searcher_free": (None, [vp]),
         "orc_searcher_clear_cache": (None, [vp]),
         "orc_searcher_set_window": (None, [vp, i32]), "orc_searcher_set_cost_rate": (None, [vp, i32]),
+        "orc_searcher_set_cost_curve": (None, [vp, i32, C.c_int64, i32]),
         "orc_search_seed": (i64, [vp, C.c_char_p, i32, C.POINTER(AstarResult), C.POINTER(AstarResult), C.c_char_p, i64]),
     }
     for name, (res, args) in sig.items():
@@ -243,9 +244,13 @@ class Searcher:
     def clear_cache(self):
         lib().orc_searcher_clear_cache(self.h)
 
-    def set_cost_rate(self, rate: int):
-        """the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j // rate (0 = no cost term)"""
-        lib().orc_searcher_set_cost_rate(self.h, rate)
+    def set_cost_rate(self, rate):
+        """the path of seed j (c_j expansions) is seen by the seeds >= j + window + c_j // rate (0 = no cost term);
+        (rate, knee, rate2): c_j // rate up to `knee` expansions, knee // rate + (c_j - knee) // rate2 beyond"""
+        if isinstance(rate, (tuple, list)) and rate[1]:
+            lib().orc_searcher_set_cost_curve(self.h, int(rate[0]), int(rate[1]), int(rate[2]))
+        else:
+            lib().orc_searcher_set_cost_rate(self.h, int(rate[0] if isinstance(rate, (tuple, list)) else rate))
 
     def set_window(self, window: int):
         """seed j sees the paths of seeds <= j - window (1 = sequential sharing like `search ... 1`)"""

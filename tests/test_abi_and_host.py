@@ -237,23 +237,27 @@ def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
     for env in ({}, {"MEGAGTA_CACHE_WINDOW": "1"}, {"MEGAGTA_CACHE_WINDOW": "-1"}, {"MEGAGTA_CACHE_WINDOW": "64", "MEGAGTA_CACHE_COST_RATE": "-2"},
                 {"MEGAGTA_CACHE_COST_RATE": "0"}, {"MEGAGTA_CACHE_WINDOW": "1", "MEGAGTA_CACHE_COST_RATE": "3"},
                 {"MEGAGTA_CACHE_WINDOW": "", "MEGAGTA_CACHE_COST_RATE": ""}, {"MEGAGTA_CACHE_WINDOW": "-3"}, {"MEGAGTA_CACHE_WINDOW": "-2", "MEGAGTA_CACHE_COST_RATE": "-1"},
-                {"MEGAGTA_CACHE_WINDOW": "0"}, {"MEGAGTA_CACHE_WINDOW": " +16"}):     # (advisor r3: '' and values below -1 meant different modes on the two sides)
-        for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
+                {"MEGAGTA_CACHE_WINDOW": "0"}, {"MEGAGTA_CACHE_WINDOW": " +16"},      # (advisor r3: '' and values below -1 meant different modes on the two sides)
+                {"MEGAGTA_CACHE_COST_KNEE": "65536", "MEGAGTA_CACHE_COST_RATE2": "16"}, {"MEGAGTA_CACHE_COST_KNEE": "0", "MEGAGTA_CACHE_COST_RATE2": "16"},
+                {"MEGAGTA_CACHE_COST_KNEE": "4096", "MEGAGTA_CACHE_COST_RATE2": "1"}, {"MEGAGTA_CACHE_COST_RATE": "-2", "MEGAGTA_CACHE_COST_KNEE": "4096", "MEGAGTA_CACHE_COST_RATE2": "8"}):
+        for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE", "MEGAGTA_CACHE_COST_KNEE", "MEGAGTA_CACHE_COST_RATE2"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
             monkeypatch.setenv(key, v)
         out = subprocess.run([exe, "searchplan"] + [str(n) for n in ns], capture_output=True, text=True, check=True, env=dict(os.environ)).stdout.split("\n")
         got = [tuple(int(x) for x in line.split()[1:]) for line in out if line.strip()]
-        assert got == [search_dist.window_and_rate(n) for n in ns], env
+        assert got == [search_dist.search_plan(n) for n in ns], env
     for bad in ("x", "8k", "4 ", "1.5"):                                   # not an integer: refused on both sides, never read as 0
         monkeypatch.setenv("MEGAGTA_CACHE_WINDOW", bad)
         r = subprocess.run([exe, "searchplan", "1000"], capture_output=True, text=True, env=dict(os.environ))
         assert r.returncode != 0 and "MEGAGTA_CACHE_WINDOW must be an integer" in r.stderr, bad
         with pytest.raises(SystemExit, match="MEGAGTA_CACHE_WINDOW must be an integer"):
             search_dist.window_and_rate(1000)
-    for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE"):
+    for key in ("MEGAGTA_CACHE_WINDOW", "MEGAGTA_CACHE_COST_RATE", "MEGAGTA_CACHE_COST_KNEE", "MEGAGTA_CACHE_COST_RATE2"):
         monkeypatch.delenv(key, raising=False)
-    assert search_dist.window_and_rate(400_000) == (8192, 1) and search_dist.window_and_rate(100_000) == (4096, 2)
+    assert search_dist.search_plan(400_000)[:2] == (8192, 1) and search_dist.search_plan(100_000)[:2] == (4096, 2)
+    monkeypatch.setenv("MEGAGTA_CACHE_COST_KNEE", "1000"); monkeypatch.setenv("MEGAGTA_CACHE_COST_RATE2", "32")
+    assert search_dist.window_and_rate(100_000) == (4096, (2, 1000, 32))
 
 
 def test_graph_checkpoint_waits_for_the_worker_to_finish_the_files(tmp_path, monkeypatch):

@@ -191,9 +191,11 @@ def test_warm_sequential_equals_reference_search_1thread(toy, search_mode):
     assert st["n_expansions"] < sum(c["R"]["closed"] + c["L"]["closed"] for c in cold) / 3      # the cache really short-cuts
 
 
-@pytest.mark.parametrize("window,rate", [(1, 0), (4, 0), (64, 0), (1, 1), (4, 16), (16, 64), (64, 4), (8, -1), (32, -3)])   # rate < 0: c * |rate| seeds
+@pytest.mark.parametrize("window,rate", [(1, 0), (4, 0), (64, 0), (1, 1), (4, 16), (16, 64), (64, 4), (8, -1), (32, -3),   # rate < 0: c * |rate| seeds
+                                         (4, (1, 64, 16)), (16, (4, 500, 64)), (2, (2, 1, 2000))])                      # (rate, knee, rate beyond the knee)
 def test_windowed_warm_vs_oracle(ctx, oracle, window, rate):
-    """cache_mode B (+ cost rate R): the path seed j found with c_j expansions is seen by the seeds >= j + B + c_j // R (R = 0: no cost term);
+    """cache_mode B (+ cost rate R): the path seed j found with c_j expansions is seen by the seeds >= j + B + c_j // R (R = 0: no cost term;
+    (R, K, R2): c_j // R up to K expansions, K // R + (c_j - K) // R2 beyond -- mgta_ctx_set_search_cost_curve);
     deterministic whatever the GPU scheduling; == the oracle run sequentially with the same rule"""
     from megagta_amd import api
     import tempfile
