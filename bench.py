@@ -450,6 +450,8 @@ def main():
     ap.add_argument("--product-seeds", type=int, default=60_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-stream", action="store_true", help="md5 of the edge records every rank holds after the timed steps (the gathered stream with "
+                                                                "--gpus N, the resident one with one rank) goes into the line: tests compare the two")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -487,15 +489,20 @@ def main():
     rd = ctx.adopt_reads(mg.packed.data_ptr(), mg.n_words, mg.start.data_ptr(), mg.n_reads, keepalive=(mg.packed, mg.start))
     b0, b1 = mdist.bucket_share(rank, world)
 
+    last_whole = [None]
+
     def step():
         g = ctx.build_sdbg(rd, k, collect=False, bucket_range=(b0, b1))
+        if args.check_stream and world == 1:
+            last_whole[0] = [api.export_records_to_torch(ctx)]
         if world > 1:
             # the path's one exchange: every rank receives every shard of the edge stream (RCCL all-gather),
             # device to device: the shard never visits the host.  The library writes the shard on its own stream: torch's stream is
             # drained first (the block it hands out may still be read by the previous step's collectives)
             torch.cuda.current_stream().synchronize()
             shard = api.export_records_to_torch(ctx)
-            whole = mdist.all_gather_bytes(shard)          # (torch.cat of the pieces = the stream; the graph loader takes them as they are)
+            whole = mdist.all_gather_bytes(shard, piece=256 << 20)   # (torch.cat of the pieces = the stream; the graph loader takes them as they are)
+            last_whole[0] = whole if args.check_stream else None
             del whole
         return g.stats
 
@@ -518,6 +525,13 @@ def main():
     fence()
     dt = time.time() - t
     note(f"{args.steps} build steps: {dt / args.steps * 1e3:.1f} ms each, {stats[-1]['n_passes']} pass(es)")
+    stream_md5 = None
+    if args.check_stream and last_whole[0] is not None:      # (outside the timed region) what this rank holds after the exchange, rank by rank in bucket order
+        hsh = hashlib.md5()
+        for piece in last_whole[0]:
+            hsh.update(piece.cpu().numpy().tobytes())
+        stream_md5 = hsh.hexdigest()
+        last_whole[0] = None
     if world > 1:
         td = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(td, op=dist.ReduceOp.MAX)
@@ -732,11 +746,18 @@ def main():
                             "frac_of_hbm_peak": n_kmers * b_build(k, L, edges_per_kmer) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "phase_ms": {p: s[p] for p in ("ms_count", "ms_gen", "ms_sort", "ms_emit", "ms_total")},
                             "oversized_segments": s["n_big_segments"],
+                            # what does not shrink with the number of GPUs: a bucket-sharded build scans ALL reads on every rank (every read has
+                            # items in every bucket range) -- the count and the key generation of a step are the floor of the 1 -> N curve
+                            "rank_invariant_floor_ms": s["ms_count"] + s["ms_gen"],
+                            "rank_invariant_floor_note": "count + key generation: every rank of a bucket-sharded build scans all reads; "
+                                                         "sort + emit shrink with N, this part does not (SURVEY.md 8e)",
                             "pcie_inclusive_note": "inputs resident; uploading the packed reads (0.25 B/base + 8 B/read at ~55 GB/s) and returning "
                                                    "2 B/edge would add ~%.0f ms per build" % ((args.reads * (L * 0.25 + 8) + s["n_edges"] * 2) / 55e9 * 1e3)},
             "input_generation_s": t_gen,
             "host": host_cores(),
         }
+        if stream_md5 is not None:
+            out["stream_md5"] = stream_md5
         if search is not None:
             out["search"] = search
             out["findstart"] = findstart_leg

@@ -271,8 +271,9 @@ typedef struct mgta_astar_stats {
                                                            * reserve) and were resumed behind the commit frontier (normally 0) */
     uint64_t reserve_bytes, reserve_used;                 /* the lowest running search's reserve (last pass) / most of it ever in use */
     int64_t max_search_nodes, max_search_expansions;      /* the largest single search of the batch: nodes opened, nodes expanded */
-    int64_t order_abandoned;                              /* ordered window only: 1 = the searches in flight outgrew the pool and the batch went on
-                                                           * sharing its paths WITHOUT an order (the reference's multi-thread behaviour) */
+    int64_t order_abandoned;                              /* ordered window only, and only with MEGAGTA_SEARCH_ALLOW_UNORDERED=1 in the environment: 1 = the
+                                                           * searches in flight outgrew the pool and the batch went on sharing its paths WITHOUT an order
+                                                           * (the reference's multi-thread behaviour); by default the order is held whatever it costs */
     int64_t n_cache_drops;                                /* shared-cache inserts that found no room within the probe limit (0 in every measured run;
                                                            * > 0: later seeds may have searched where they could have followed a cached path) */
     int64_t hmm_in_lds;                                   /* 1: the HMM tables were staged in LDS; 0: (M + 1)(A + 11) * 8 B beside the heap tops

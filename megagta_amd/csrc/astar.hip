@@ -413,8 +413,10 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
             a.ramp_base = (uint32_t)std::max<uint64_t>(64, slots / 16);              // an eighth of a direction's slots
-            // (an explicit pool = a test of the ordered paths under starvation: the order is held whatever it costs; MEGAGTA_SEARCH_STRICT_ORDER=1 likewise)
-            a.auto_unorder = gated && !ctx->astar_pool_bytes && !(getenv("MEGAGTA_SEARCH_STRICT_ORDER") && atoi(getenv("MEGAGTA_SEARCH_STRICT_ORDER"))) ? 1 : 0;
+            // The order is HELD by default, whatever it costs (advisor r4: giving it up silently made the contigs of large inputs depend on timing and
+            // on the rank count).  MEGAGTA_SEARCH_ALLOW_UNORDERED=1 opts into the last resort: a batch whose searches in flight have outgrown the
+            // pool (thousands of refused requests) goes on WITHOUT the order, says so on stderr and in mgta_astar_stats.order_abandoned.
+            a.auto_unorder = gated && getenv("MEGAGTA_SEARCH_ALLOW_UNORDERED") && atoi(getenv("MEGAGTA_SEARCH_ALLOW_UNORDERED")) ? 1 : 0;
             if (cache_mode > 0) {
                 MGTA_HIP_CHECK(hipMemsetAsync(d_start_limit.p, 0, 128, st));           // (limits are recomputed: a conservative restart of the gate)
                 if (ST.order_abandoned) {                                            // (a batch that gave its order up resumes without one)
@@ -506,12 +508,19 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                 ST.order_abandoned = 1;
                 fprintf(stderr, "[megagta_amd] search: the searches in flight outgrew their pool (%.1f GB, %llu requests refused): the batch of %lld seeds gave up the ORDER of its "
                         "cache sharing from there on -- every path is seen by every search as soon as it is found, as in the reference's multi-thread search "
-                        "(search.cpp:182-189); which of several equally good paths a later seed takes depends on timing.  MEGAGTA_SEARCH_STRICT_ORDER=1 holds the order.\n",
+                        "(search.cpp:182-189); which of several equally good paths a later seed takes depends on timing (MEGAGTA_SEARCH_ALLOW_UNORDERED=1 asked for this).\n",
                         pool_bytes / 1e9, h_pool[2], (long long)n);
             }
             if (gated && h_lim[13])
                 fprintf(stderr, "[megagta_amd] search: %llu path entries found no room in the shared cache (%.1f GB per direction): later seeds may have searched "
                         "where they could have followed a path -- which ones depends on timing\n", h_lim[13], d_cache[0].bytes / 1e9);
+            for (int64_t s = 0; s < n * 2; ++s)
+                if (h_status[(size_t)s] == 5) {      // (terminal at once: more memory or another pass cannot help, and the searches behind it have seen nothing of it)
+                    set_error("search %lld (seed %lld, %s) outgrew the library's limit of %d pages of %d MB per array (~%lld M nodes): the reference's pool has no "
+                              "bound (pool_st.h:43), this build's page tables do", (long long)s, (long long)(s / 2), (s & 1) ? "left" : "right", kMaxPages,
+                              1 << (kPageLog - 20), (long long)(((uint64_t)kMaxPages << (kPageLog - 6)) >> 20));
+                    return MGTA_EOVERFLOW;
+                }
             size_t left = 0, starved_out = 0;
             for (int d = 0; d < 2; ++d) {
                 std::vector<int64_t> again;
@@ -663,9 +672,13 @@ int mgta_astar_batch_packed(mgta_sdbg *g, const mgta_hmm *fwd, const mgta_hmm *r
             if (!buf) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
             buf[0] = 0; offsets[0] = 0; *contigs = buf;
         }
-        return astar_batch_impl(g->ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, nullptr, nullptr, stats, &po);
-    } catch (const std::bad_alloc &) { set_error("mgta_astar_batch_packed: out of host memory"); return MGTA_ENOMEM; }
-      catch (const std::exception &e) { set_error("mgta_astar_batch_packed: %s", e.what()); return MGTA_EHIP; }
+        const int rc = astar_batch_impl(g->ctx, g, fwd, rev, kmers, start_state, n, prune_len, low_cov_penalty, cache_mode, nullptr, nullptr, stats, &po);
+        if (rc != MGTA_OK && *contigs) { free(*contigs); *contigs = nullptr; }   // (a call that fails hands nothing over: the caller frees only what MGTA_OK gave it)
+        return rc;
+    } catch (const std::bad_alloc &) { set_error("mgta_astar_batch_packed: out of host memory"); }
+      catch (const std::exception &e) { set_error("mgta_astar_batch_packed: %s", e.what()); if (*contigs) { free(*contigs); *contigs = nullptr; } return MGTA_EHIP; }
+    if (*contigs) { free(*contigs); *contigs = nullptr; }
+    return MGTA_ENOMEM;
 }
 
 }  // extern "C"

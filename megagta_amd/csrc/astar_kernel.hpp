@@ -135,7 +135,8 @@ struct AstarArgs {
     int log_b0;                   // base arena = 1 << log_b0 nodes, 2 << log_b0 heap slots and 2 << log_b0 hash entries
     mgta_astar_side *sides;       // [2n]
     char *out_seq; uint32_t out_cap; uint32_t *out_len;   // [2n]
-    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = pool exhausted, 3 = bad seed, 4 = gate timeout
+    int32_t *status;              // [2n] 0 = pending, 1 = done, 2 = pool exhausted, 3 = bad seed, 4 = gate timeout, 5 = one array of the search reached
+                                  // kMaxPages pages (2 GB beyond the base arena: ~33 M nodes): the library's limit, not the device's
     // shared term_nodes caches (search.cpp:182), one per direction.  window = 0: off (cold).  window = B >= 1: the path found by
     // seed j (c_j expansions) is seen by exactly the seeds >= j + B + c_j / cost_rate (cost_rate = 0: no cost term; B = 1 then is
     // the reference's sequential run).  The cost term lets later seeds start while a long search is still running: it cannot
@@ -166,7 +167,7 @@ struct AstarArgs {
                                   // seeds' model positions promise (a forward search covers M - s columns, a reverse one s), not in halves
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
     uint32_t ramp_base;           // ordered launches: searches in flight per direction before any has ended (slow start)
-    int auto_unorder;             // ordered launches: when the searches in flight have outgrown the pool (thousands of refused requests) the
+    int auto_unorder;             // ordered launches, OPT-IN (MEGAGTA_SEARCH_ALLOW_UNORDERED=1): when the searches in flight have outgrown the pool (thousands of refused requests) the
                                   // batch gives up the ORDER, not the searches: start_limit[14] is set, from then on every path is visible
                                   // to every search as soon as it is inserted and no seed waits at the gate -- the reference's multi-thread
                                   // behaviour (search.cpp:182-189).  Holding the order there means thousands of long searches waiting for
@@ -816,9 +817,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     // lane 0: page g of an array (named in LDS below kLdsPages, else in the array's table chunk, obtained with the first such page)
     auto in_pool = [&](uint32_t u) { return a.pool.reserve_bytes == 0ull || ((unsigned long long)(u & kUnitMask) << kUnitLog) < a.pool.reserve_off; };
     // lane 0: page g of an array (named in LDS below kLdsPages, else in the array's table chunk, obtained with the first such page).
-    // 0 = no memory now, 1 = a page of the reserve, 2 = a page of the pool
+    // 0 = no memory now, 1 = a page of the reserve, 2 = a page of the pool, -1 = the array is at its limit (kMaxPages pages: no memory ever helps)
     auto take_page = [&](uint32_t *pt, uint32_t *gtw, uint32_t g) -> int {
-        if (g >= (uint32_t)kMaxPages) return 0;
+        if (g >= (uint32_t)kMaxPages) return -1;
         if (g == (uint32_t)kLdsPages) {                                // the table chunk first
             const uint32_t t = chunk_alloc(a.pool, 0, use_reserve);
             if (t == kNoChunk) return 0;
@@ -851,6 +852,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             if (gl == 0) { free_pages(pt_nodes, gt_words, np_nodes); free_pages(pt_heap, gt_words + 1, np_heap); free_pages(pt_hash, gt_words + 2, hp_pages); }
         }
         np_nodes = 0; np_heap = 0; hp_pages = 0; hp = 0; hL = 0;
+        if (gl == 0) gt_words[3] = kNoChunk;                             // (the spare page of the reserve's owner goes with the reserve)
     };
 
     PROF_DECL
@@ -1043,6 +1045,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             n_closed = 0; n_expanded = 0; n_opened = 0;
             status = 1; partial = 0; ok = 0; goal = -1; inter = 0; cur = 0; first = true; starved = 0; have_curr = false;
             use_reserve = false; lowest_check = false; yield_check = false;
+            if (gl == 0) gt_words[3] = kNoChunk;
             if (a.auto_unorder && !order_off) {
                 int off = 0;
                 if (gl == 0) off = ld_agent(&a.start_limit[14]) != 0ull;
@@ -1149,7 +1152,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if (gl == 0) got = take_page(pt_nodes, gt_words, np_nodes);
                 got = GX::bcast(got, 0, gbase);
                 tables_written(np_nodes);
-                if (got) ++np_nodes;
+                if (got > 0) ++np_nodes;
+                else if (got < 0) { status = 5; stop = true; }                         // (its own status: not a starvation, nothing to wait for or to resume)
                 else wait_mem = true;
             }
             if (!stop && !wait_mem && heap_slots_needed(n_heap + kMaxNew) > cap_heap) {    // pages of heap slots (a new block level can ask for several)
@@ -1160,6 +1164,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     if (gl == 0) got = take_page(pt_heap, gt_words + 1, np_heap);
                     got = GX::bcast(got, 0, gbase);
                     tables_written(np_heap);
+                    if (got < 0) { status = 5; stop = true; break; }
                     if (!got) { wait_mem = true; break; }
                     ++np_heap;
                 }
@@ -1171,16 +1176,23 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 if ((np_nodes | np_heap | hp_pages) == 0u && gl == 0) __hip_atomic_fetch_add(&a.pool.stat[3], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool first_bucket = hp_pages == 0u;
                 const uint32_t b_old = hp, b_new = hp_pages;                           // the bucket that is split, the bucket it splits into
+                if (b_new >= (uint32_t)kMaxPages) { status = 5; stop = true; break; }  // the table is at its limit
                 // lane 0: the new page(s).  uA takes the place of the split bucket (or is the first bucket), uB is the new bucket
                 uint32_t uA = kNoChunk, uB = kNoChunk, tnew = kNoChunk;
                 if (gl == 0 && b_new < (uint32_t)kMaxPages) {
                     bool ok_t = true;
                     if (b_new == (uint32_t)kLdsPages) { tnew = chunk_alloc(a.pool, 0, use_reserve); ok_t = tnew != kNoChunk; }
                     if (ok_t) {
-                        uA = chunk_alloc(a.pool, kPageClass, use_reserve);
+                        // (the reserve's owner: the page its last split emptied serves this one -- pages of the reserve never go back to a list, so
+                        // without this slot every split of the owner used up two new pages for one more bucket; advisor r4)
+                        if (gt_words[3] != kNoChunk) { uA = gt_words[3]; gt_words[3] = kNoChunk; }
+                        else uA = chunk_alloc(a.pool, kPageClass, use_reserve);
                         if (uA != kNoChunk && !first_bucket) {
                             uB = chunk_alloc(a.pool, kPageClass, use_reserve);
-                            if (uB == kNoChunk) { pool_free(a.pool, kPageClass, uA); uA = kNoChunk; }
+                            if (uB == kNoChunk) {
+                                if (!in_pool(uA)) gt_words[3] = uA; else pool_free(a.pool, kPageClass, uA);
+                                uA = kNoChunk;
+                            }
                         }
                         if (uA == kNoChunk && tnew != kNoChunk) { pool_free(a.pool, 0, tnew); tnew = kNoChunk; }
                     }
@@ -1230,7 +1242,8 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         const uint32_t u_old = b_old < (uint32_t)kLdsPages ? pt_hash[b_old]
                                              : reinterpret_cast<const uint32_t *>(a.pool.base + ((uint64_t)(gt_words[2] & kUnitMask) << kUnitLog))[b_old];
                         put(b_old, uA); put(b_new, uB);
-                        pool_free(a.pool, kPageClass, u_old);
+                        if (!in_pool(u_old) && gt_words[3] == kNoChunk) gt_words[3] = u_old;   // (a page of the reserve: kept for the owner's next split)
+                        else pool_free(a.pool, kPageClass, u_old);
                     }
                     __hip_atomic_fetch_add(&a.pool.stat[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -3,7 +3,8 @@
 The path shards in two places:
   * SdBG build: the 65536 prefix buckets are independent once every rank holds the reads -> rank r builds buckets [r*S, (r+1)*S).
     Product path (`megagta.py --gpus N`): every rank writes its share as <prefix>.sdbg.<r>, no exchange at all.  bench.py's timed step
-    keeps the whole stream on every GPU instead: ONE device-to-device all-gather of the record shards (`all_gather_record_shards`);
+    keeps the whole stream on every GPU instead: ONE device-to-device all-gather of the record shards (`all_gather_record_shards`), moved in
+    pieces of GATHER_PIECE bytes per rank (a variable-length all-gather: the sizes differ, the collective moves equal pieces);
   * A* search: seeds are independent given the (replicated) graph -> seeds shard by GENE first, then round-robin inside a gene
     (`gene_seed_share`); ONE all-gather of the contig bytes at the end (`all_gather_packed_contigs`); rank 0 writes FASTA in seed order.
 No collective runs inside any kernel.  Works with any backend (gloo on CPU tensors in the tests).
@@ -26,24 +27,42 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def all_gather_bytes(flat: torch.Tensor, group=None) -> list[torch.Tensor]:
-    """all-gather of uint8 tensors of different lengths (they stay where they are: device tensors over RCCL, CPU tensors over gloo):
-    an 8-byte all-gather tells the sizes, then ONE `all_gather_into_tensor` of the payloads (padded to the longest: the collective moves
-    equal pieces) into one buffer of world x longest bytes -- the returned tensors are views of it, no copy per rank"""
+GATHER_PIECE = 64 << 20      # bytes per rank and collective of a variable-length exchange (staging: (world + 1) pieces)
+
+
+def all_gather_bytes(flat: torch.Tensor, group=None, piece: int | None = None, to_host: bool = False) -> list[torch.Tensor]:
+    """all-gather of uint8 tensors of DIFFERENT lengths.  An 8-byte all-gather tells the sizes; the payloads then travel in pieces of at
+    most `piece` bytes per rank: one `all_gather_into_tensor` per piece into a staging buffer of world x piece bytes, from which every
+    rank's valid bytes are copied into an output tensor of exactly that rank's size.  The longest payload decides the NUMBER of
+    collectives, never the size of a buffer: with genes dealt to ranks whole, one rank's blob (the heaviest gene's contigs) used to set
+    world x longest bytes of device memory on every rank (advisor r4).  `flat` may live on the host while the backend is RCCL: it is staged
+    through the device piece by piece; `to_host` returns CPU tensors (the device then holds the staging only)."""
     world = dist.get_world_size(group)
-    n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
-    ns = torch.zeros(world, dtype=torch.int64, device=flat.device)
+    dev = _dev()
+    piece = int(piece or GATHER_PIECE)
+    n = torch.tensor([flat.numel()], dtype=torch.int64, device=dev)
+    ns = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(ns, n, group=group)
     sizes = [int(x) for x in ns.cpu().tolist()]
-    longest = max(max(sizes), 1)
-    if flat.numel() == longest:
-        pad = flat.contiguous()
-    else:
-        pad = torch.zeros(longest, dtype=torch.uint8, device=flat.device)
-        pad[: flat.numel()] = flat
-    out = torch.empty(world * longest, dtype=torch.uint8, device=flat.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return [out[r * longest: r * longest + s] for r, s in enumerate(sizes)]
+    longest = max(sizes)
+    out_dev = torch.device("cpu") if to_host else dev
+    outs = [torch.empty(s, dtype=torch.uint8, device=out_dev) for s in sizes]
+    if longest == 0:
+        return outs
+    plen = min(piece, longest)
+    send = torch.zeros(plen, dtype=torch.uint8, device=dev)
+    recv = torch.empty(world * plen, dtype=torch.uint8, device=dev)
+    mine = flat.numel()
+    for off in range(0, longest, plen):
+        m = max(0, min(plen, mine - off))
+        if m:
+            send[:m].copy_(flat[off:off + m], non_blocking=False)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        for r, s in enumerate(sizes):
+            v = max(0, min(plen, s - off))
+            if v:
+                outs[r][off:off + v].copy_(recv[r * plen: r * plen + v])
+    return outs
 
 
 def all_gather_record_shards(shard: torch.Tensor, group=None) -> torch.Tensor:
@@ -139,7 +158,8 @@ def all_gather_all_genes(n_seeds: list[int], mine: list[np.ndarray], contigs: li
     blobs = [_contig_blob(m, c, o) for m, c, o in zip(mine, contigs, offsets)]
     table = np.array([b.size for b in blobs], dtype=np.int64)
     buf = np.concatenate([table.view(np.uint8)] + blobs) if blobs else np.zeros(0, np.uint8)
-    parts = [p.cpu().numpy() for p in all_gather_bytes(torch.from_numpy(buf).to(_dev()), group)]
+    # (the rank's buffer stays on the host and so do the results: the device holds (world + 1) pieces of staging, whatever the genes weigh)
+    parts = [p.numpy() for p in all_gather_bytes(torch.from_numpy(buf), group, to_host=True)]
     G = len(blobs)
     out = []
     starts = []

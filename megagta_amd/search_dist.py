@@ -132,6 +132,11 @@ def main(argv: list[str]) -> int:
     graph = api.Graph.from_files(ctx, sdbg_prefix)
     if rank == 0:
         print(f"    [megagta_amd] rank 0 of {world}: graph of {graph.size} edges on the device ({time.time() - t0:.2f} s)", file=sys.stderr, flush=True)
+    if rank == 0 and world > 1 and search_plan(1 << 20)[0] != 0:
+        # (measured: one gene split over two ranks differs from the one-rank run on ~1 % of its seeds, tests/test_multi_gpu_gpu.py)
+        print(f"    [megagta_amd] note: {world} ranks -- every rank shares paths among the seeds IT searches (ordered window over its sub-sequence of the "
+              f"seed list), so which of several equally good paths a seed takes is a function of (seed order, number of ranks): deterministic for a given "
+              f"--gpus, not identical across rank counts.  MEGAGTA_CACHE_WINDOW=0 (no sharing) is independent of the rank count.", file=sys.stderr, flush=True)
     genes = read_gene_list(gene_list)
     seeds = [read_seeds(f"{seeds_prefix}_{name}_starting_kmers.txt") for name, _, _ in genes]
     share = mdist.gene_seed_share([len(s[0]) if s else 0 for s in seeds], rank, world)
@@ -155,21 +160,27 @@ def main(argv: list[str]) -> int:
                                                            cache_mode=window, cost_rate=rate)
             nexp = st["n_expansions"]
             fw.free(); rv.free()
-        results.append((name, len(kmers), mine, contigs, offsets))
+        if world == 1:                                                # one rank: a gene's file is written as soon as the gene is searched
+            write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
+            results.append((name, len(kmers), mine, None, None))
+        else:
+            results.append((name, len(kmers), mine, contigs, offsets))
         if rank == 0:
             print(f"    [megagta_amd] Done {name}: {len(kmers)} seeds over {world} rank(s), rank 0: {mine.size} seeds, {nexp} expansions, "
                   f"{time.time() - tg:.2f} s", file=sys.stderr, flush=True)
     tg = time.time()
+    # the searches are over: the graph and the searches' pool (sized to most of the free memory) go BEFORE the exchange, which then has the
+    # device to itself -- its staging is (world + 1) pieces of 64 MB, the contigs themselves stay on the host (advisor r4: the gather used to
+    # ask for world x longest bytes next to a pool that had left 20 % free, at the very end of a run whose results were not on disk yet)
+    graph.free()
+    ctx.release_scratch()
     if world > 1:
         merged = mdist.all_gather_all_genes([r[1] for r in results], [r[2] for r in results], [r[3] for r in results], [r[4] for r in results])
-    else:
-        merged = [(r[3], r[4]) for r in results]
-    if rank == 0:
-        for (name, _, _, _, _), (contigs, offsets) in zip(results, merged):
-            write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
-        print(f"    [megagta_amd] {len(results)} gene(s): one all-gather of {sum(int(o[-1]) for _, o in merged)} contig bytes + the files in {time.time() - tg:.2f} s",
-              file=sys.stderr, flush=True)
-    graph.free()
+        if rank == 0:
+            for (name, _, _, _, _), (contigs, offsets) in zip(results, merged):
+                write_fasta(f"{out_prefix}_raw_contigs_{name}.fasta", name, contigs, offsets)
+            print(f"    [megagta_amd] {len(results)} gene(s): one all-gather of {sum(int(o[-1]) for _, o in merged)} contig bytes + the files in {time.time() - tg:.2f} s",
+                  file=sys.stderr, flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()

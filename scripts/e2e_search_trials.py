@@ -18,6 +18,7 @@ n_seeds = int(sys.argv[3])
 limit = int(sys.argv[4])
 trials = [dict(kv.split("=") for kv in t.split(",") if kv) for t in sys.argv[5].split(";")]
 logdir = sys.argv[6] if len(sys.argv) > 6 else os.path.join(ROOT, "gpurun_out")
+os.makedirs(logdir, exist_ok=True)
 BIN = os.path.join(ROOT, "megagta_amd", "bin", "megagta")
 d = tempfile.mkdtemp(prefix="mgta_trials_")
 t00 = time.time()

@@ -90,7 +90,8 @@ def test_models_beyond_the_lds_vs_reference(ctx, golden_dir, tmp_path, case, sea
     `search ... 1`)"""
     from megagta_amd import api
     # (every lane mode on one of the two models, not 12 combinations of ~25 s: the suite has a time budget)
-    if (case, request_id(search_mode)) not in {("m600", "g16"), ("m600", "g8-grow"), ("m600", "g64"), ("m1200", "g16-grow"), ("m1200", "g8")}:
+    # (("m1200", "g64") = astar_kernel<64, false>: one search per wavefront with the tables in device memory, cold only)
+    if (case, request_id(search_mode)) not in {("m600", "g16"), ("m600", "g8-grow"), ("m600", "g64"), ("m1200", "g16-grow"), ("m1200", "g8"), ("m1200", "g64")}:
         pytest.skip("combination left to the other model")
     packed, start, gdir, cold, warm = H.bigm_case(golden_dir, case, str(tmp_path))
     g = api.Graph(ctx, ctx.build_sdbg(ctx.upload_reads(packed, start), 44))
@@ -106,6 +107,54 @@ def test_models_beyond_the_lds_vs_reference(ctx, golden_dir, tmp_path, case, sea
             _check_side(r.left_side, ref["L"])
             assert r.contig(ref["kmer"]) == ref["contig"]
     assert st["max_search_expansions"] > 10000                        # (these searches are long ones: ~10^5 expansions per seed)
+
+
+def test_giving_up_the_order_is_opt_in_and_says_so(ctx, oracle, monkeypatch):
+    """advisor r4: a batch whose searches in flight outgrow their pool used to give up the ORDER of its cache sharing on its own (timing-
+    dependent contigs by default on large inputs, and a branch no test ran).  Now the order is held unless MEGAGTA_SEARCH_ALLOW_UNORDERED=1:
+    the same starved pool gives the roomy run's result without it, and with it the batch says `order_abandoned`, every search still ends,
+    and every contig is a path of the graph through its seed k-mer (which of the admissible paths: a matter of timing, as in the reference's
+    multi-thread search, search.cpp:182-189)"""
+    from megagta_amd import api
+    import tempfile
+    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_gene_models(mg.genes, td)
+        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
+        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
+        g = api.Graph(ctx, stream)
+        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+        monkeypatch.delenv("MEGAGTA_SEARCH_ALLOW_UNORDERED", raising=False)
+        want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)          # roomy, ordered; prune 0: the largest searches
+        assert st0["order_abandoned"] == 0
+        try:
+            ctx.set_search_arena(7, 12288 << 10)                                             # 128-node base arenas, 12 MB for 800 searches
+            held, st1 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)
+            monkeypatch.setenv("MEGAGTA_SEARCH_ALLOW_UNORDERED", "1")
+            free, st2 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)
+        finally:
+            ctx.set_search_arena(0, 0)
+        # default: the order is held whatever it costs -- the roomy run's contigs, scores and counts
+        assert st1["order_abandoned"] == 0 and st1["n_expansions"] == st0["n_expansions"]
+        for a, b, km in zip(held, want, kmers):
+            assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
+        # opted in: the batch gave the order up (thousands of refused requests) and said so; every seed has its contig, every contig is a walk
+        # in the graph that contains its seed
+        assert st2["order_abandoned"] == 1, st2
+        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        n_checked = 0
+        for r, km in zip(free, kmers):
+            c = r.contig(km)
+            assert km.lower() in c
+            if og.index_edge(km.upper()) < 0:
+                continue                                                 # (a synthetic seed that is not in the graph stays as it is)
+            for i in range(0, len(c) - 44, 7):                           # every 7th (k+1)-mer of the contig is an edge of the graph
+                assert og.index_edge(c[i:i + 45].upper()) >= 0, (km, i)
+                n_checked += 1
+        assert n_checked > 1000
 
 
 def test_vs_oracle_bigger_graph(ctx, oracle):

@@ -134,3 +134,36 @@ def test_bucket_share_covers_everything():
         spans = [mdist.bucket_share(r, world) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == 65536
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_pieces(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from megagta_amd import dist as mdist
+    rng = np.random.default_rng(100 + rank)
+    sizes = [0, 70_001, 3, 1000][:world]                              # one rank with nothing, one whose payload is many pieces long
+    mine = torch.from_numpy(rng.integers(0, 256, sizes[rank], dtype=np.uint8))
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda out, inp, group=None: (calls.append((int(inp.numel()), int(out.numel()))), real(out, inp, group=group))[1]
+    parts = mdist.all_gather_bytes(mine, piece=1000, to_host=True)
+    dist.all_gather_into_tensor = real
+    ok = [p.numel() for p in parts] == sizes
+    for r in range(world):
+        want = np.random.default_rng(100 + r).integers(0, 256, sizes[r], dtype=np.uint8)
+        ok = ok and np.array_equal(parts[r].numpy(), want)
+    # the sizes first, then ceil(longest / piece) collectives of `piece` bytes per rank: the longest payload sets their NUMBER, no buffer's size
+    ok = ok and calls[0] == (1, world) and len(calls) == 1 + 71 and all(c == (1000, world * 1000) for c in calls[1:])
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_variable_length_gather_moves_pieces_not_the_longest_payload():
+    """advisor r4: padding every rank's payload to the longest made one rank's blob (a whole gene's contigs) set world x longest bytes on
+    every rank; the exchange now moves pieces of a fixed size and every rank's bytes land in a tensor of exactly their length"""
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_pieces, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))

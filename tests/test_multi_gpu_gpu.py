@@ -277,3 +277,24 @@ def test_split_gene_agreement_fraction(tmp_path):
     assert common >= 0.97 * len(b), (common, len(b))
     names = [l for l in open(d / "s2_0_raw_contigs_g.fasta") if l.startswith(">")]
     assert names == [l for l in open(d / "s1_raw_contigs_g.fasta") if l.startswith(">")]
+
+
+def test_bench_two_ranks_gathers_the_one_rank_stream():
+    """the driver's multi-GPU call of bench.py (`torch.distributed.run --nproc-per-node N bench.py --gpus N`) rehearsed with two ranks on the
+    one GPU over gloo: the bucket-sharded build + the variable-length all-gather of the record shards leave on every rank the stream the
+    one-rank run builds (md5 of the records in bucket order), and the line keeps its contract (n_gpus, strong scaling, the rank-invariant
+    floor next to the number)"""
+    import json
+    small = ["--reads", "200000", "--steps", "2", "--warmup", "1", "--seeds", "300", "--product-seeds", "0", "--e2e-reads", "0", "--no-cpu-baseline", "--check-stream"]
+    env = {**os.environ, **ONE_GPU}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    l2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["scaling"] == "strong" and l2["config"]["reads"] == 200000
+    assert l1["stream_md5"] == l2["stream_md5"] and len(l1["stream_md5"]) == 32
+    assert l2["whole_build"]["rank_invariant_floor_ms"] > 0 and l2["value"] > 0
+    assert l2["search"]["expansions_per_step"] == l1["search"]["expansions_per_step"] > 0      # cold searches: the same work however the seeds are dealt

@@ -94,7 +94,7 @@ def test_findstart_and_search_1m_reads_vs_reference(big, oracle):
     if not os.path.exists(d / "ours.sdbg_info"):
         pytest.skip("needs test_buildgraph_1m_reads_vs_reference")
     genes = {l.split()[0]: l.split() for l in open(d / "models" / "gene_list.txt")}
-    n_take = {"rplB": 600, "nirK": 300}
+    n_take = {"rplB": 1200, "nirK": 600}          # (round 4: 600 + 300; the oracle's passes now run side by side)
     for g, a in genes.items():
         r_ref, t_ref = _run([REF, "findstart", a[3], str(d / "reads.lib.bin"), "45", "16"])
         r_ours, t_ours = _run([BIN, "findstart", a[3], str(d / "reads.lib.bin"), "45", "4"])
@@ -131,32 +131,43 @@ def test_findstart_and_search_1m_reads_vs_reference(big, oracle):
     # over the same seeds in the same order -- every contig equal, not only counted.  And what the seeds that differ from the
     # reference's sequential run are: each is the result of the same A* under the window's (smaller) view of the cache; most of them
     # equal the seed's COLD result (the path the sequential run took from a recent seed's cache entry was not visible yet).
+    from concurrent.futures import ThreadPoolExecutor
     from megagta_amd import search_dist
     og = oracle.Graph(oracle.Stream.read(str(d / "ours")))
-    for g, a in genes.items():
-        seeds = [l.split("\t") for l in open(d / f"s_{g}_starting_kmers.txt").read().splitlines()]
-        window, rate = search_dist.window_and_rate(len(seeds))
+    seeds_of = {g: [l.split("\t") for l in open(d / f"s_{g}_starting_kmers.txt").read().splitlines()] for g in genes}
+
+    def oracle_pass(g, window, rate):                                  # (one searcher per pass: the passes run side by side, the library holds no lock)
+        a = genes[g]
         S = oracle.Searcher(og, oracle.Hmm(a[1]), oracle.Hmm(a[2]), 20, 0.5)
         S.clear_cache(); S.set_window(window); S.set_cost_rate(rate)
-        t = time.time()
-        want = [S.search(x[3], int(x[7]) - 1, cold=False) for x in seeds]
+        return [S.search(x[3], int(x[7]) - 1, cold=False) for x in seeds_of[g]]
+
+    t = time.time()
+    plan = {g: search_dist.window_and_rate(len(seeds_of[g])) for g in genes}
+    with ThreadPoolExecutor(max_workers=2 * len(genes)) as ex:         # the product's rule and the sequential run, both genes: four passes at once
+        fut = {(g, kind): ex.submit(oracle_pass, g, *(plan[g] if kind == "rule" else (1, 0))) for g in genes for kind in ("rule", "seq")}
+        res = {key: f.result() for key, f in fut.items()}
+    t_oracle = time.time() - t
+    for g in genes:
+        want, seq = res[(g, "rule")], res[(g, "seq")]
         dflt, ref, cold = (seqs(d / f"{n}_raw_contigs_{g}.fasta") for n in ("dflt", "ref1", "cold"))
         assert [w[0] for w in want] == dflt, g                        # the product's default mode == the oracle's restatement of its rule
+        assert [w[0] for w in seq] == ref, g                          # the oracle's sequential run == the reference's `search ... 1`
         differ = [i for i, (x, y) in enumerate(zip(dflt, ref)) if x != y]
-        as_cold = sum(1 for i in differ if dflt[i] == cold[i])
-        # the differing seeds' scores next to the sequential run's (oracle, same seeds, window 1 = `search ... 1`, pinned against the
-        # reference's file above): a different view of the cache may only change WHICH admissible path is taken
-        rel = []
-        if g == "nirK":                                               # (one gene's worth of a second oracle pass: the suite has a time budget)
-            S.clear_cache(); S.set_window(1); S.set_cost_rate(0)
-            seq = [S.search(x[3], int(x[7]) - 1, cold=False) for x in seeds]
-            assert [w[0] for w in seq] == ref, g
-            rel = [abs((want[i][1].real_score + want[i][2].real_score) - (seq[i][1].real_score + seq[i][2].real_score)) /
-                   max(1e-9, abs(seq[i][1].real_score + seq[i][2].real_score)) for i in differ]
-        print(f"parity 1M search {g}: default mode (window {window}, rate {rate}) == oracle's ordered-commit restatement on all {len(seeds)} seeds "
-              f"({time.time() - t:.1f} s of oracle time); {len(differ)} seeds differ from `search ... 1`: {as_cold} of them are the seed's cold result, "
-              f"{len(differ) - as_cold} a third path; relative difference of the summed path log-probabilities: median "
-              f"{sorted(rel)[len(rel) // 2] if rel else 0:.2e}, max {max(rel) if rel else 0:.2e}")
+        # Every seed whose contig differs from the sequential run's is ACCOUNTED FOR (asserted, not printed): it is the seed's cold result (the
+        # path the sequential run followed from a recent seed's cache entry was not visible yet under the window), or another admissible path
+        # of the same summed log-probability within the north star's tolerance -- a different view of the cache may only change WHICH path of
+        # that quality is taken
+        as_cold, rel = 0, []
+        for i in differ:
+            r_ = abs((want[i][1].real_score + want[i][2].real_score) - (seq[i][1].real_score + seq[i][2].real_score)) / \
+                max(1e-9, abs(seq[i][1].real_score + seq[i][2].real_score))
+            rel.append(r_)
+            as_cold += dflt[i] == cold[i]
+            assert dflt[i] == cold[i] or r_ <= 1e-4, (g, i, seeds_of[g][i][3], r_)
+        print(f"parity 1M search {g}: default mode (window {plan[g][0]}, rate {plan[g][1]}) == oracle's ordered-commit restatement on all {len(dflt)} seeds; "
+              f"{len(differ)} seeds differ from `search ... 1`: {as_cold} of them are the seed's cold result, {len(differ) - as_cold} another path within 1e-4 of "
+              f"the sequential run's summed log-probability (largest relative difference {max(rel) if rel else 0:.2e}); four oracle passes side by side: {t_oracle:.1f} s")
 
 
 def test_denovo_1m_reads_vs_reference_one_thread(big):
