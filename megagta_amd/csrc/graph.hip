@@ -21,13 +21,15 @@
 namespace mgta {
 
 // G1: pack 64 records into a line, count ones per line: cnt[c*n_lines + line], c = 0 last, 1 tip, 2..5 symbols 1..4
-__global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, int64_t size, GLine *lines, uint64_t n_lines,
-                                                         uint32_t *cnt) {
+// (the lines [line_lo, line_hi) from the records recs[0 ...) = records rec_base ...: a graph too large to hold its records AND its lines at once
+// is packed range by range, mgta_sdbg_load_files)
+__global__ __launch_bounds__(256) void graph_pack_kernel(const uint16_t *recs, int64_t rec_base, int64_t size, GLine *lines, uint64_t n_lines,
+                                                         uint64_t line_lo, uint64_t line_hi, uint32_t *cnt) {
     // one wave per line, one lane per edge; the grid is capped (a dispatch holds < 2^32 work-items: 6.3 G edges do not fit one lane each)
     const int lane = lane_id();
-    for (uint64_t li = (uint64_t)blockIdx.x * 4 + wave_id(); li < n_lines; li += (uint64_t)gridDim.x * 4) {
+    for (uint64_t li = line_lo + (uint64_t)blockIdx.x * 4 + wave_id(); li < line_hi; li += (uint64_t)gridDim.x * 4) {
     int64_t e = (int64_t)(li << 6) + lane;
-    uint32_t it = e < size ? recs[e] : 0;
+    uint32_t it = e < size ? recs[e - rec_base] : 0;
     bool in = e < size;
     uint32_t w = it & 15;
     uint64_t b_last = __ballot(in && ((it >> 4) & 1));
@@ -164,80 +166,117 @@ __global__ __launch_bounds__(256) void graph_invalid_kernel(const GLine *lines, 
 
 extern "C" {
 
+// A graph under construction: graph_begin() allocates the lines, the per-line counts and the tip labels, graph_pack() packs a range of lines
+// from records on the device, graph_finish() builds the rank / select tables.  (succinct_dbg.cpp:595-723, rank_and_select.h:80,430)
+struct GraphBuild {
+    std::unique_ptr<mgta_sdbg> g;
+    DevBuf d_cnt;
+    uint64_t n_lines = 0;
+    int64_t size = 0;
+};
+// tips: the labels (host or device memory, `tips_on_device`), or null = the caller fills g->tips itself before graph_finish()
+static int graph_begin(mgta_ctx *ctx, int k, int64_t size, const int64_t *bucket_items, const uint32_t *tips, int64_t n_tip_words, int words_per_tip,
+                       bool tips_on_device, GraphBuild &B) {
+    MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    B.g = std::make_unique<mgta_sdbg>();
+    auto &g = B.g;
+    g->ctx = ctx;
+    GraphDev &d = g->dev;
+    memset(&d, 0, sizeof(d));
+    d.size = size; d.k = k; d.words_per_tip = words_per_tip;
+    d.f[0] = -1; d.f[1] = 0;                                        // sdbg_multi_io.h:254-268
+    int64_t acc = 0;
+    for (int b = 0; b < MGTA_NUM_BUCKETS; ++b) { acc += bucket_items[b]; d.f[b / (MGTA_NUM_BUCKETS / 4) + 2] = acc; }
+    if (acc != size) { set_error("mgta_sdbg_load: bucket_items sum %lld != size %lld", (long long)acc, (long long)size); return MGTA_EINVAL; }
+    const uint64_t n_lines = (uint64_t)((size + 63) / 64);
+    if (n_lines >= 0xFFFFFFFFull) { set_error("graph too large for 32-bit line samples"); return MGTA_EUNSUPPORTED; }
+    d.n_lines = n_lines;
+    B.n_lines = n_lines; B.size = size;
+    g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
+    MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
+    g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
+    if (n_tip_words && tips)
+        MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, tips_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    d.lines = g->lines.as<GLine>();
+    d.tip_labels = g->tips.as<uint32_t>();
+    if (size > 0) B.d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
+    return MGTA_OK;
+}
+static void graph_pack(GraphBuild &B, const uint16_t *dev_recs, int64_t rec_base, uint64_t line_lo, uint64_t line_hi) {
+    if (line_hi <= line_lo) return;
+    mgta_ctx *ctx = B.g->ctx;
+    hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)std::min<uint64_t>((line_hi - line_lo + 3) / 4, 1u << 22)), dim3(256), 0, ctx->stream, dev_recs, rec_base,
+                       B.size, B.g->lines.as<GLine>(), B.n_lines, line_lo, line_hi, B.d_cnt.as<uint32_t>());
+    MGTA_HIP_CHECK(hipGetLastError());
+}
+static int graph_finish(GraphBuild &B, mgta_sdbg **out) {
+    auto &g = B.g;
+    mgta_ctx *ctx = g->ctx;
+    hipStream_t st = ctx->stream;
+    GraphDev &d = g->dev;
+    const uint64_t n_lines = B.n_lines;
+    if (B.size > 0) {
+        DevBuf d_base, d_tmp, d_tot;
+        d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
+        d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
+        d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+        uint64_t tot[6];
+        for (int c = 0; c < 6; ++c)
+            exclusive_scan_u32(st, B.d_cnt.as<uint32_t>() + c * n_lines, n_lines, d_base.as<uint64_t>() + c * n_lines, d_tmp.as<uint64_t>(),
+                               d_tot.as<uint64_t>() + c);
+        MGTA_HIP_CHECK(hipMemcpyAsync(tot, d_tot.p, 48, hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        d.total_last = (int64_t)tot[0];
+        for (int a = 1; a <= 4; ++a) d.total_w[a] = (int64_t)tot[1 + a];
+        g->sel_last.alloc((tot[0] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+        for (int a = 1; a <= 4; ++a) g->sel_w[a].alloc((tot[1 + a] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
+        d.sel_last = g->sel_last.as<uint32_t>();
+        for (int a = 1; a <= 4; ++a) d.sel_w[a] = g->sel_w[a].as<uint32_t>();
+        hipLaunchKernelGGL(graph_rank_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, g->lines.as<GLine>(), n_lines,
+                           B.d_cnt.as<uint32_t>(), d_base.as<uint64_t>(), g->sel_last.as<uint32_t>(), g->sel_w[1].as<uint32_t>(),
+                           g->sel_w[2].as<uint32_t>(), g->sel_w[3].as<uint32_t>(), g->sel_w[4].as<uint32_t>());
+        DevBuf d_rf;
+        d_rf.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
+        hipLaunchKernelGGL(graph_rankf_kernel, dim3(1), dim3(64), 0, st, d, d_rf.as<int64_t>());
+        MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(graph_hint_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d, g->lines.as<GLine>());
+        MGTA_HIP_CHECK(hipGetLastError());
+        MGTA_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    B.d_cnt.release();
+    ctx_retain(ctx);
+    *out = g.release();
+    return MGTA_OK;
+}
+
 // records / tip labels in host memory (`resident` false) or still on the device where the build left them (true: no copy of the records)
 // (`recs_owner`: a device buffer of the caller that holds `recs` and nothing else -- released as soon as the lines are packed, before
 // the rank tables are built: at 2 bytes per edge it is as large as the graph itself)
 static int load_graph(mgta_ctx *ctx, int k, const uint16_t *recs, int64_t size, const int64_t *bucket_items, const uint32_t *tips,
                       int64_t n_tip_words, int words_per_tip, bool resident, mgta_sdbg **out, DevBuf *recs_owner = nullptr) {
     try {
-        MGTA_HIP_CHECK(hipSetDevice(ctx->device));
+        GraphBuild B;
+        const int rc = graph_begin(ctx, k, size, bucket_items, tips, n_tip_words, words_per_tip, resident, B);
+        if (rc != MGTA_OK) return rc;
         hipStream_t st = ctx->stream;
-        auto g = std::make_unique<mgta_sdbg>();
-        g->ctx = ctx;
-        GraphDev &d = g->dev;
-        memset(&d, 0, sizeof(d));
-        d.size = size; d.k = k; d.words_per_tip = words_per_tip;
-        d.f[0] = -1; d.f[1] = 0;                                        // sdbg_multi_io.h:254-268
-        int64_t acc = 0;
-        for (int b = 0; b < MGTA_NUM_BUCKETS; ++b) { acc += bucket_items[b]; d.f[b / (MGTA_NUM_BUCKETS / 4) + 2] = acc; }
-        if (acc != size) { set_error("mgta_sdbg_load: bucket_items sum %lld != size %lld", (long long)acc, (long long)size); return MGTA_EINVAL; }
-        uint64_t n_lines = (uint64_t)((size + 63) / 64);
-        if (n_lines >= 0xFFFFFFFFull) { set_error("graph too large for 32-bit line samples"); return MGTA_EUNSUPPORTED; }
-        d.n_lines = n_lines;
-        g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
-        MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
-        g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
-        if (n_tip_words)
-            MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        d.lines = g->lines.as<GLine>();
-        d.tip_labels = g->tips.as<uint32_t>();
         if (size > 0) {
-            DevBuf d_recs, d_cnt, d_base, d_tmp, d_tot;
+            DevBuf d_recs;
             const uint16_t *dev_recs = recs;
             if (!resident) {
                 d_recs.alloc((size_t)size * 2, &ctx->live_bytes, &ctx->peak_bytes);
                 MGTA_HIP_CHECK(hipMemcpyAsync(d_recs.p, recs, (size_t)size * 2, hipMemcpyHostToDevice, st));
                 dev_recs = d_recs.as<uint16_t>();
             }
-            d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            hipLaunchKernelGGL(graph_pack_kernel, dim3((unsigned)std::min<uint64_t>((n_lines + 3) / 4, 1u << 22)), dim3(256), 0, st, dev_recs, size,
-                               g->lines.as<GLine>(), n_lines, d_cnt.as<uint32_t>());
-            MGTA_HIP_CHECK(hipGetLastError());
+            graph_pack(B, dev_recs, 0, 0, B.n_lines);
             if (!resident || recs_owner) {                                   // the records have done their part
                 MGTA_HIP_CHECK(hipStreamSynchronize(st));
                 d_recs.release();
                 if (recs_owner) recs_owner->release();
             }
-            d_base.alloc(n_lines * 6 * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tmp.alloc(scan_tmp_elems(n_lines) * 8, &ctx->live_bytes, &ctx->peak_bytes);
-            d_tot.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-            uint64_t tot[6];
-            for (int c = 0; c < 6; ++c)
-                exclusive_scan_u32(st, d_cnt.as<uint32_t>() + c * n_lines, n_lines, d_base.as<uint64_t>() + c * n_lines, d_tmp.as<uint64_t>(),
-                                   d_tot.as<uint64_t>() + c);
-            MGTA_HIP_CHECK(hipMemcpyAsync(tot, d_tot.p, 48, hipMemcpyDeviceToHost, st));
-            MGTA_HIP_CHECK(hipStreamSynchronize(st));
-            d.total_last = (int64_t)tot[0];
-            for (int a = 1; a <= 4; ++a) d.total_w[a] = (int64_t)tot[1 + a];
-            g->sel_last.alloc((tot[0] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            for (int a = 1; a <= 4; ++a) g->sel_w[a].alloc((tot[1 + a] / 64 + 2) * 4, &ctx->live_bytes, &ctx->peak_bytes);
-            d.sel_last = g->sel_last.as<uint32_t>();
-            for (int a = 1; a <= 4; ++a) d.sel_w[a] = g->sel_w[a].as<uint32_t>();
-            hipLaunchKernelGGL(graph_rank_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, g->lines.as<GLine>(), n_lines,
-                               d_cnt.as<uint32_t>(), d_base.as<uint64_t>(), g->sel_last.as<uint32_t>(), g->sel_w[1].as<uint32_t>(),
-                               g->sel_w[2].as<uint32_t>(), g->sel_w[3].as<uint32_t>(), g->sel_w[4].as<uint32_t>());
-            DevBuf d_rf;
-            d_rf.alloc(64, &ctx->live_bytes, &ctx->peak_bytes);
-            hipLaunchKernelGGL(graph_rankf_kernel, dim3(1), dim3(64), 0, st, d, d_rf.as<int64_t>());
-            MGTA_HIP_CHECK(hipMemcpyAsync(d.rank_f, d_rf.p, 48, hipMemcpyDeviceToHost, st));
-            MGTA_HIP_CHECK(hipStreamSynchronize(st));
-            hipLaunchKernelGGL(graph_hint_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, st, d, g->lines.as<GLine>());
-            MGTA_HIP_CHECK(hipGetLastError());
-            MGTA_HIP_CHECK(hipStreamSynchronize(st));
         }
-        ctx_retain(ctx);
-        *out = g.release();
-        return MGTA_OK;
+        return graph_finish(B, out);
     } catch (const HipError &e) { return e.code; }
 }
 
@@ -313,9 +352,19 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
                                                           prefix.c_str(), acc_r, acc_t, total, ntips); return MGTA_EINVAL; }
         MGTA_HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
-        DevBuf d_recs, d_tips, d_piece[2], d_desc[2], d_bad;
-        d_recs.alloc((size_t)total * 2 + 64, &ctx->live_bytes, &ctx->peak_bytes);
-        d_tips.alloc((size_t)ntips * 4 * wpt + 64, &ctx->live_bytes, &ctx->peak_bytes);
+        // The records never sit on the device all at once: they are decoded into a buffer of at most `range` records (MGTA_LOAD_RANGE_RECORDS;
+        // 2^32 = 8 GB), the lines they fill are packed at once, the buffer serves the next range.  Round 4 held all records (2 B per edge) next
+        // to the lines (2 B) and the line counts: 285 GB for the 63 G-edge graph of a 1 G-read set -- it could not be loaded at all; now the
+        // peak is the graph + its rank prefix sums (3.2 B per edge) + the range buffer.  A line (64 edges) that straddles two ranges is packed
+        // with the second: its first records are carried over to the front of the buffer.
+        GraphBuild B;
+        {
+            const int rc = graph_begin(ctx, k, (int64_t)total, items.data(), nullptr, (int64_t)ntips * wpt, wpt, true, B);
+            if (rc != MGTA_OK) return rc;
+        }
+        uint64_t range = 1ull << 32;
+        if (const char *e = getenv("MGTA_LOAD_RANGE_RECORDS")) range = std::max<uint64_t>(64, strtoull(e, nullptr, 10));
+        DevBuf d_range, d_piece[2], d_desc[2], d_bad;
         d_bad.alloc(64);
         MGTA_HIP_CHECK(hipMemsetAsync(d_bad.p, 0, 64, st));
         const size_t kPiece = 512ull << 20, kStage = 64ull << 20;
@@ -342,43 +391,85 @@ int mgta_sdbg_load_files(mgta_ctx *ctx, const char *prefix_c, mgta_sdbg **out) {
                 stage ^= 1;
             }
         };
-        int pc = 0;
+        for (int t = 0; t < nf; ++t) std::sort(of_file[t].begin(), of_file[t].end(), [&](int a, int b) { return bl[a].off < bl[b].off; });
+        int pc = 0, n_ranges = 0;
         std::vector<BucketSrc> desc;
-        for (int t = 0; t < nf; ++t) {
-            std::vector<int> &bs = of_file[t];
-            std::sort(bs.begin(), bs.end(), [&](int a, int b) { return bl[a].off < bl[b].off; });
-            for (size_t i = 0; i < bs.size();) {
-                const unsigned long long lo = (unsigned long long)bl[bs[i]].off;
-                unsigned long long hi = lo;
-                desc.clear();
-                size_t j = i;
-                for (; j < bs.size(); ++j) {
-                    const Line &L = bl[bs[j]];
-                    const unsigned long long nbytes = 2ull * L.items + 2ull * L.large + 4ull * wpt * L.tips;
-                    if (j > i && (unsigned long long)L.off + nbytes - lo > kPiece) break;
-                    hi = std::max(hi, (unsigned long long)L.off + nbytes);
-                    desc.push_back(BucketSrc{(uint64_t)L.off - lo, nbytes, L.items, rec_out[bs[j]], tip_out[bs[j]]});
-                }
-                // (the piece buffers alternate: the kernel of one piece runs while the next is being staged; a buffer is re-used two
-                // pieces later, behind that kernel in stream order)
-                if (d_piece[pc].bytes < hi - lo + 64) d_piece[pc].alloc((size_t)(hi - lo) + 64, &ctx->live_bytes, &ctx->peak_bytes);
-                if (d_desc[pc].bytes < desc.size() * sizeof(BucketSrc)) d_desc[pc].alloc(std::max<size_t>(desc.size(), 4096) * sizeof(BucketSrc));
-                upload(files[t].map + lo, (size_t)(hi - lo), d_piece[pc].as<char>());
-                MGTA_HIP_CHECK(hipMemcpyAsync(d_desc[pc].p, desc.data(), desc.size() * sizeof(BucketSrc), hipMemcpyHostToDevice, st));
-                MGTA_HIP_CHECK(hipStreamSynchronize(st));                             // (desc is re-used by the host; pieces are hundreds of MB)
-                hipLaunchKernelGGL(sdbg_decode_kernel, dim3((unsigned)((desc.size() + 63) / 64)), dim3(64), 0, st, d_piece[pc].as<uint16_t>(),
-                                   d_desc[pc].as<BucketSrc>(), (uint32_t)desc.size(), wpt, d_recs.as<uint16_t>(), d_tips.as<uint32_t>(), d_bad.as<uint32_t>());
-                MGTA_HIP_CHECK(hipGetLastError());
-                pc ^= 1;
-                i = j;
+        int64_t carry = 0;                                                // records at the front of the buffer that belong to a line not packed yet (< 64)
+        for (int b0 = 0; b0 < nb;) {
+            // the buckets [b0, b1) of this range: as many as fit the buffer beside the carried records (one at least)
+            const int64_t first = rec_out[b0];
+            int b1 = b0;
+            int64_t n_in = 0;
+            while (b1 < nb && (b1 == b0 || (uint64_t)(carry + n_in + items[b1]) <= range)) { n_in += items[b1]; ++b1; }
+            const int64_t rec_base = first - carry;                      // record held at the front of the buffer: a multiple of 64
+            if (d_range.bytes < (size_t)(carry + n_in + 64) * 2) {
+                DevBuf bigger;
+                bigger.alloc((size_t)std::max<uint64_t>((uint64_t)(carry + n_in), std::min<uint64_t>(range, (uint64_t)total)) * 2 + 256, &ctx->live_bytes, &ctx->peak_bytes);
+                if (carry) MGTA_HIP_CHECK(hipMemcpyAsync(bigger.p, d_range.p, (size_t)carry * 2, hipMemcpyDeviceToDevice, st));
+                MGTA_HIP_CHECK(hipStreamSynchronize(st));
+                d_range = std::move(bigger);
             }
+            for (int t = 0; t < nf; ++t) {
+                const std::vector<int> &bs = of_file[t];
+                for (size_t i = 0; i < bs.size();) {
+                    if (bs[i] < b0 || bs[i] >= b1) { ++i; continue; }
+                    const unsigned long long lo = (unsigned long long)bl[bs[i]].off;
+                    unsigned long long hi = lo;
+                    desc.clear();
+                    size_t j = i;
+                    for (; j < bs.size(); ++j) {
+                        if (bs[j] < b0 || bs[j] >= b1) break;            // (a bucket of another range: the piece ends here)
+                        const Line &L = bl[bs[j]];
+                        const unsigned long long nbytes = 2ull * L.items + 2ull * L.large + 4ull * wpt * L.tips;
+                        if (j > i && (unsigned long long)L.off + nbytes - lo > kPiece) break;
+                        hi = std::max(hi, (unsigned long long)L.off + nbytes);
+                        desc.push_back(BucketSrc{(uint64_t)L.off - lo, nbytes, L.items, rec_out[bs[j]] - rec_base, tip_out[bs[j]]});
+                    }
+                    // (the piece buffers alternate: the kernel of one piece runs while the next is being staged; a buffer is re-used two
+                    // pieces later, behind that kernel in stream order)
+                    if (d_piece[pc].bytes < hi - lo + 64) d_piece[pc].alloc((size_t)(hi - lo) + 64, &ctx->live_bytes, &ctx->peak_bytes);
+                    if (d_desc[pc].bytes < desc.size() * sizeof(BucketSrc)) d_desc[pc].alloc(std::max<size_t>(desc.size(), 4096) * sizeof(BucketSrc));
+                    upload(files[t].map + lo, (size_t)(hi - lo), d_piece[pc].as<char>());
+                    MGTA_HIP_CHECK(hipMemcpyAsync(d_desc[pc].p, desc.data(), desc.size() * sizeof(BucketSrc), hipMemcpyHostToDevice, st));
+                    MGTA_HIP_CHECK(hipStreamSynchronize(st));                             // (desc is re-used by the host; pieces are hundreds of MB)
+                    hipLaunchKernelGGL(sdbg_decode_kernel, dim3((unsigned)((desc.size() + 63) / 64)), dim3(64), 0, st, d_piece[pc].as<uint16_t>(),
+                                       d_desc[pc].as<BucketSrc>(), (uint32_t)desc.size(), wpt, d_range.as<uint16_t>(), B.g->tips.as<uint32_t>(), d_bad.as<uint32_t>());
+                    MGTA_HIP_CHECK(hipGetLastError());
+                    pc ^= 1;
+                    i = j;
+                }
+            }
+            // the lines these records complete (all that are left, at the end)
+            const int64_t end = first + n_in;
+            const bool last = b1 == nb;
+            const uint64_t line_lo = (uint64_t)(rec_base >> 6), line_hi = last ? B.n_lines : (uint64_t)(end >> 6);
+            graph_pack(B, d_range.as<uint16_t>(), rec_base, line_lo, line_hi);
+            const int64_t new_carry = last ? 0 : end - (int64_t)(line_hi << 6);
+            if (new_carry) {
+                // (behind the pack kernel in stream order; source and destination cannot overlap: the source starts >= 64 records in, or the
+                // range held less than a line and nothing moves)
+                const int64_t src = (int64_t)(line_hi << 6) - rec_base;
+                if (src >= new_carry) MGTA_HIP_CHECK(hipMemcpyAsync(d_range.p, d_range.as<uint16_t>() + src, (size_t)new_carry * 2, hipMemcpyDeviceToDevice, st));
+                else if (src > 0) {                                      // (a range shorter than a line: through a bounce buffer)
+                    uint16_t tmp[64];
+                    MGTA_HIP_CHECK(hipMemcpyAsync(tmp, d_range.as<uint16_t>() + src, (size_t)new_carry * 2, hipMemcpyDeviceToHost, st));
+                    MGTA_HIP_CHECK(hipStreamSynchronize(st));
+                    MGTA_HIP_CHECK(hipMemcpyAsync(d_range.p, tmp, (size_t)new_carry * 2, hipMemcpyHostToDevice, st));
+                    MGTA_HIP_CHECK(hipStreamSynchronize(st));
+                }
+            }
+            MGTA_HIP_CHECK(hipStreamSynchronize(st));                     // (the next range decodes into the same buffer)
+            carry = new_carry;
+            b0 = b1;
+            ++n_ranges;
         }
         uint32_t bad = 0;
         MGTA_HIP_CHECK(hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, st));
         MGTA_HIP_CHECK(hipStreamSynchronize(st));
-        d_piece[0].release(); d_piece[1].release();
+        d_piece[0].release(); d_piece[1].release(); d_range.release();
         if (bad) { set_error("%s: %u buckets do not parse to the sizes the index gives", prefix.c_str(), bad); return MGTA_EINVAL; }
-        return load_graph(ctx, k, d_recs.as<uint16_t>(), (int64_t)total, items.data(), d_tips.as<uint32_t>(), (int64_t)ntips * wpt, wpt, true, out, &d_recs);
+        if (getenv("MGTA_LOAD_VERBOSE")) fprintf(stderr, "[load] %lld records in %d range(s) of <= %llu\n", total, n_ranges, (unsigned long long)range);
+        return graph_finish(B, out);
     } catch (const HipError &e) { return e.code; }
 }
 

@@ -8,6 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <zlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <cstring>
 #include <fstream>
@@ -69,6 +72,93 @@ void PackedReads::append_packed(const uint32_t *w, size_t n, bool reverse) {
     start.push_back(n_bases_);
     max_len = std::max<int>(max_len, (int)n);
 }
+// ---- many sequences at once, by all host threads ---------------------------------------------------------------------------------------
+namespace {
+inline uint32_t rev16(uint32_t x) {                                     // the 16 characters of a word in reverse order
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+struct BitOr {                                                          // the bit stream as push_bits() builds it: first bit = the top bit of word 0
+    uint32_t *w;
+    inline void put(uint64_t bitpos, uint32_t v, int nbits) const {     // v: nbits <= 32 bits, right-aligned
+        if (nbits == 0) return;
+        const size_t j = (size_t)(bitpos >> 5);
+        const int off = (int)(bitpos & 31);
+        const uint64_t x = (uint64_t)(nbits == 32 ? v : (v & ((1u << nbits) - 1u))) << (64 - nbits - off);
+        const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+        if (hi) __atomic_fetch_or(&w[j], hi, __ATOMIC_RELAXED);         // (neighbouring sequences share their boundary words)
+        if (lo) __atomic_fetch_or(&w[j + 1], lo, __ATOMIC_RELAXED);
+    }
+};
+}  // namespace
+
+template <class Put> void PackedReads::append_many(const uint32_t *len, size_t n, Put put) {
+    if (start.empty()) start.push_back(0);
+    if (n == 0) return;
+    const size_t s0 = start.size();
+    start.resize(s0 + n);
+    uint64_t at = n_bases_;
+    int ml = max_len;
+    for (size_t i = 0; i < n; ++i) { at += len[i]; start[s0 + i] = at; ml = std::max<int>(ml, (int)len[i]); }
+    max_len = ml;
+    // the words that are complete now + the one the accumulator holds a part of + what the new bases need (+ one of slack: a piece may touch j + 1)
+    const size_t full = words.size();
+    const uint64_t bits_end = 2 * at;
+    if (acc_bits_ > 0) words.push_back((uint32_t)(acc_ << (32 - acc_bits_)));
+    words.resize((size_t)((bits_end + 31) / 32) + 1, 0u);
+    (void)full;
+    const BitOr bo{words.data()};
+    const uint64_t base0 = n_bases_;
+    const uint64_t *st = start.data() + s0;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (long long i = 0; i < (long long)n; ++i) put((size_t)i, bo, 2 * (i == 0 ? base0 : st[i - 1]));
+    n_bases_ = at;
+    words.pop_back();                                                   // the slack word
+    const int rem = (int)(bits_end & 31);
+    if (rem) { acc_ = (uint64_t)(words.back() >> (32 - rem)); acc_bits_ = rem; words.pop_back(); }
+    else { acc_ = 0; acc_bits_ = 0; }
+}
+
+void PackedReads::append_packed_many(const uint32_t *const *w, const uint32_t *len, size_t n, bool reverse) {
+    append_many(len, n, [&](size_t i, const BitOr &bo, uint64_t bit) {
+        const uint32_t *s = w[i];
+        const size_t nb = len[i], nw = (nb + 15) / 16;
+        const int tail = (int)(nb - (nw ? (nw - 1) * 16 : 0));
+        if (reverse) {
+            if (nw) { bo.put(bit, rev16(s[nw - 1]), 2 * tail); bit += 2 * tail; }
+            for (size_t j = nw - 1; j-- > 0;) { bo.put(bit, rev16(s[j]), 32); bit += 32; }
+        } else {
+            for (size_t j = 0; j + 1 < nw; ++j) { bo.put(bit, s[j], 32); bit += 32; }
+            if (nw) bo.put(bit, tail == 16 ? s[nw - 1] : s[nw - 1] >> (32 - 2 * tail), 2 * tail);
+        }
+    });
+}
+
+void PackedReads::append_text_many(const char *const *seq, const uint32_t *len, size_t n, bool reverse) {
+    static const struct CodeTable {
+        uint8_t t[256];
+        CodeTable() {
+            memset(t, 0, sizeof(t));                         // (as load_fastx: anything that is not a base reads as A)
+            t[(int)'C'] = t[(int)'c'] = 1;
+            t[(int)'G'] = t[(int)'g'] = t[(int)'N'] = t[(int)'n'] = 2;
+            t[(int)'T'] = t[(int)'t'] = 3;
+        }
+    } code;
+    append_many(len, n, [&](size_t i, const BitOr &bo, uint64_t bit) {
+        const unsigned char *s = reinterpret_cast<const unsigned char *>(seq[i]);
+        const size_t nb = len[i];
+        for (size_t b = 0; b < nb; b += 16) {                           // 16 bases per piece
+            const int m = (int)std::min<size_t>(16, nb - b);
+            uint32_t v = 0;
+            if (reverse) for (int q = 0; q < m; ++q) v = (v << 2) | code.t[s[nb - 1 - b - (size_t)q]];
+            else for (int q = 0; q < m; ++q) v = (v << 2) | code.t[s[b + (size_t)q]];
+            bo.put(bit, v, 2 * m);
+            bit += 2 * (uint64_t)m;
+        }
+    });
+}
+
 void PackedReads::finish() {
     if (start.empty()) start.push_back(0);
     if (acc_bits_ > 0) { words.push_back((uint32_t)(acc_ << (32 - acc_bits_))); acc_ = 0; acc_bits_ = 0; }
@@ -84,14 +174,42 @@ void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out) {
     setvbuf(f, nullptr, _IOFBF, 1 << 20);
     out.words.reserve((size_t)total_bases / 16 + 16);
     out.start.reserve((size_t)num_reads + 2);
-    std::vector<uint32_t> w;
-    for (long long r = 0; r < num_reads; ++r) {
-        uint32_t len;
-        if (fread(&len, 4, 1, f) != 1) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
-        size_t nw = (len + 15) / 16;
-        w.resize(nw);
-        if (nw && fread(w.data(), 4, nw, f) != nw) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
-        out.append_packed(w.data(), len, reverse);                                              // sequence_package.h:126-129
+    // the file in pieces of ~256 MB (whole records): the records of a piece are found by one pass over their length words and appended by
+    // all host threads (sequence_package.h:126-129 for the layout)
+    std::vector<uint32_t> buf;
+    std::vector<const uint32_t *> ptr;
+    std::vector<uint32_t> lens;
+    long long r = 0;
+    size_t have = 0;                                                    // words of `buf` that hold unread file content
+    const size_t piece = 64u << 20;                                     // words
+    buf.resize(piece + 64);
+    bool eof = false;
+    while (r < num_reads) {
+        if (!eof) {
+            if (buf.size() < have + piece) buf.resize(have + piece);
+            const size_t got = fread(buf.data() + have, 4, piece, f);
+            have += got;
+            eof = got < piece;
+        }
+        ptr.clear(); lens.clear();
+        size_t at = 0;
+        while (r + (long long)ptr.size() < num_reads && at < have) {
+            const uint32_t len = buf[at];
+            const size_t nw = (len + 15) / 16;
+            if (at + 1 + nw > have) break;                              // the record continues in the next piece
+            ptr.push_back(buf.data() + at + 1);
+            lens.push_back(len);
+            at += 1 + nw;
+        }
+        if (ptr.empty()) {
+            if (eof) die("%s.bin: truncated at read %lld", prefix.c_str(), r);
+            buf.resize(buf.size() * 2);                                 // (a record longer than a piece)
+            continue;
+        }
+        out.append_packed_many(ptr.data(), lens.data(), ptr.size(), reverse);
+        r += (long long)ptr.size();
+        memmove(buf.data(), buf.data() + at, (have - at) * 4);
+        have -= at;
     }
     fclose(f);
     out.n_short = (uint64_t)num_reads;
@@ -206,6 +324,46 @@ static bool fastx_next(FastxReader::Impl &r, std::vector<uint8_t> *codes_p, std:
         codes.resize(at + r.line.size());
         for (size_t i = 0; i < r.line.size(); ++i) codes[at + i] = code.t[(unsigned char)r.line[i]];
     }
+}
+
+void load_fasta_text(const char *text, size_t len, bool reverse, PackedReads &out) {
+    // records: '>' at the start of the text or right after a '\n'; the sequence = the line after the header line
+    int nt = 1;
+#ifdef _OPENMP
+    nt = std::max(1, omp_get_max_threads());
+#endif
+    std::vector<std::vector<const char *>> seqs((size_t)nt);
+    std::vector<std::vector<uint32_t>> lens((size_t)nt);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < nt; ++t) {
+        const size_t lo = len * (size_t)t / (size_t)nt, hi = len * ((size_t)t + 1) / (size_t)nt;
+        const char *p = text + lo, *const end = text + len, *const stop = text + hi;
+        while (p < stop) {                                              // headers that START in [lo, hi)
+            if (!(*p == '>' && (p == text || p[-1] == '\n'))) {
+                const char *q = static_cast<const char *>(memchr(p, '\n', (size_t)(stop - p)));
+                if (!q) break;
+                p = q + 1;
+                continue;
+            }
+            const char *h = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            if (!h) break;                                              // a header without a sequence line: no record
+            const char *s = h + 1;
+            const char *e = static_cast<const char *>(memchr(s, '\n', (size_t)(end - s)));
+            if (!e) e = end;
+            size_t n = (size_t)(e - s);
+            if (n && s[n - 1] == '\r') --n;
+            seqs[(size_t)t].push_back(s);
+            lens[(size_t)t].push_back((uint32_t)n);
+            p = e < end ? e + 1 : end;
+        }
+    }
+    size_t total = 0;
+    for (auto &v : seqs) total += v.size();
+    std::vector<const char *> all;
+    std::vector<uint32_t> all_len;
+    all.reserve(total); all_len.reserve(total);
+    for (int t = 0; t < nt; ++t) { all.insert(all.end(), seqs[(size_t)t].begin(), seqs[(size_t)t].end()); all_len.insert(all_len.end(), lens[(size_t)t].begin(), lens[(size_t)t].end()); }
+    out.append_text_many(all.data(), all_len.data(), total, reverse);
 }
 
 void load_fastx(const std::string &path, bool reverse, PackedReads &out) {

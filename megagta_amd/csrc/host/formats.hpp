@@ -27,6 +27,11 @@ struct PackedReads {
     int max_len = 0;
     void append(const uint8_t *codes, size_t n, bool reverse);
     void append_packed(const uint32_t *w, size_t n, bool reverse);   // n bases as the .bin files hold them (base j of a word at bits 30-2j)
+    // the same result as n calls of append_packed() / of append() on the codes of the text, computed by all host threads: every sequence's
+    // place in the bit stream follows from the lengths, the pieces are OR-ed into zeroed words (100 M reads: the one-thread loop took 6 s per
+    // `buildgraph`, a k's contigs -- 4 GB of text -- 8 s)
+    void append_packed_many(const uint32_t *const *w, const uint32_t *len, size_t n, bool reverse);
+    void append_text_many(const char *const *seq, const uint32_t *len, size_t n, bool reverse);   // ACGT in any case, N -> G (sequence_package.h:67-69)
     void finish();
     // a loaded library kept between the steps of one process: mark() before sequences are appended for one step (assist contigs),
     // rewind() afterwards (finish() only flushes the last partial word, which rewind() takes back)
@@ -34,6 +39,7 @@ struct PackedReads {
     Mark mark() const { return Mark{words.size(), start.size(), acc_, n_bases_, acc_bits_, max_len}; }
     void rewind(const Mark &m) { words.resize(m.n_words); start.resize(m.n_start); acc_ = m.acc; n_bases_ = m.n_bases; acc_bits_ = m.acc_bits; max_len = m.max_len; }
   private:
+    template <class Put> void append_many(const uint32_t *len, size_t n, Put put);
     uint64_t acc_ = 0;
     int acc_bits_ = 0;
     uint64_t n_bases_ = 0;
@@ -52,6 +58,9 @@ void load_read_lib(const std::string &prefix, bool reverse, PackedReads &out);  
 void load_assist_fasta(const std::string &path, bool reverse, PackedReads &out);        // s1.cpp:104-134
 void load_read_bin(const std::string &bin_path, bool reverse, PackedReads &out);         // a bare reads.lib.bin, read to EOF (findstart)
 void load_fastx(const std::string &path, bool reverse, PackedReads &out);                // FASTA / FASTQ (plain or .gz), N -> G (sequence_package.h:67-69)
+// FASTA text in memory whose records are one header line + ONE sequence line each (what `denovo` writes): the same sequences load_fastx
+// would append from the file, found and packed by all host threads
+void load_fasta_text(const char *text, size_t len, bool reverse, PackedReads &out);
 class FastxReader {                                                                      // kseq.h's record rules over zlib
   public:
     explicit FastxReader(const std::string &path);

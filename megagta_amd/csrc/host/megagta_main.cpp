@@ -60,6 +60,15 @@ struct Session {
     std::thread writer;           // PREFIX.sdbg.* of the last buildgraph being written while the next step already runs on the resident graph
     std::string writer_error;     // why that thread failed (set by the thread, read after the join)
     mgta_stream *stream = nullptr;   // the edge stream that thread downloads from the device (freed on this thread once it has joined)
+    // the contigs of the last `denovo`: their FASTA text stays in memory for the `buildgraph` / `findstart` that take them as --assist_seq /
+    // extra sequences (100 M reads: 4 GB of text, 8 s to read back and parse on one thread), and is written to PREFIX.contigs.fa by a thread
+    // of its own behind the next step
+    char *ctext = nullptr;
+    uint64_t ctext_len = 0;
+    std::string ctext_path;       // the file the text is (being) written to; stays set after the text is freed
+    std::thread cwriter;
+    std::atomic<bool> cwriter_done{true};
+    std::string cwriter_error;
 };
 static Session g_sess;
 // The graph files of the last buildgraph are complete: called before anything reads them, before the next build, at the end, and by the
@@ -73,6 +82,17 @@ static int writer_join() {
     fprintf(stderr, "    [ERROR] writing the graph files of the last buildgraph failed: %s\n", g_sess.writer_error.c_str());
     fflush(stderr);
     g_sess.writer_error.clear();
+    return 1;
+}
+// The contigs file of the last denovo is complete (and its text, if no step can want it any more, is freed): before the next denovo, at
+// "sync" / "release" / the end.  Returns 1 when the writer failed.
+static int contigs_join(bool free_text) {
+    if (g_sess.cwriter.joinable()) g_sess.cwriter.join();
+    if (free_text && g_sess.ctext) { mgta_host_free(g_sess.ctext); g_sess.ctext = nullptr; g_sess.ctext_len = 0; }
+    if (g_sess.cwriter_error.empty()) return 0;
+    fprintf(stderr, "    [ERROR] writing the contigs of the last denovo failed: %s\n", g_sess.cwriter_error.c_str());
+    fflush(stderr);
+    g_sess.cwriter_error.clear();
     return 1;
 }
 
@@ -111,15 +131,25 @@ static PackedReads &lib_get(const std::string &bin_path, const std::string &lib_
         else g_sess.lib_mark = pr.mark();
     }
     mk = g_sess.lib_mark;
-    const std::string key = extra.empty() ? std::string() : file_key(extra);
+    // the contigs this worker's own denovo has just made: taken from their text in memory (the file may still be on its way to the disk)
+    const bool from_memory = g_sess.active && !extra.empty() && extra == g_sess.ctext_path;
+    const std::string key = extra.empty() ? std::string() : from_memory ? "mem|" + extra : file_key(extra);
     if (g_sess.active && g_sess.have_extra && g_sess.extra_key == key) {
         logf("library%s: still in memory", extra.empty() ? "" : " + contigs");
         return pr;
     }
     pr.rewind(mk);
     if (!extra.empty()) {
-        if (extra_is_assist) load_assist_fasta(extra, /*reverse=*/true, pr);            // :121-134
-        else load_fastx(extra, true, pr);
+        if (from_memory && g_sess.ctext) {
+            const double t0 = now_s();
+            load_fasta_text(g_sess.ctext, (size_t)g_sess.ctext_len, /*reverse=*/true, pr);
+            logf("contigs of %s: %zu sequences packed from memory (%.3f s)", extra.c_str(), pr.start.size() - mk.n_start, now_s() - t0);
+            if (g_sess.cwriter_done.load()) contigs_join(true);                          // (written already: the text has served)
+        } else {
+            if (from_memory && contigs_join(true) != 0) die("%s is incomplete", extra.c_str());   // (the text is gone: the file is complete by now)
+            if (extra_is_assist) load_assist_fasta(extra, /*reverse=*/true, pr);        // :121-134
+            else load_fastx(extra, true, pr);
+        }
     }
     pr.finish();
     if (g_sess.active) { g_sess.extra_key = key; g_sess.have_extra = true; }
@@ -704,15 +734,33 @@ static int main_denovo(int argc, char **argv) {
     logf("Tips removed: %lld (%.1f ms); bubbles removed: %lld of %lld candidates in %lld rounds (%.1f ms); %lld simple paths, %lld contigs, "
          "total length %lld (%.1f ms)", (long long)st.n_tips, st.ms_tips, (long long)st.n_bubbles, (long long)st.n_bubble_candidates,
          (long long)st.n_bubble_rounds, st.ms_bubbles, (long long)st.n_paths, (long long)st.n_contigs, (long long)st.total_len, st.ms_unitigs);
-    FILE *f = fopen((out_prefix + ".contigs.fa").c_str(), "w");
-    if (!f) die("cannot write %s.contigs.fa", out_prefix.c_str());
-    if (len && fwrite(fasta, 1, len, f) != len) die("short write to %s.contigs.fa", out_prefix.c_str());
-    fclose(f);
-    f = fopen((out_prefix + ".contigs.fa.info").c_str(), "w");
-    if (!f) die("cannot write %s.contigs.fa.info", out_prefix.c_str());
+    const std::string cpath = out_prefix + ".contigs.fa";
+    auto write_contigs = [cpath](const char *text, uint64_t n) {
+        FILE *f = fopen(cpath.c_str(), "w");
+        if (!f) die("cannot write %s", cpath.c_str());
+        if (n && fwrite(text, 1, n, f) != n) die("short write to %s", cpath.c_str());
+        if (fclose(f) != 0) die("short write to %s", cpath.c_str());
+    };
+    FILE *f = fopen((cpath + ".info").c_str(), "w");
+    if (!f) die("cannot write %s.info", cpath.c_str());
     fprintf(f, "%lld %lld\n", (long long)st.n_contigs, (long long)st.total_len);        // assembler.cpp:162
     fclose(f);
-    mgta_host_free(fasta);
+    if (g_sess.active && !getenv("MEGAGTA_SYNC_WRITES")) {
+        // the worker: the text stays for the step that takes these contigs, the file is written behind it (joined by "sync" before the
+        // driver's checkpoint says "assembled", and before anything reads the file)
+        if (contigs_join(true) != 0) return 1;
+        g_sess.ctext = fasta; g_sess.ctext_len = len; g_sess.ctext_path = cpath;
+        g_sess.cwriter_done = false;
+        g_sess.cwriter = std::thread([write_contigs, fasta, len]() {
+            set_soft_die(true);
+            try { write_contigs(fasta, len); }
+            catch (const std::exception &e) { g_sess.cwriter_error = e.what(); }
+            g_sess.cwriter_done = true;
+        });
+    } else {
+        write_contigs(fasta, len);
+        mgta_host_free(fasta);
+    }
     mgta_sdbg_free(g);
     ctx_put(ctx);
     return 0;
@@ -744,14 +792,15 @@ static int main_serve() {
             if (!e) break;
         }
         if (f[0] == "quit") break;
-        if (f[0] == "sync") {                                             // the files of the last buildgraph are on disk (or: why not)
-            fprintf(rep, "DONE %d\n", writer_join());
+        if (f[0] == "sync") {                                             // the files of the last buildgraph / denovo are on disk (or: why not)
+            const int crc = contigs_join(false);
+            fprintf(rep, "DONE %d\n", writer_join() | crc);
             fflush(rep);
             continue;
         }
         if (f[0] == "release") {                                          // hand the device memory back (another process is going to need it:
             graph_drop();                                                 // it reads the graph from the files, so they are complete first)
-            const int wrc = writer_join();
+            const int wrc = writer_join() | contigs_join(true);
             if (g_sess.ctx) mgta_ctx_release_scratch(g_sess.ctx);
             if (g_sess.ctx2) mgta_ctx_release_scratch(g_sess.ctx2);
             fprintf(rep, "DONE %d\n", wrc);
@@ -790,7 +839,7 @@ static int main_serve() {
         fflush(rep);
     }
     graph_drop();
-    const int wrc = writer_join();
+    const int wrc = writer_join() | contigs_join(true);
     if (g_sess.ctx2) mgta_ctx_destroy(g_sess.ctx2);
     if (g_sess.ctx) mgta_ctx_destroy(g_sess.ctx);
     return wrc;
@@ -850,7 +899,17 @@ static int dispatch(int argc, char **argv) {
         PackedReads pr;
         if (std::string(argv[3]) == "bin") load_read_bin(std::string(argv[2]) + ".bin", true, pr);
         else load_read_lib(argv[2], true, pr);
-        if (argc > 5) load_assist_fasta(argv[5], true, pr);
+        if (argc > 5) {
+            if (env_int("MEGAGTA_LIBDUMP_TEXT", 0)) {                   // the in-memory route a worker takes for the contigs its `denovo` has just made
+                FILE *tf = fopen(argv[5], "rb");
+                if (!tf) die("cannot open %s", argv[5]);
+                std::string text;
+                char tb[1 << 16];
+                for (size_t got; (got = fread(tb, 1, sizeof tb, tf)) > 0;) text.append(tb, got);
+                fclose(tf);
+                load_fasta_text(text.data(), text.size(), true, pr);
+            } else load_assist_fasta(argv[5], true, pr);
+        }
         pr.finish();
         FILE *fw = fopen((std::string(argv[4]) + ".words").c_str(), "wb"), *fs = fopen((std::string(argv[4]) + ".start").c_str(), "wb");
         if (!fw || !fs) die("cannot write %s.words / .start", argv[4]);

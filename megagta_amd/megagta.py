@@ -226,7 +226,7 @@ def flush_deferred_cp():
     if worker is not None:
         ret = worker.request(["sync"])
         if ret != 0:
-            fail_step("writing the graph files", ret)
+            fail_step("writing the graph / contig files", ret)
     with open(opt.temp_dir + "cp.txt", "a") as f:
         for line in deferred_cp:
             f.write(line)
@@ -433,6 +433,8 @@ def assemble(k):
         run_step([opt.bin, "denovo", "-s", graph_prefix(k), "-o", graph_prefix(k), "-t", str(opt.num_cpu_threads),
                   "--min_standalone", "400", "--max_tip_len", str(opt.max_tip_len), "--min_contig", str(nxt + 1)],
                  "De novo assembling contigs from SdBG for k = %d" % k, stdout_path=os.devnull)
+        write_cp(defer=True)          # (the worker replies while a thread still writes PREFIX.contigs.fa: the checkpoint waits for the file)
+        return
     write_cp()
 
 
@@ -463,6 +465,46 @@ def run_multi_gpu_search(par, k):
         fail_step("searching contigs for k = %d on %d GPUs" % (k, opt.gpus), ret)
 
 
+def filter_and_translate_side_by_side(k):
+    """the two host-only text filters of every gene (filter_by_len.cpp, translate.cpp): the genes' chains are independent, so they run as
+    child processes side by side (100 M reads: 8 + 12 s one after the other through the worker); the log lines and the checkpoints keep the
+    reference's order (:705-710), written once the chains have ended"""
+    results = {}
+
+    def chain(gene):
+        d = opt.out_dir + "contigs/" + gene
+        os.makedirs(d, exist_ok=True)
+        lines = []
+        for cmd, fin_path, fout_path in (([opt.bin, "filterbylen", str(opt.min_contig_len)], graph_prefix(k) + "_raw_contigs_" + gene + ".fasta", d + "/nucl_merged.fasta"),
+                                         ([opt.bin, "translate", d + "/nucl_merged.fasta"], None, d + "/prot_merged.fasta")):
+            with open(fout_path, "wb") as fout:
+                fin = open(fin_path, "rb") if fin_path else None
+                try:
+                    p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+                finally:
+                    if fin:
+                        fin.close()
+            lines.append((" ".join(cmd), p.stderr.decode(errors="replace"), p.returncode))
+            if p.returncode != 0:
+                break
+        results[gene] = lines
+
+    threads = [threading.Thread(target=chain, args=(gene,)) for gene in opt.gene_info]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for gene in opt.gene_info:
+        for what, (cmd, err, ret) in zip(("Filtering contigs with minimum length = %d" % opt.min_contig_len, "Translating nucl contigs to aa contigs"), results.get(gene, [])):
+            logging.info("--- [%s] %s ---" % (datetime.now().strftime("%c"), what))
+            logging.debug("cmd: " + cmd)
+            for line in err.splitlines():
+                logging.debug(line.rstrip())
+            if ret != 0:
+                fail_step("running \"%s\"" % what, ret)
+            write_cp()
+
+
 def search_contigs(k):
     """search, then per gene filterbylen + translate.  Checkpoints as the reference writes them (:680-760): the two filters of every
     gene have their own, written INSIDE the search step, the search's own comes last -- a finished run continues identically under
@@ -475,6 +517,10 @@ def search_contigs(k):
         else:
             run_step([opt.bin, "search"] + par, "Searching contigs for k = %d" % k)
         os.makedirs(opt.out_dir + "contigs", exist_ok=True)
+        if len(opt.gene_info) > 1 and not opt.continue_mode and worker is not None:
+            filter_and_translate_side_by_side(k)
+            write_cp()
+            return
         for gene in opt.gene_info:
             d = opt.out_dir + "contigs/" + gene
             os.makedirs(d, exist_ok=True)

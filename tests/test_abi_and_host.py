@@ -291,15 +291,21 @@ def test_graph_checkpoint_waits_for_the_worker_to_finish_the_files(tmp_path, mon
         cp_path = drv.opt.temp_dir + "cp.txt"
         drv.build_graph(29, "")
         assert not os.path.exists(cp_path) or open(cp_path).read() == ""          # the files may still be in flight: nothing is promised yet
+        # (round 5: `denovo` in the worker replies while a thread still writes PREFIX.contigs.fa -- its checkpoint waits like the build's;
+        # the first step whose files are complete when it returns asks for the "sync" and writes the three of them)
+        drv.assemble(29)
+        assert w.requests == ["buildgraph", "denovo"]
+        assert not os.path.exists(cp_path) or open(cp_path).read() == ""
+        drv.opt.gene_info = {"g": ("f", "r", "a")}
         if sync_rc == 0:
-            drv.assemble(29)
-            assert w.requests == ["buildgraph", "denovo", "sync"]
-            assert open(cp_path).read() == "0\tdone\n1\tdone\n"
+            drv.find_seed(29, "g")
+            assert w.requests == ["buildgraph", "denovo", "findstart", "sync"]
+            assert open(cp_path).read() == "0\tdone\n1\tdone\n2\tdone\n"
         else:
             with pytest.raises(SystemExit) as e:
-                drv.assemble(29)
+                drv.find_seed(29, "g")
             assert e.value.code == 1 and "sync" in w.requests
-            assert not os.path.exists(cp_path) or open(cp_path).read() == ""      # --continue re-builds the graph
+            assert not os.path.exists(cp_path) or open(cp_path).read() == ""      # --continue re-builds the graph and the contigs
     # one process per step (no worker): the step returns when its files are complete, the checkpoint follows at once
     drv = importlib.reload(drv)
     out = tmp_path / "run_steps"

@@ -58,11 +58,11 @@ def test_buildlib_reader_across_buffer_refills(tmp_path):
     assert open(tmp_path / "big.lib_info").read().splitlines()[0] == f"{n * L} {n}"
 
 
-def _libdump(tmp_path, prefix, mode, assist=None):
+def _libdump(tmp_path, prefix, mode, assist=None, env=None):
     import numpy as np
     out = str(tmp_path / ("dump_" + mode + ("_a" if assist else "")))
     cmd = [BIN, "libdump", prefix, mode, out] + ([assist] if assist else [])
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env={**os.environ, **(env or {})})
     assert r.returncode == 0, r.stderr
     n_reads, n_words, max_len, n_short = (int(x) for x in r.stdout.split())
     w, s = np.fromfile(out + ".words", np.uint32), np.fromfile(out + ".start", np.uint64)
@@ -99,6 +99,18 @@ def test_host_read_loaders_match_python_packers(tmp_path, golden_dir):
     packed, start = readlib.pack_for_build(reads + assist)
     w, s, _, n_short = _libdump(tmp_path, prefixes[1], "lib", str(tmp_path / "assist.fa"))
     assert np.array_equal(s, start) and np.array_equal(w, packed) and n_short == len(reads)
+    # the worker's route for the contigs its own `denovo` has just made: the FASTA text in memory, records found and packed by all host
+    # threads (PackedReads::append_text_many) -- the same words whatever the number of threads and wherever their pieces of the text begin
+    many = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(1, 400, 3000)]
+    with open(tmp_path / "many.fa", "w") as f:
+        for i, a in enumerate(many):
+            f.write(f">k29_{i + 1} flag=1 multi=2.0000 len={a.size}\n" + "".join("ACGT"[c] for c in a) + "\n")
+    open(tmp_path / "many.fa.info", "w").write(f"{len(many)} {sum(a.size for a in many)}\n")
+    packed, start = readlib.pack_for_build(reads + many)
+    for threads in ("1", "3", "8"):
+        for route in ("0", "1"):
+            w, s, _, n_short = _libdump(tmp_path, prefixes[1], "lib", str(tmp_path / "many.fa"), env={"MEGAGTA_LIBDUMP_TEXT": route, "OMP_NUM_THREADS": threads})
+            assert np.array_equal(s, start) and np.array_equal(w, packed) and n_short == len(reads), (threads, route)
 
 
 def test_filterbylen_and_translate_match_reference(tmp_path):
