@@ -186,7 +186,10 @@ int mgta_sdbg_load(mgta_ctx *, int k, const uint16_t *recs, int64_t size, const 
 int mgta_sdbg_load_resident(mgta_ctx *, mgta_sdbg **out);
 /* The same load from the files `buildgraph` wrote: PREFIX.sdbg_info + PREFIX.sdbg.0 .. N-1 (SdbgReader + LoadFromMultiFile,
  * sdbg_multi_io.h:201-417, succinct_dbg.cpp:595-723).  The host maps the files and copies them to the device; the variable-length records
- * are parsed there, one bucket per lane.  What every rank of a multi-GPU search and every one-shot `megagta denovo|search` calls. */
+ * are parsed there, one bucket per lane.  What every rank of a multi-GPU search and every one-shot `megagta denovo|search` calls.
+ * The records are never on the device all at once: they are decoded range by range (at most MGTA_LOAD_RANGE_RECORDS of them, default 2^32 =
+ * 8 GB) and the 64-edge lines each range completes are packed at once, so the peak is the graph (2 B per edge) + its rank prefix sums
+ * (1.2 B per edge) + one range -- the 63 G-edge graph of a 1 G-read set loads into 288 GB (round 4 held all records beside the lines). */
 int mgta_sdbg_load_files(mgta_ctx *, const char *prefix, mgta_sdbg **out);
 void mgta_sdbg_free(mgta_sdbg *);
 int64_t mgta_sdbg_size(const mgta_sdbg *);
