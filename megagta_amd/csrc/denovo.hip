@@ -892,6 +892,8 @@ static uint64_t remove_tips(Work &w, int max_tip_len) {   // assembly_algorithms
 
 struct BubbleWork {
     DevBuf scratch, stamp_key, stamp_val, marked, status, win[2], pos[2], ok, keep, base, tmp, small, unknown;
+    int64_t *scratch_p = nullptr;   // the per-candidate scratch: `scratch`, or a buffer of the context's pool that nobody uses during a denovo
+    uint64_t scratch_bytes = 0;
     uint64_t stamp_mask = 0;
     int64_t n_crowded = 0;   // rounds in which the stamp table turned a candidate away
     size_t per = 0;          // int64 of scratch per candidate
@@ -928,12 +930,12 @@ static void pop_in_order(Work &w, BubbleWork &b, const DevBuf &cand, uint64_t n,
         const StampTab tab{b.stamp_key.as<unsigned long long>(), b.stamp_val.as<unsigned long long>(), b.stamp_mask, (unsigned long long)(b.round + 1) << 40};
         // (the list of the wide candidates lives in `ok` until the check kernel writes that; its length in the fourth counter)
         hipLaunchKernelGGL(bubble_reach_narrow_kernel, dim3((m + 64 / kNarrowLanes - 1) / (64 / kNarrowLanes)), dim3(64), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), m, max_len,
-                           b.scratch.as<int64_t>(), b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3, b.unknown.as<uint32_t>());
-        hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 8192u)), dim3(kWideThreads), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch.as<int64_t>(), b.per,
+                           b.scratch_p, b.per, tab, (unsigned long long)b.round, b.reach_max, b.narrow_max, barrier, b.ok.as<uint32_t>(), barrier + 3, b.unknown.as<uint32_t>());
+        hipLaunchKernelGGL(bubble_reach_kernel, dim3(std::min<uint32_t>(m, 8192u)), dim3(kWideThreads), 0, w.st, g, c, b.pos[cur].as<uint64_t>(), max_len, b.scratch_p, b.per,
                            tab, (unsigned long long)b.round, b.reach_max, barrier, b.ok.as<uint32_t>(), barrier + 3, b.unknown.as<uint32_t>());
-        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch.as<int64_t>(), b.per, tab,
+        hipLaunchKernelGGL(bubble_check_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, g, c, m, max_len, b.scratch_p, b.per, tab,
                            (unsigned long long)b.round, b.ok.as<uint32_t>(), barrier, b.unknown.as<uint32_t>());
-        hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch.as<int64_t>(), b.per,
+        hipLaunchKernelGGL(bubble_commit_kernel, dim3((m + 63) / 64), dim3(64), 0, w.st, w.d, c, b.pos[cur].as<uint64_t>(), m, max_len, b.scratch_p, b.per,
                            b.ok.as<uint32_t>(), barrier, b.marked.as<unsigned long long>(), b.status.as<uint32_t>(), b.keep.as<uint32_t>(), n_done);
         if (shed) {      // the candidates beyond the cut stay pending, behind the ones this round keeps
             hipLaunchKernelGGL(fill_u32_kernel, dim3((shed + 255) / 256), dim3(256), 0, w.st, b.keep.as<uint32_t>() + m, shed, 1u);
@@ -967,20 +969,40 @@ static uint64_t pop_bubbles(Work &w, int64_t &n_rounds, int64_t &n_candidates) {
     // launches and look-ups whatever it commits, 100 M reads took 513 rounds with 8 GB
     size_t free_b = 0, total_b = 0;
     MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t scratch_budget = std::min<uint64_t>(32ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t)free_b / 8));
+    uint64_t scratch_budget = std::min<uint64_t>(32ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t)free_b / 8));
+    // ... but never more than the branching edges can use (a window slot per candidate, a read-only search per branching edge for as many
+    // threads as the device holds at once), and obtained ONCE: 2 M reads: 32 GB of scratch for 263 k candidates cost 1.0-1.8 s of
+    // hipMalloc per `denovo`, five to nine times the rounds themselves.  The build's key buffers sit idle in the context's pool while a
+    // denovo runs (the worker keeps them between the steps): the larger of the two is borrowed when it holds at least a quarter of that.
+    {
+        const uint64_t per_find_b = (uint64_t)kMaxBranches * (uint64_t)max_len * 8;
+        const uint64_t need = std::max<uint64_t>(std::min<uint64_t>((nb + 63) / 64 * 64, 1ull << 20) * per_find_b,
+                                                 std::min<uint64_t>((nb + 63) / 64 * 64 + 64, kBubbleWindowMax) * (uint64_t)b.per * 8);
+        scratch_budget = std::min(scratch_budget, std::max<uint64_t>(256ull << 20, need));
+    }
+    int64_t *scratch_p = nullptr;
+    for (size_t slot = 4; slot <= 5 && slot < w.ctx->pool.size(); ++slot) {      // S_KEYS_A / S_KEYS_B of sdbg_build.hip
+        DevBuf &kb = w.ctx->pool[slot];
+        if (kb.p && kb.bytes >= scratch_budget / 4 && kb.bytes >= (256ull << 20) && (!scratch_p || kb.bytes > b.scratch_bytes)) {
+            scratch_p = kb.as<int64_t>(); b.scratch_bytes = kb.bytes;
+        }
+    }
+    if (getenv("MGTA_DENOVO_OWN_SCRATCH")) scratch_p = nullptr;          // (measurements)
+    if (scratch_p) scratch_budget = std::min<uint64_t>(scratch_budget, b.scratch_bytes);
     b.window = (uint32_t)std::min<uint64_t>(kBubbleWindowMax, std::max<uint64_t>(4096, scratch_budget / (b.per * 8)));
     // test knobs: tiny windows exercise the carry of pending candidates, a tiny reach limit the hold-back of a region that does not fit
     if (const char *e = getenv("MGTA_DENOVO_WINDOW")) b.window = (uint32_t)std::max(64, atoi(e)) & ~63u;
     if (const char *e = getenv("MGTA_DENOVO_REACH_MAX")) b.reach_max = std::min(kReachMax, std::max(1, atoi(e)));
     if (const char *e = getenv("MGTA_DENOVO_NARROW_MAX")) b.narrow_max = std::min(kReachFrontier, std::max(1, atoi(e)));   // (tiny: every region takes the wave-wide walk)
-    b.scratch.alloc((size_t)b.window * b.per * 8, w.live(), w.peak());
+    if (scratch_p && (uint64_t)b.window * b.per * 8 <= b.scratch_bytes) b.scratch_p = scratch_p;
+    else { b.scratch.alloc((size_t)b.window * b.per * 8, w.live(), w.peak()); b.scratch_p = b.scratch.as<int64_t>(); }
     found.alloc(nb * 4 + 64, w.live(), w.peak());
     if (nb) {
         // the read-only searches need kMaxBranches * max_len words each, not a reach table: as many threads as the scratch holds of those
         // (10 M reads: 8.5 M branching edges took 1 s with one thread per window slot)
         const size_t per_find = (size_t)kMaxBranches * max_len;
         const uint64_t threads = std::min<uint64_t>((nb + 63) / 64 * 64, ((uint64_t)b.window * b.per / per_find) / 64 * 64);
-        hipLaunchKernelGGL(bubble_find_kernel, dim3((unsigned)(threads / 64)), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len, b.scratch.as<int64_t>(),
+        hipLaunchKernelGGL(bubble_find_kernel, dim3((unsigned)(threads / 64)), dim3(64), 0, w.st, g, branching.as<int64_t>(), nb, max_len, b.scratch_p,
                            per_find, found.as<uint32_t>());
     }
     const uint64_t nc = compact_list(w, branching, found, nb, cand);

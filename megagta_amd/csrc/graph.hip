@@ -175,8 +175,10 @@ struct GraphBuild {
     int64_t size = 0;
 };
 // tips: the labels (host or device memory, `tips_on_device`), or null = the caller fills g->tips itself before graph_finish()
+// adopt_lines: a device buffer that holds the RECORDS and is large enough for the lines: the lines are then packed IN PLACE (a GLine is exactly
+// as large as the 64 two-byte records it is made of, and a wavefront reads its 64 records before it stores its line)
 static int graph_begin(mgta_ctx *ctx, int k, int64_t size, const int64_t *bucket_items, const uint32_t *tips, int64_t n_tip_words, int words_per_tip,
-                       bool tips_on_device, GraphBuild &B) {
+                       bool tips_on_device, GraphBuild &B, DevBuf *adopt_lines = nullptr) {
     MGTA_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     B.g = std::make_unique<mgta_sdbg>();
@@ -193,8 +195,11 @@ static int graph_begin(mgta_ctx *ctx, int k, int64_t size, const int64_t *bucket
     if (n_lines >= 0xFFFFFFFFull) { set_error("graph too large for 32-bit line samples"); return MGTA_EUNSUPPORTED; }
     d.n_lines = n_lines;
     B.n_lines = n_lines; B.size = size;
-    g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
-    MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
+    if (adopt_lines) g->lines = std::move(*adopt_lines);
+    else {
+        g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
+        MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
+    }
     g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
     if (n_tip_words && tips)
         MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, tips_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -564,6 +569,31 @@ int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
             MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
             const uint64_t need = (uint64_t)((double)ctx->last_n_rec * 3.3) + (1ull << 30);      // lines 2.0 + line counts 0.4 + their prefix sums 0.75 bytes per edge
             if ((uint64_t)free_b < need) { MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream)); ctx->pool.clear(); }
+        }
+        // A stream that nobody else is going to want (mgta_ctx_keep_stream 1, not the worker's hand-over to its file writer) and that the
+        // device cannot hold a second time as lines: the lines are packed INTO the stream's buffer.  The graph of a 1 G-read set is 63 G
+        // edges: 126 GB of records + 126 GB of lines + 24 GB of line counts do not fit 288 GB, records-turned-lines + counts + rank sums do.
+        // MGTA_LOAD_INPLACE=1 / 0 forces / forbids it (tests).
+        if (ctx->acc_valid && ctx->keep_stream != 2) {
+            const int64_t size = (int64_t)ctx->last_n_rec;
+            const uint64_t n_lines = (uint64_t)((size + 63) / 64);
+            size_t free_b = 0, total_b = 0;
+            MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            const char *force = getenv("MGTA_LOAD_INPLACE");
+            const bool want = force ? atoi(force) != 0 : (uint64_t)free_b < (uint64_t)((double)size * 3.3) + (1ull << 30);
+            if (want && size > 0 && ctx->acc_rec.p == ctx->last_rec && ctx->acc_rec.bytes >= (n_lines + 1) * sizeof(GLine)) {
+                GraphBuild B;
+                const int rc = graph_begin(ctx, ctx->last_k, size, ctx->acc_items.data(), static_cast<const uint32_t *>(ctx->last_tips),
+                                           (int64_t)ctx->last_n_tips * ctx->last_words_per_tip, ctx->last_words_per_tip, true, B, &ctx->acc_rec);
+                if (rc != MGTA_OK) return rc;
+                graph_pack(B, B.g->lines.as<uint16_t>(), 0, 0, B.n_lines);
+                MGTA_HIP_CHECK(hipMemsetAsync(B.g->lines.as<GLine>() + n_lines, 0, sizeof(GLine), ctx->stream));   // (the line past the end reads as empty)
+                MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                // the stream is gone: it IS the graph now
+                ctx->acc_tips.release(); ctx->acc_valid = false;
+                ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0;
+                return graph_finish(B, out);
+            }
         }
         if (ctx->acc_valid)      // a multi-pass build that kept its whole stream (mgta_ctx_keep_stream): records per bucket are on the host
             return load_graph(ctx, ctx->last_k, static_cast<const uint16_t *>(ctx->last_rec), (int64_t)ctx->last_n_rec, ctx->acc_items.data(),

@@ -160,33 +160,43 @@ def stagewise_vs_reference(out, work, gene_list: str, oracle, ref_bin: str, our_
     seed files, the driver's own run (whatever window it ran with) compared as a multiset.  -> {gene: (equal as a multiset, seeds)}"""
     import subprocess
     from collections import Counter
+    from concurrent.futures import ThreadPoolExecutor
     run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
     lib = str(out / "tmp" / "reads.lib")
     common = ["-m", "1", "--host_mem", "4000000000", "--mem_flag", "1", "--gpu_mem", "0", "--num_cpu_threads", "4", "--num_output_threads", "1",
               "--read_lib_file", lib]
-    prev = None
-    for k in (29, 35, 44):                                            # the three graphs
-        cmd = [ref_bin, "buildgraph", "-k", str(k), "--output_prefix", str(work / f"ref_{k}")] + common
-        if prev is not None:
-            cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
-        run(cmd)
-        assert oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges().md5() == oracle.Stream.read(str(work / f"ref_{k}")).edges().md5(), k
-        prev = k
-    for k, nxt in ((29, 35), (35, 44)):                               # the contigs of the intermediate k
-        run([ref_bin, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(work / f"ref_{k}"), "-t", "1", "--min_standalone", "400", "--max_tip_len", "150",
-             "--min_contig", str(nxt + 1)])
-        assert (out / f"k{k}" / f"{k}.contigs.fa").read_text() == (work / f"ref_{k}.contigs.fa").read_text(), k
     genes = {l.split()[0]: l.split()[3] for l in open(gene_list)}
+    # every reference step takes its inputs from the FINISHED run under `out` (the previous k's contigs, the graph and seed files), so the
+    # steps do not wait for each other: they run side by side on the host cores (one after the other they were most of the test's minute)
+    jobs = {}
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        prev = None
+        for k in (29, 35, 44):                                        # the three graphs
+            cmd = [ref_bin, "buildgraph", "-k", str(k), "--output_prefix", str(work / f"ref_{k}")] + common
+            if prev is not None:
+                cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
+            jobs[("graph", k)] = ex.submit(run, cmd)
+            prev = k
+        for k, nxt in ((29, 35), (35, 44)):                           # the contigs of the intermediate k
+            jobs[("denovo", k)] = ex.submit(run, [ref_bin, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(work / f"ref_{k}"), "-t", "1", "--min_standalone", "400",
+                                                  "--max_tip_len", "150", "--min_contig", str(nxt + 1)])
+        for gene, faa in genes.items():                               # the seeds of every gene
+            jobs[("seeds", gene)] = ex.submit(run, [ref_bin, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")])
+        # the reference's one-thread search on OUR graph files and seed files; window 1 == that run, byte for byte, all genes in one call
+        jobs["ref1"] = ex.submit(run, [ref_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ref1"), "20", "0.5", "1"])
+        jobs["w1"] = ex.submit(run, [our_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ours_w1"), "20", "0.5", "4"],
+                               env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
+        done = {key: f.result() for key, f in jobs.items()}
+    for k in (29, 35, 44):
+        assert oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges().md5() == oracle.Stream.read(str(work / f"ref_{k}")).edges().md5(), k
+    for k in (29, 35):
+        assert (out / f"k{k}" / f"{k}.contigs.fa").read_text() == (work / f"ref_{k}.contigs.fa").read_text(), k
     n_seeds = {}
-    for gene, faa in genes.items():                                   # the seeds of every gene
-        ref_seeds = run([ref_bin, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")]).stdout.decode().splitlines()
+    for gene in genes:
+        ref_seeds = done[("seeds", gene)].stdout.decode().splitlines()
         ours = (out / "k44" / f"44_{gene}_starting_kmers.txt").read_text().splitlines()
         assert ours == sorted(ref_seeds) and len(ours) > 64, gene
         n_seeds[gene] = len(ours)
-    # the reference's one-thread search on OUR graph files and seed files; window 1 == that run, byte for byte, all genes in one call
-    run([ref_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ref1"), "20", "0.5", "1"])
-    run([our_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ours_w1"), "20", "0.5", "4"],
-        env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
     res = {}
     for gene in genes:
         assert (work / f"ours_w1_raw_contigs_{gene}.fasta").read_text() == (work / f"ref1_raw_contigs_{gene}.fasta").read_text(), gene

@@ -323,7 +323,8 @@ def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
         # small pools serve one or two searches at a time, through the reserve, resumed passes and the one-search-at-a-time last resort:
         # 4 MB cannot hold one grown search = the loud error; 8 and 12 MB finish after two and one resumed passes; 16 MB needs none and
         # serves the lowest search from the reserve alone)
-        for (window, rate), pools in (((8, 0), (4096, 8192, 12288)), ((64, 4), (16384,))):
+        # (the 12 MB pool under window 8 is test_giving_up_the_order_is_opt_in_and_says_so's "held" run)
+        for (window, rate), pools in (((8, 0), (4096, 8192)), ((64, 4), (16384,))):
             want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=window, cost_rate=rate)      # prune 0: the largest searches
             assert st0["n_retries"] == 0
             try:

@@ -134,14 +134,25 @@ def test_graph_from_resident_stream_of_a_multi_pass_build(ctx, golden_dir):
         st = ctx.build_sdbg(rd, 44, collect=False).stats
         assert st["n_passes"] >= 3 and st["n_edges"] == stream.records.size
         g_dev = api.Graph(ctx, None, 44)
+        # ... and with the lines packed INTO the stream's buffer (what a graph too large to exist twice takes: MGTA_LOAD_INPLACE forces it
+        # here): the same graph, and the stream is consumed -- a second graph from it is refused
+        os.environ["MGTA_LOAD_INPLACE"] = "1"
+        try:
+            g_inplace = api.Graph(ctx, None, 44)
+        finally:
+            os.environ.pop("MGTA_LOAD_INPLACE", None)
+        with pytest.raises(api.MegaGtaError):
+            api.Graph(ctx, None, 44)
     finally:
         ctx.set_mem_limit(0)
         ctx.keep_stream(False)
-    assert g_dev.size == g_host.size
+    assert g_dev.size == g_host.size == g_inplace.size
     ids = np.arange(g_host.size)
     d0, o0 = g_host.outgoing(ids)
     d1, o1 = g_dev.outgoing(ids)
     assert np.array_equal(d0, d1) and np.array_equal(o0, o1)
+    d2, o2 = g_inplace.outgoing(ids)
+    assert np.array_equal(d0, d2) and np.array_equal(o0, o2) and np.array_equal(g_inplace.invalid_bits(), g_host.invalid_bits())
     _, qs = H.parse_probe_graph(H.gz_lines(os.path.join(golden_dir, "toy", "graph_k44.txt.gz")))
     deg, out = g_dev.outgoing([q["e"] for q in qs])
     for q, d, o in zip(qs, deg.tolist(), out.tolist()):
