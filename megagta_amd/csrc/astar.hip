@@ -340,8 +340,10 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // (round 4, multi-k graphs of 50 M reads and more: the first-of-their-gene-copy searches of nirK reach 1-4 M nodes, 150-500 MB
             // each, and how many of them run side by side is what the first minutes of such a batch cost: 24 MB per slot there too)
             const uint64_t per_slot = cache_mode == 0 ? (24ull << 20) : (n_search >= (1ull << 20) || g->dev.size > (3ll << 30)) ? (n_search >= (1ull << 21) ? (24ull << 20) : (16ull << 20)) : (8ull << 20);
+            uint64_t per_slot_used = per_slot;
+            if (const char *e = getenv("MGTA_ASTAR_PER_SLOT_MB")) per_slot_used = (uint64_t)std::max(1, atoi(e)) << 20;   // (experiments)
             uint64_t dyn = ctx->astar_pool_bytes ? ctx->astar_pool_bytes
-                                                 : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot);
+                                                 : std::max<uint64_t>(4ull << 30, std::min<uint64_t>(slots, n_search) * per_slot_used);
             const uint64_t avail = (uint64_t)((double)(free_b + ar.pool.bytes) * 0.8);
             const uint64_t room = avail > slots * slot_bytes ? avail - slots * slot_bytes : 0;
             uint64_t reserve = 0;
@@ -516,9 +518,9 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                         "where they could have followed a path -- which ones depends on timing\n", h_lim[13], d_cache[0].bytes / 1e9);
             for (int64_t s = 0; s < n * 2; ++s)
                 if (h_status[(size_t)s] == 5) {      // (terminal at once: more memory or another pass cannot help, and the searches behind it have seen nothing of it)
-                    set_error("search %lld (seed %lld, %s) outgrew the library's limit of %d pages of %d MB per array (~%lld M nodes): the reference's pool has no "
+                    set_error("search %lld (seed %lld, %s) outgrew the library's limit of %d pages of %d KB per array (~%lld M nodes): the reference's pool has no "
                               "bound (pool_st.h:43), this build's page tables do", (long long)s, (long long)(s / 2), (s & 1) ? "left" : "right", kMaxPages,
-                              1 << (kPageLog - 20), (long long)(((uint64_t)kMaxPages << (kPageLog - 6)) >> 20));
+                              1 << (kPageLog - 10), (long long)(((uint64_t)kMaxPages << (kPageLog - 6)) >> 20));
                     return MGTA_EOVERFLOW;
                 }
             size_t left = 0, starved_out = 0;
