@@ -446,6 +446,10 @@ def find_seed(k, gene):
             par.append(contig_file(opt.k_list[i - 1]))
         run_step([opt.bin, "findstart"] + par, "Finding starting kmers for %s k = %d" % (gene, k),
                  stdout_path=graph_prefix(k) + "_" + gene + "_starting_kmers.txt")
+        # (its own file is complete, but cp.txt is an ordered log: while the graph / contig files of the steps before are still on their way
+        # to the disk this line waits with theirs -- 100 M reads: the "sync" it used to trigger stood 8 s in front of the search)
+        write_cp(defer=True)
+        return
     write_cp()
 
 

@@ -297,13 +297,16 @@ def test_graph_checkpoint_waits_for_the_worker_to_finish_the_files(tmp_path, mon
         assert w.requests == ["buildgraph", "denovo"]
         assert not os.path.exists(cp_path) or open(cp_path).read() == ""
         drv.opt.gene_info = {"g": ("f", "r", "a")}
+        drv.find_seed(29, "g")                                             # (its checkpoint queues behind theirs: cp.txt is an ordered log)
+        assert w.requests == ["buildgraph", "denovo", "findstart"]
+        assert not os.path.exists(cp_path) or open(cp_path).read() == ""
         if sync_rc == 0:
-            drv.find_seed(29, "g")
+            drv.flush_deferred_cp()                                       # what the first step with a checkpoint of its own (the search's filters) and the end of the run do
             assert w.requests == ["buildgraph", "denovo", "findstart", "sync"]
             assert open(cp_path).read() == "0\tdone\n1\tdone\n2\tdone\n"
         else:
             with pytest.raises(SystemExit) as e:
-                drv.find_seed(29, "g")
+                drv.flush_deferred_cp()
             assert e.value.code == 1 and "sync" in w.requests
             assert not os.path.exists(cp_path) or open(cp_path).read() == ""      # --continue re-builds the graph and the contigs
     # one process per step (no worker): the step returns when its files are complete, the checkpoint follows at once
