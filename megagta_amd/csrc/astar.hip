@@ -216,7 +216,12 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         // passes) pay where the batch is large and independent: cold, 120 000 seeds on the 100 M-read graph 46.6 -> 43.6 s, 40 000 seeds
         // on the 10 M-read graph +14 %; they lose where single searches bound the run (30 000 seeds per gene at 100 M reads -5 %, the
         // ordered window on the 100 M-read graph 38.6 -> 42.7 s): profiles/r03/astar_ab.md.  MGTA_ASTAR_GROUP=8|16|32|64 overrides.
+        // Round 5, ordered window on the driver's multi-k graphs (profiles/r05/trials_*_lanes*.log, same box back to back): 2 M reads (80 k / 108 k
+        // seeds, 0.1 G edges) rplB 4.9 -> 4.7 s, nirK 8.0 -> 7.3 s; 20 M reads (0.8 M / 1.06 M seeds, 1.3 G edges) 23.2 -> 24.3 s and 44.5 -> 36.4 s;
+        // 50 M reads (2.64 M seeds, 3.2 G edges: first-of-their-gene-copy searches of millions of expansions) nirK 179 -> 188 s: eight lanes for
+        // ordered batches of 65 536 seeds and more on graphs of up to 2 G edges.
         int G = (cache_mode == 0 && n >= 32768) ? 8 : 16;
+        if (cache_mode > 0 && !free_share && n >= 65536 && g->dev.size <= (2ll << 30)) G = 8;
         if (const char *e = getenv("MGTA_ASTAR_GROUP")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) G = v; }
         const int groups = 64 / G;
         const int64_t spb = (int64_t)kAstarWaves * groups;                          // search slots per workgroup
