@@ -116,9 +116,26 @@ struct ScanArgs {
     uint32_t multi_width, multi_n;         // count mode: multi_n > 0 counts multi_n consecutive bucket ranges of multi_width buckets from
                                            // b_lo in one scan: block_count[range * gridDim.x + workgroup]
     uint64_t multi_magic;                  // ceil(2^32 / multi_width) (the range of a bucket without a division per item)
+    uint8_t *side;                         // write mode, optional: ((word 0 - side_bias) >> side_shift) & 255 of every key next to it (the
+    int side_shift;                        // first global sort pass then counts these bytes instead of reading the keys back)
+    uint32_t side_bias;
 };
 constexpr int kMaxCountRanges = 64;
 
+// masks of the first n characters of a W-word string (keep_chars as W ANDs with wave-uniform operands)
+template <int W>
+__device__ __forceinline__ void keep_masks(int n, uint32_t (&m)[W]) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const int lo = j * 16;
+        m[j] = n <= lo ? 0u : (n < lo + 16 ? ~0u << (32 - 2 * (n - lo)) : ~0u);
+    }
+}
+
+// The kernel is bound by VALU issue in write mode (SQ counters at 100 M reads, k = 44: 227 vector instructions per 64 positions, a wave64
+// instruction takes four cycles of a 16-lane SIMD) and by load latency in count mode (117), so the write path keeps everything
+// wave-uniform out of the vector unit: character masks and the workgroup's slice of the output as scalars, no bounds checks on the read
+// words where the workgroup's reads end well inside the array, no staging array for the items of a position.
 template <int W, bool WRITE>
 __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     __shared__ uint32_t s_cursor;
@@ -129,6 +146,7 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     __shared__ uint64_t s_start[kReadsPerBlock + 1];                  // one coalesced load instead of two dependent ones per read
     const bool multi = !WRITE && a.multi_n > 0;
     const uint64_t multi_magic = a.multi_magic;                      // ceil(2^32 / multi_width): exact quotients for operands of at most 2^16
+    const bool magic24 = multi_magic < (1u << 24);                   // (multi_width > 256: the product of a 16-bit and a 24-bit operand)
     uint64_t r0 = (uint64_t)blockIdx.x * kReadsPerBlock;
     uint64_t r1 = r0 + kReadsPerBlock < a.n_reads ? r0 + kReadsPerBlock : a.n_reads;
     if (threadIdx.x == 0) s_cursor = 0;
@@ -140,6 +158,16 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     uint32_t my_count = 0;
     unsigned long long kmers = 0;
     const int pad_bits = 2 * (16 * W - (k + 1));   // 2..32
+    const bool even = !((k + 1) & 1);
+    // up to 8 ranges counted at once: per lane in registers (an LDS atomic per item from 64 lanes on 3 addresses serialises)
+    const bool few = multi && a.multi_n <= 8;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t m_edge[W], m_k[W], m_k1[W];                             // the first k+1 / k / k-1 characters
+    keep_masks<W>(k + 1, m_edge);
+    keep_masks<W>(k, m_k);
+    keep_masks<W>(k - 1, m_k1);
+    // every word a lane of this workgroup can ask for lies inside the array (all but the workgroups of the array's last reads)
+    const bool in_bounds = wave_uniform((s_start[r1 - r0] >> 4) + (uint64_t)(W + 1)) < a.n_words;
 
     for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
         uint64_t s0 = s_start[r - r0];
@@ -162,64 +190,115 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
                     run_last = p == npos - 1 || !sol(p + 1);
                 }
             }
-            Key<W> items[6];
             int cnt = 0;
+            uint32_t fields = 0;                                       // count mode, few ranges: items of this position per range, 4 bits each
+            uint32_t mask = 0;                                         // write mode: bit t = item type t of the position is wanted
+            uint32_t e[W], rc[W];
             if (active) {
                 // edge = characters [p, p+k] of the read
                 uint64_t q = s0 + (uint64_t)p;
                 uint64_t wi = q >> 4;
                 int sh = (int)(q & 15) * 2;
                 uint32_t raw[W + 1];
+                if (in_bounds) {
 #pragma unroll
-                for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
-                uint32_t e[W], rc[W];
+                    for (int j = 0; j <= W; ++j) raw[j] = a.packed[wi + j];
+                } else {
 #pragma unroll
-                for (int j = 0; j < W; ++j) e[j] = sh ? ((raw[j] << sh) | (raw[j + 1] >> (32 - sh))) : raw[j];
-                keep_chars<W>(e, k + 1);
+                    for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < W; ++j) e[j] = (uint32_t)(((((uint64_t)raw[j]) << 32) | (uint64_t)raw[j + 1]) >> (32 - sh)) & m_edge[j];
                 // reverse complement (MegahitKmer::ReverseComplement, megahit_kmer.h:115-174)
 #pragma unroll
                 for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
                 shl_bits<W>(rc, pad_bits);
-                bool pal = true;                                       // s2.cpp:278
+                bool pal = even;                                       // s2.cpp:278 (an edge of odd length is never its own reverse complement)
+                if (even) {
 #pragma unroll
-                for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
-                int e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3;
+                    for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
+                }
                 // the bucket (first 8 characters of the key, s2.cpp:832) is known before the key is built: most keys of a
                 // narrow bucket range (memory-bound passes, multi-GPU shares) are dropped after three instructions
-                auto push = [&](const uint32_t (&src)[W], int from, int n, int prev) {
-                    const uint64_t two = ((uint64_t)src[0] << 32) | (uint64_t)(W > 1 ? src[W > 1 ? 1 : 0] : 0u);
-                    const uint32_t b = (uint32_t)((two << (2 * from)) >> 48);
+                auto push = [&](int t, const uint32_t (&src)[W], int from) {
+                    const uint32_t b = ((src[0] << (2 * from)) >> 16);   // characters [from, from + 8), from <= 2
                     if (b < a.b_lo || b >= a.b_hi) return;
-                    if (WRITE) items[cnt] = make_key<W>(src, from, n, k, prev);
-                    else if (multi) atomicAdd(&s_range_cnt[(uint32_t)(((uint64_t)(b - a.b_lo) * multi_magic) >> 32)], 1u);   // = (b - b_lo) / multi_width: both at most 2^16
+                    if (WRITE) mask |= 1u << t;
+                    else if (multi) {
+                        const uint32_t x = b - a.b_lo;                  // (b - b_lo) / multi_width: both at most 2^16
+                        uint32_t range;
+                        if (magic24) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(range) : "v"(x), "v"((uint32_t)multi_magic));   // full rate (v_mul_hi_u32: a quarter)
+                        else range = (uint32_t)(((uint64_t)x * multi_magic) >> 32);
+                        if (few) fields += 1u << (4 * range);
+                        else atomicAdd(&s_range_cnt[range], 1u);
+                    }
                     ++cnt;
                 };
                 if (run_first) {                                       // left $  (s2.cpp:531-540)
-                    push(e, 0, k, kDollar);
-                    if (!pal) push(rc, 2, k - 1, r1c);
+                    push(0, e, 0);
+                    if (!pal) push(1, rc, 2);
                 }
-                push(e, 1, k, e0);                                     // solid   (s2.cpp:543-550)
-                if (!pal) push(rc, 1, k, r0c);
+                push(2, e, 1);                                         // solid   (s2.cpp:543-550)
+                if (!pal) push(3, rc, 1);
                 if (run_last) {                                        // right $ (s2.cpp:553-562)
-                    push(e, 2, k - 1, e1);
-                    if (!pal) push(rc, 0, k, kDollar);
+                    push(4, e, 2);
+                    if (!pal) push(5, rc, 0);
                 }
             }
             if (!WRITE) {
                 my_count += (uint32_t)cnt;
+                if (few) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g)
+                        if (g < (int)a.multi_n) acc[g] += (fields >> (4 * g)) & 15u;
+                }
             } else {
-                uint32_t inc = wave_incl_scan((uint32_t)cnt);
-                uint32_t tot = __shfl(inc, 63, 64);
-                uint32_t wbase = 0;
-                if (lane == 0 && tot) wbase = atomicAdd(&s_cursor, tot);
-                wbase = __shfl(wbase, 0, 64);
-                uint64_t dst = base + wbase + (inc - (uint32_t)cnt);
-                for (int i = 0; i < cnt; ++i) out[dst + i] = items[i];
+                const uint32_t inc = wave_incl_scan((uint32_t)cnt);
+                const uint32_t tot = __shfl(inc, 63, 64);
+                if (tot) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&s_cursor, tot);
+                    const uint64_t first = base + (uint64_t)wave_uniform(wbase);   // the wave's slots [first, first + tot): a scalar
+                    char *const wave_out = reinterpret_cast<char *>(out + first);
+                    uint8_t *const wave_side = a.side ? a.side + first : nullptr;
+                    uint32_t slot = inc - (uint32_t)cnt;                    // < 6 * 64
+                    // every wanted item straight to its slot (no staging array: a lane-varying index into one costs a waterfall loop per store).
+                    // key = characters [from, from + n) of src, flags in the low 4 bits: (n == k) << 3 | prev   [cx1_read2sdbg_s2.cpp:613-671]
+                    auto put = [&](int t, const uint32_t (&src)[W], int from, const uint32_t (&keep)[W], uint32_t flags) {
+                        if (!((mask >> t) & 1u)) return;
+                        Key<W> key;
+#pragma unroll
+                        for (int j = 0; j < W; ++j) {
+                            const uint32_t nx = j + 1 < W ? src[j + 1 < W ? j + 1 : j] : 0u;
+                            key.w[j] = (from ? ((src[j] << (2 * from)) | (nx >> (32 - 2 * from))) : src[j]) & keep[j];
+                        }
+                        key.w[W - 1] |= flags;
+                        *reinterpret_cast<Key<W> *>(wave_out + slot * (uint32_t)sizeof(Key<W>)) = key;
+                        if (wave_side) wave_side[slot] = (uint8_t)((key.w[0] - a.side_bias) >> a.side_shift);
+                        ++slot;
+                    };
+                    const uint32_t e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3u, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3u;
+                    put(0, e, 0, m_k, 8u | (uint32_t)kDollar);
+                    put(1, rc, 2, m_k1, r1c);
+                    put(2, e, 1, m_k, 8u | e0);
+                    put(3, rc, 1, m_k, 8u | r0c);
+                    put(4, e, 2, m_k1, e1);
+                    put(5, rc, 0, m_k, 8u | (uint32_t)kDollar);
+                }
             }
         }
     }
     if (!WRITE) {
         my_count = wave_sum(my_count);
+        if (few) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < (int)a.multi_n) {
+                    const uint32_t t = wave_sum(acc[g]);
+                    if (lane == 0 && t) atomicAdd(&s_range_cnt[g], t);
+                }
+            }
+        }
         if (lane == 0) s_wave_cnt[wv] = my_count;
         __syncthreads();
         if (threadIdx.x == 0 && !multi) {
@@ -333,7 +412,7 @@ __global__ __launch_bounds__(256) void item_count_closed_kernel(const uint64_t *
         }
         items = wave_sum(items);
         kmers += wave_sum(npos);
-        if (lane_id() == 0) block_count[blk] = items;
+        if (lane_id() == 0 && block_count) block_count[blk] = items;   // (nullptr: only the k-mer total is wanted)
     }
     if (lane_id() == 0 && n_kmers && kmers) atomicAdd(n_kmers, kmers);
 }
@@ -413,6 +492,35 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W>
             uint32_t v = (keys[idx].w[wi] - (wi == 0 ? d.bias : 0u)) >> off;
             if (straddle) v |= (keys[idx].w[wi - 1] - (wi == 1 ? d.bias : 0u)) << (32 - off);
             atomicAdd(&h[v & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
+}
+
+// The same census from the SIDE array of the previous scatter (one byte per key: the digit this pass sorts on, written next to the
+// key at its destination): 1 byte read per key instead of the whole key (W = 3: 7.2 GB instead of 86 GB per launch at 100 M reads).
+__global__ __launch_bounds__(kSortThreads) void radix_census_side_kernel(const uint8_t *side, uint64_t n, uint64_t n_tiles, uint64_t *hist) {
+    __shared__ uint32_t h[256];
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kBlockTile;                 // a multiple of 32768: 16-byte loads are aligned
+    constexpr int kPerThread = kBlockTile / kSortThreads;                    // 32 bytes = two 16-byte loads, consecutive threads consecutive
+#pragma unroll
+    for (int half = 0; half < kPerThread / 16; ++half) {
+        const uint64_t idx = base + (uint64_t)half * (kSortThreads * 16) + (uint64_t)threadIdx.x * 16;
+        if (idx + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(side + idx);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&h[w[j] & 255u], 1u);
+                atomicAdd(&h[(w[j] >> 8) & 255u], 1u);
+                atomicAdd(&h[(w[j] >> 16) & 255u], 1u);
+                atomicAdd(&h[w[j] >> 24], 1u);
+            }
+        } else {
+            for (uint64_t i = idx; i < n && i < idx + 16; ++i) atomicAdd(&h[side[i]], 1u);
         }
     }
     __syncthreads();
@@ -546,8 +654,11 @@ __global__ __launch_bounds__(1024) void radix_rowscan_kernel(uint64_t *hist, uin
 
 // keys staged in LDS per round of the scatter: 4096, or 2048 for the 10- and 11-word records of stage 1 at k > 110 (a 4096-key stage
 // of those would not fit the 160 KB); a tile stays 32768 keys either way (census and scatter agree on that)
+#ifndef MGTA_SCATTER_IPT_NARROW
+#define MGTA_SCATTER_IPT_NARROW kItemsPerThread                  // (experiment builds: keys per thread of the staged sub-tile for W <= 3)
+#endif
 template <int W> struct ScatterCfg {
-    static constexpr int kIpt = W >= 10 ? 2 : kItemsPerThread;
+    static constexpr int kIpt = W >= 10 ? 2 : (W <= 3 ? MGTA_SCATTER_IPT_NARROW : kItemsPerThread);
     static constexpr int kSub = kSortThreads * kIpt;
     static constexpr int kChunk = kSub / kSortWaves;
 };
@@ -564,13 +675,24 @@ struct ScatterShared {
 
 // stable scatter of in[0..n) by digit d to out[gbase[digit]++...], sub-tile by sub-tile (gbase must be set and visible; all threads
 // call).  Four workgroup barriers per sub-tile; the next sub-tile's keys are on their way while the current one is placed.
-template <int W, bool BIASED = false>
-__device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d) {
+// SIDE: the digit the NEXT pass sorts on (d_next) of every key, one byte per key, for that pass's census.  The bytes of a 32768-key
+// tile are collected in LDS in the order the tile's keys land in (per digit value the eight sub-tiles append to ONE run of ~128 keys)
+// and written run by run when the tile is done: byte stores straight from the sub-tiles (runs of ~16 bytes, four per wave
+// instruction) cost the scatter 21 % (100 M reads: 43.9 -> 53.4 ms per launch).
+struct SideShared {
+    uint8_t bytes[kBlockTile];
+    uint64_t gtile[256];               // global destination of the tile's first key of a digit value minus that key's place in `bytes`
+    uint32_t toff[257];                // place in `bytes` of the tile's first key of a digit value
+};
+
+template <int W, bool BIASED = false, bool SIDE = false>
+__device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d, SideShared *ss = nullptr,
+                                                 Digit d_next = Digit{0, 0, 0}) {
     constexpr int kItemsPerThread = ScatterCfg<W>::kIpt, kSubTile = ScatterCfg<W>::kSub, kWaveChunk = ScatterCfg<W>::kChunk;   // (shadow the 4096-key constants)
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     uint16_t *whist = sh.whist[wv];               // wave-private row, updated lane-to-lane inside the wave
     for (int i = lane; i < 256; i += 64) whist[i] = 0;
-    constexpr bool kPrefetch = W <= 4;            // wider keys: the registers are better spent on the keys in flight
+    constexpr bool kPrefetch = W * kItemsPerThread <= 16;   // wider keys: the registers are better spent on the keys in flight
     Key<W> key[kItemsPerThread], nxt[kItemsPerThread];
     auto load = [&](Key<W> (&dst)[kItemsPerThread], uint64_t sub_base) {   // wave w owns keys [w*512, w*512+512) of the sub-tile, 64 at a time
 #pragma unroll
@@ -644,10 +766,24 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
                 if (j < n_valid) kk[it] = sh.keys[j];
             }
             get_digits<W, kItemsPerThread, BIASED>(kk, d, dg);
+            if constexpr (SIDE) {
+                uint32_t dn[kItemsPerThread];
+                get_digits<W, kItemsPerThread, BIASED>(kk, d_next, dn);
 #pragma unroll
-            for (int it = 0; it < kItemsPerThread; ++it) {
-                uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
-                if (j < n_valid) out[sh.gdelta[dg[it]] + j] = kk[it];
+                for (int it = 0; it < kItemsPerThread; ++it) {
+                    uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+                    if (j < n_valid) {
+                        const uint64_t to = sh.gdelta[dg[it]] + j;
+                        out[to] = kk[it];
+                        ss->bytes[(uint32_t)(to - ss->gtile[dg[it]])] = (uint8_t)dn[it];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < kItemsPerThread; ++it) {
+                    uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
+                    if (j < n_valid) out[sh.gdelta[dg[it]] + j] = kk[it];
+                }
             }
 #pragma unroll
             for (int it = 0; it < kItemsPerThread; ++it) key[it] = nxt[it];
@@ -657,7 +793,10 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
                 uint32_t j = (uint32_t)it * kSortThreads + (uint32_t)tid;
                 if (j < n_valid) {
                     Key<W> kk = sh.keys[j];
-                    out[sh.gdelta[get_digit<W, BIASED>(kk, d)] + j] = kk;
+                    const uint32_t dg = get_digit<W, BIASED>(kk, d);
+                    const uint64_t to = sh.gdelta[dg] + j;
+                    out[to] = kk;
+                    if constexpr (SIDE) ss->bytes[(uint32_t)(to - ss->gtile[dg])] = (uint8_t)get_digit<W, BIASED>(kk, d_next);
                 }
             }
             if (sub_base + kSubTile < n) load(key, sub_base + kSubTile);
@@ -666,22 +805,53 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 }
 
 // stable scatter of one 32768-key tile by the current digit
-template <int W, bool BIASED>
+// side digits only where the tile's bytes fit the LDS next to the staged keys (W <= 7 key words)
+template <int W> constexpr bool kSideFits = sizeof(ScatterShared<W>) + sizeof(SideShared) + 1024 <= 160 * 1024;
+
+template <int W, bool BIASED, bool SIDE = false>
 __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
-                                                                      const uint64_t *totals) {
+                                                                      const uint64_t *totals, uint8_t *side = nullptr,
+                                                                      Digit d_next = Digit{0, 0, 0}) {
     __shared__ ScatterShared<W> sh;
     __shared__ uint64_t s64[kSortThreads / 64 + 1];
     const int tid = threadIdx.x;
     // global base of every digit value for this tile = scan(totals)[digit] + rowoff[digit][tile]
     uint64_t t = tid < 256 ? totals[tid] : 0;
     uint64_t ex = block_excl_scan64<kSortThreads>(t, s64, nullptr);
-    if (tid < 256) sh.gbase[tid] = ex + rowoff[(uint64_t)tid * n_tiles + blockIdx.x];
-    __syncthreads();
+    const uint64_t my_off = tid < 256 ? rowoff[(uint64_t)tid * n_tiles + blockIdx.x] : 0;
+    if (tid < 256) sh.gbase[tid] = ex + my_off;
     const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
-    if (tile_base >= n) return;
-    const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
-    scatter_subtiles<W, BIASED>(sh, in + tile_base, out, cnt, d);
+    if constexpr (SIDE) {
+        __shared__ SideShared ss;
+        // keys of the tile per digit value: the next tile's row offset (the row total behind the last tile) minus this tile's
+        uint64_t c = 0;
+        if (tid < 256) c = (blockIdx.x + 1 < n_tiles ? rowoff[(uint64_t)tid * n_tiles + blockIdx.x + 1] : t) - my_off;
+        __syncthreads();                                                 // s64 is free again
+        const uint64_t place = block_excl_scan64<kSortThreads>(c, s64, nullptr);
+        if (tid < 256) {
+            ss.toff[tid] = (uint32_t)place;
+            ss.gtile[tid] = ex + my_off - place;
+            if (tid == 255) ss.toff[256] = (uint32_t)(place + c);
+        }
+        __syncthreads();
+        if (tile_base >= n) return;
+        const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
+        scatter_subtiles<W, BIASED, true>(sh, in + tile_base, out, cnt, d, &ss, d_next);
+        __syncthreads();
+        // the tile's bytes, run by run: a wave per 16 digit values, consecutive lanes consecutive bytes
+        const int lane = lane_id(), wv = wave_id();
+        for (int v = wv * (256 / kSortWaves); v < (wv + 1) * (256 / kSortWaves); ++v) {
+            const uint32_t from = ss.toff[v], len = ss.toff[v + 1] - from;
+            uint8_t *to = side + ss.gtile[v] + from;
+            for (uint32_t i = lane; i < len; i += 64) to[i] = ss.bytes[from + i];
+        }
+    } else {
+        __syncthreads();
+        if (tile_base >= n) return;
+        const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
+        scatter_subtiles<W, BIASED, false>(sh, in + tile_base, out, cnt, d);
+    }
 }
 
 // One workgroup sorts ONE oversized segment [big[b], big_end[b]) on all the low digits: census, scan and scatter of
@@ -1513,7 +1683,7 @@ static std::vector<Digit> low_digit_plan(int k, int W, int T) {
 // grow-only device buffers kept in the context between calls (multi-k builds, repeated steps):
 // hipMalloc/hipFree of multi-GB buffers costs far more than the kernels that use them.
 enum Slot { S_BLOCK_COUNT, S_BLOCK_BASE, S_SCAN_TMP, S_SMALL, S_KEYS_A, S_KEYS_B, S_HIST, S_TILE_HEADS, S_TILE_BASE, S_CNT, S_BASE,
-            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_MULTI_COUNT, S_POS2ID, S_SOLID, S_MERCY, S_EDGE_COUNT, S_NUM };
+            S_FIRST, S_OUT_REC, S_OUT_LARGE, S_OUT_TIPS, S_PLAN, S_BIG, S_LSD, S_MULTI_COUNT, S_POS2ID, S_SOLID, S_MERCY, S_EDGE_COUNT, S_SIDE, S_NUM };
 
 template <class T>
 static T *pool_get(mgta_ctx *ctx, int slot, uint64_t bytes) {
@@ -1591,15 +1761,38 @@ static TopPlan choose_top_plan(const mgta_ctx *ctx, uint64_t n_items, int max_to
 template <int WT, class LowPlanFn>
 static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<WT> *b, uint64_t n_items, int max_top, LowPlanFn low_plan_for,
                             std::vector<std::pair<hipEvent_t, hipEvent_t>> *scatter_ev, mgta_build_stats *S, double prefix_frac = 1.0,
-                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u, bool first_census_done = false, uint32_t b_lo = 0, uint32_t b_hi = 0) {
+                            uint32_t mask_last2 = ~0u, uint32_t mask_last = ~0u, bool first_census_done = false, uint32_t b_lo = 0, uint32_t b_hi = 0,
+                            bool first_side_done = false) {
     const uint64_t n_tiles = (n_items + kBlockTile - 1) / kBlockTile;
     uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);
     uint64_t *d_totals = pool_get<uint64_t>(ctx, S_SMALL, 4096) + 8;
     Key<WT> *src = a, *dst = b;
-    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg, bool have_census) {
+    bool side_failed = false;
+    // side digits (MGTA_SORT_SIDE=0 switches them off; 2 checks every side census against the census of the keys): the scatter of
+    // a pass leaves the NEXT pass's digit of every key in a byte array, and that pass's census reads the bytes instead of the keys
+    const char *side_env = getenv("MGTA_SORT_SIDE");
+    const int side_mode = side_env ? atoi(side_env) : 1;
+    const TopPlan tp = choose_top_plan(ctx, n_items, max_top, prefix_frac, b_lo, b_hi);
+    const int P = tp.P, T = tp.T();
+    uint8_t *d_side = side_mode > 0 && P >= 2 && kSideFits<WT> ? pool_get<uint8_t>(ctx, S_SIDE, n_items + 64) : nullptr;
+    bool side_valid = first_side_done && d_side;                        // d_side holds the digits of the pass about to run
+    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg, bool have_census, const Digit *dg_next) {
         uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
-        if (!have_census)
-            hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+        if (!have_census) {
+            if (side_valid) {
+                hipLaunchKernelGGL(radix_census_side_kernel, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, d_side, cnt, tiles, d_hist);
+                if (side_mode >= 2) {                                   // (test aid) the same census from the keys must agree
+                    std::vector<uint64_t> h_side(tiles * 256), h_keys(tiles * 256);
+                    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                    MGTA_HIP_CHECK(hipMemcpy(h_side.data(), d_hist, tiles * 256 * 8, hipMemcpyDeviceToHost));
+                    hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+                    MGTA_HIP_CHECK(hipStreamSynchronize(stream));
+                    MGTA_HIP_CHECK(hipMemcpy(h_keys.data(), d_hist, tiles * 256 * 8, hipMemcpyDeviceToHost));
+                    if (h_side != h_keys) { set_error("internal: side-digit census differs from the census of the keys"); side_failed = true; }
+                }
+            } else
+                hipLaunchKernelGGL((radix_census_kernel<WT>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, cnt, dg, tiles, d_hist);
+        }
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(1024), 0, stream, d_hist, tiles, d_totals);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (scatter_ev) {
@@ -1607,25 +1800,39 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
             MGTA_HIP_CHECK(hipEventCreate(&e1));
             MGTA_HIP_CHECK(hipEventRecord(e0, stream));
         }
-        if (dg.bias)
-            hipLaunchKernelGGL((radix_scatter_kernel<WT, true>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
-                               d_totals);
-        else
-            hipLaunchKernelGGL((radix_scatter_kernel<WT, false>), dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, from, to, cnt, dg, tiles, d_hist,
-                               d_totals);
+        const bool write_side = d_side && dg_next;
+        const Digit dn = dg_next ? *dg_next : Digit{0, 0, 0};
+        const dim3 grid((unsigned)tiles), block(kSortThreads);
+        bool launched = false;
+        if constexpr (kSideFits<WT>) {
+            if (write_side) {
+                if (dg.bias) hipLaunchKernelGGL((radix_scatter_kernel<WT, true, true>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, d_side, dn);
+                else hipLaunchKernelGGL((radix_scatter_kernel<WT, false, true>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, d_side, dn);
+                launched = true;
+            }
+        }
+        if (!launched) {
+            if (dg.bias) hipLaunchKernelGGL((radix_scatter_kernel<WT, true, false>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, nullptr, dn);
+            else hipLaunchKernelGGL((radix_scatter_kernel<WT, false, false>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, nullptr, dn);
+        }
+        side_valid = write_side;
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
             scatter_ev->emplace_back(e0, e1);
             if (S) S->n_sort_launches++;
         }
+        return 0;
     };
-    const TopPlan tp = choose_top_plan(ctx, n_items, max_top, prefix_frac, b_lo, b_hi);
-    const int P = tp.P, T = tp.T();
-    for (int i = P - 1; i >= 0; --i) {
+    auto pass_digit = [&](int i) {
         Digit dg = top_digit(WT, i);
         dg.pos -= tp.skip;
         dg.bias = tp.bias;
-        global_pass(src, dst, n_items, dg, first_census_done && i == P - 1);
+        return dg;
+    };
+    for (int i = P - 1; i >= 0; --i) {
+        const Digit dg = pass_digit(i), dn = i > 0 ? pass_digit(i - 1) : Digit{0, 0, 0};
+        if (global_pass(src, dst, n_items, dg, first_census_done && i == P - 1, i > 0 ? &dn : nullptr)) return nullptr;
+        if (side_failed) return nullptr;
         std::swap(src, dst);
     }
     const std::vector<Digit> low = low_plan_for(T);
@@ -1913,6 +2120,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
     sa.n_kmers = (unsigned long long *)d_kmers;
     sa.n_sentinel = (unsigned long long *)d_sentinel;
     sa.is_solid = nullptr; sa.num_k1_per_read = 0; sa.n_short = n_short;
+    sa.side = nullptr; sa.side_shift = 0; sa.side_bias = 0;
     if (min_count > 1) {
         unsigned long long *sol = nullptr;
         int nk1 = 0;
@@ -1948,8 +2156,8 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         // ---- 1. count
         t_ph.start();
         sa.b_lo = b_lo; sa.b_hi = b_hi;
+        sa.n_kmers = first_pass ? (unsigned long long *)d_kmers : nullptr;
         if (first_pass) MGTA_HIP_CHECK(hipMemsetAsync(d_kmers, 0, 8, stream));
-        else sa.n_kmers = nullptr;
         uint64_t *d_scan_tmp = pool_get<uint64_t>(ctx, S_SCAN_TMP, scan_tmp_elems(std::max<uint64_t>(n_blocks, 1024)) * 8);
         static_assert(kReadsPerBlock == 64, "item_count_closed_kernel: one lane per read of a workgroup");
         static const bool closed_even = !(getenv("MGTA_CLOSED_EVEN") && atoi(getenv("MGTA_CLOSED_EVEN")) == 0);   // 0: k+1 even takes the scans
@@ -1960,6 +2168,13 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(256), 0, stream, sa.start, sa.n_reads, n_blocks, k,
                                sa.block_count, sa.n_kmers);
         else if (n_blocks) {
+            // the k-mer total of the first pass from the read lengths alone: one atomic per wave of the scan on ONE address (6.25 M of
+            // them at 100 M reads) kept the count scan at 80 ms where the write scan, which does more, takes 52
+            if (sa.n_kmers) {
+                hipLaunchKernelGGL(item_count_closed_kernel, dim3((unsigned)((n_blocks + 63) / 64)), dim3(256), 0, stream, sa.start, sa.n_reads, n_blocks, k,
+                                   (uint32_t *)nullptr, sa.n_kmers);
+                sa.n_kmers = nullptr;
+            }
             // several equally wide ranges ahead (memory-bound passes): one scan counts them all
             const uint32_t ranges_left = (bucket_end - b_lo + width - 1) / width;
             if (multi_n && (width != multi_width || b_lo < multi_lo || (b_lo - multi_lo) % width != 0 || (b_lo - multi_lo) / width >= multi_n)) multi_n = 0;
@@ -1987,7 +2202,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
         // either key buffer may end up as the emitter's scratch (11 bytes per key: run start u64, record u16, info u8), whichever
         // the last sort pass leaves idle: both hold >= 12 bytes per key
         uint64_t key_b = std::max<uint64_t>(n_items * sizeof(Key<W>), n_items * 12) + 4096;
-        uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + (8u << 20);
+        uint64_t need = 2 * key_b + n_tiles * 256 * 8 + n_items * 2 + n_items /* side digits */ + (8u << 20);
         uint64_t other = ctx->live_bytes - pool_bytes(ctx);
         if (acc) {     // room for the stream the passes leave behind: ~0.6 edges of 2 bytes per (k+1)-mer, tips, slack
             const uint64_t est = (uint64_t)((double)S.n_kmers * 1.5 * range_frac) + (64ull << 20);
@@ -2018,6 +2233,7 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
             const int P_top = choose_top_plan(ctx, n_items, max_top, prefix_frac).P;
             static const bool tiled_keygen = !(getenv("MGTA_KEYGEN_TILED") && atoi(getenv("MGTA_KEYGEN_TILED")) == 0);
             const bool fused_census = closed_form && P_top >= 1 && tiled_keygen && n_tiles <= 0x7FFFFFFFull;
+            bool first_side = false;
             if (closed_form) MGTA_HIP_CHECK(hipMemsetAsync(d_sentinel, 0, 8, stream));
             if (fused_census) {
                 uint64_t *d_hist = pool_get<uint64_t>(ctx, S_HIST, std::max<uint64_t>(1, n_tiles) * 256 * 8);   // the buffer device_sort uses
@@ -2025,13 +2241,25 @@ static int build_impl(mgta_ctx *ctx, const mgta_reads *rd, uint64_t n_short, int
                                    32 - 8 * P_top, n_tiles, d_hist);
             } else if (closed_form)
                 hipLaunchKernelGGL((item_write_closed_kernel<W>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
-            else
+            else {
+                // the general writer leaves the first global pass's digit of every key in the side array (see device_sort): that pass's
+                // census then reads one byte per key.  The plan is the one device_sort is about to choose (same arguments).
+                const TopPlan tp = choose_top_plan(ctx, n_items, max_top, prefix_frac, b_lo, b_hi);
+                const char *side_env = getenv("MGTA_SORT_SIDE");
+                if (tp.P >= 2 && kSideFits<W> && (!side_env || atoi(side_env) > 0)) {
+                    sa.side = pool_get<uint8_t>(ctx, S_SIDE, n_items + 64);
+                    sa.side_shift = 32 - 8 * tp.P - tp.skip;
+                    sa.side_bias = tp.bias;
+                    first_side = true;
+                }
                 hipLaunchKernelGGL((item_scan_kernel<W, true>), dim3((unsigned)n_blocks), dim3(kScanBlock), 0, stream, sa);
+                sa.side = nullptr;
+            }
             S.ms_gen += t_ph.stop();
             // ---- 4. sort: P global passes on the most significant bytes, then the segment-local finish in LDS
             t_ph.start();
             Key<W> *src = device_sort<W>(ctx, stream, d_a, d_b, n_items, max_top, [&](int T) { return low_digit_plan(k, W, T); }, &scatter_ev, &S,
-                                           prefix_frac, ~0u, ~0u, fused_census, b_lo, b_hi);
+                                           prefix_frac, ~0u, ~0u, fused_census, b_lo, b_hi, first_side);
             if (!src) return MGTA_EUNSUPPORTED;
             Key<W> *dst = src == d_a ? d_b : d_a;
             S.ms_sort += t_ph.stop();

@@ -349,6 +349,30 @@ def test_routes_agree_at_scale_other_key_widths(ctx, k, L):
     assert np.array_equal(sum(p.bucket_items for p in parts), a.bucket_items)
 
 
+@pytest.mark.parametrize("k,L,m", [(29, 100, 1), (44, 150, 1), (95, 250, 1), (127, 250, 1), (44, 150, 2)])
+def test_side_digit_census_equals_the_census_of_the_keys(ctx, monkeypatch, k, L, m):
+    """the scatter of a global pass leaves the next pass's digit of every key in a byte array and that pass counts the bytes instead of
+    reading the keys: with MGTA_SORT_SIDE=2 every such census is repeated from the keys and compared (the build fails if they differ), over
+    W = 2, 3, 6, 8 key words, the payload-carrying keys of -m 2, whole-range and sub-range (biased digits) passes; and the stream is the
+    one of a build without side digits"""
+    from megagta_amd import synth
+    mg = synth.make_metagenome(150_000, L, (("rplB", 60),), seed=300 + k)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    rd = ctx.upload_reads(packed, start)
+    monkeypatch.setenv("MGTA_SORT_SIDE", "0")
+    plain = ctx.build_sdbg(rd, k, min_count=m)
+    assert plain.stats["n_sort_launches"] >= 2
+    monkeypatch.setenv("MGTA_SORT_SIDE", "2")
+    _same(ctx.build_sdbg(rd, k, min_count=m), plain)
+    if m == 1:
+        monkeypatch.setenv("MGTA_SORT_BIAS", "2")
+        parts = [ctx.build_sdbg(rd, k, bucket_range=r) for r in ((0, 30000), (30000, 65536))]
+        assert np.array_equal(np.concatenate([p.records for p in parts]), plain.records)
+        monkeypatch.delenv("MGTA_SORT_BIAS")
+    monkeypatch.delenv("MGTA_SORT_SIDE")
+    _same(ctx.build_sdbg(rd, k, min_count=m), plain)
+
+
 @pytest.mark.parametrize("k,m", [(29, 2), (60, 3)])
 def test_stage1_routes_agree_at_scale(ctx, k, m):
     """-m >= 2 on 3*10^7 stage-1 sort items (payload-carrying keys, masked comparisons): comparison finish == LSD finish, stream and
