@@ -569,6 +569,13 @@ def main(argv=None):
             else:
                 for gene in opt.gene_info:
                     find_seed(k, gene)
+                if os.environ.get("MEGAGTA_STOP_BEFORE_SEARCH"):         # (measurements of reads -> seeds at sizes whose search takes minutes)
+                    flush_deferred_cp()
+                    logging.info("--- [%s] stopped before the search (MEGAGTA_STOP_BEFORE_SEARCH). Time elapsed: %f seconds ---"
+                                 % (datetime.now().strftime("%c"), time.time() - t0))
+                    if worker is not None:
+                        worker.close()
+                    return 0
                 search_contigs(k)
         flush_deferred_cp()
         if worker is not None:

@@ -92,6 +92,9 @@ try:
             lg.write("\n==== <out>/log ====\n" + open(d + "/out/log", errors="replace").read())
     if r.returncode != 0:
         sys.exit(f"megagta.py failed ({r.returncode}) after {dt:.0f} s: see the step log")
+    if os.environ.get("MEGAGTA_STOP_BEFORE_SEARCH"):
+        print(f"reads -> seeds: {dt:.1f} s (stopped before the search)", flush=True)
+        sys.exit(0)
     nc = {g: sum(1 for l in open(f"{d}/out/contigs/{g}/nucl_merged.fasta") if l.startswith(">")) for g in ("rplB", "nirK")}
     line = {"reads": n, "read_len": L, "k_list": "30,36,45", "genes": ["rplB", "nirK"], "seconds": dt, "reads_per_s": n / dt, "contigs": nc,
             "note": "megagta.py, one MI355X, default mode (ordered-commit window); reads.fa on the box's scratch disk; the reference was not run at this size"}
