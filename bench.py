@@ -708,6 +708,12 @@ def main():
         ms_local = sum(x["ms_local_sort"] for x in stats) / max(1, sum(x["n_passes"] for x in stats))
         scatter_total = sum(x["ms_sort_scatter"] for x in stats)
         local_total = sum(x["ms_local_sort"] for x in stats)
+        # since round 5 every scatter launch but the last of a pass also writes the NEXT pass's digit of every key (1 B/key, W <= 7) so that the
+        # census in between reads 1 byte instead of the key; `achieved` stays on SURVEY 8(d)'s bytes (2 x 4W per key), the bytes including
+        # that side array are reported next to it
+        n_pass_total = sum(x["n_passes"] for x in stats)
+        side_on = os.environ.get("MGTA_SORT_SIDE", "1") != "0" and W <= 7 and launches > n_pass_total
+        side_bytes = items_per_launch * (launches - n_pass_total) / max(1, launches) if side_on else 0.0
         dom_name, dom_ms = ("local_sort_kernel", ms_local) if local_total >= scatter_total else ("radix_scatter_kernel", ms_scatter)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the PMC passes (they cannot be collected inline: separate rocprofv3 runs,
@@ -738,7 +744,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "avg_launch_ms": dom_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "other_kernels": {"radix_scatter_kernel": {"avg_launch_ms": ms_scatter, "launches_per_step": launches / args.steps,
-                                                                    "achieved": alg_bytes / (ms_scatter * 1e-3) / 1e9 if ms_scatter > 0 else 0.0},
+                                                                    "achieved": alg_bytes / (ms_scatter * 1e-3) / 1e9 if ms_scatter > 0 else 0.0,
+                                                                    "achieved_incl_side_digits": (alg_bytes + side_bytes) / (ms_scatter * 1e-3) / 1e9 if ms_scatter > 0 else 0.0,
+                                                                    "side_digit_bytes_per_launch": side_bytes},
                                            "local_sort_kernel": {"avg_launch_ms": ms_local, "launches_per_step": s["n_passes"],
                                                                  "achieved": alg_bytes / (ms_local * 1e-3) / 1e9 if ms_local > 0 else 0.0}}},
             "whole_build": {"algorithmic_bytes_per_kmer": b_build(k, L, edges_per_kmer),
