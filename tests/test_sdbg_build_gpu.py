@@ -98,6 +98,29 @@ def test_multi_pass_bucket_ranges(ctx, oracle, golden_dir):
     c2.close()
 
 
+@pytest.mark.parametrize("m", [1, 2])
+def test_count_scan_of_few_and_of_many_ranges(m):
+    """one scan counts the items of every bucket range still ahead: up to 8 ranges per lane in registers, more through LDS atomics.  Both
+    routes (and the key writer's side digits behind them, and -m 2's solid-run scan) give the stream of a build in one pass"""
+    from megagta_amd import api
+    mg = synth.make_metagenome(120_000, 150, (("rplB", 60),), seed=77)
+    packed, start = synth.pack_reads_for_build(mg.reads)
+    c2 = api.Context(0)
+    try:
+        rd = c2.upload_reads(packed, start)
+        whole = c2.build_sdbg(rd, 44, min_count=m)
+        assert whole.stats["n_passes"] == 1
+        seen = set()
+        for limit_mb in (420, 130, 48):
+            c2.set_mem_limit(limit_mb << 20)
+            g = c2.build_sdbg(rd, 44, min_count=m)
+            _same(g, whole)
+            seen.add("few" if 2 <= g.stats["n_passes"] <= 8 else ("many" if g.stats["n_passes"] > 8 else "one"))
+        assert {"few", "many"} <= seen, seen
+    finally:
+        c2.close()
+
+
 def test_larger_synthetic_properties(ctx, oracle):
     """100k x 150 bp (BASELINE config 1 size): oracle parity + size-independent properties"""
     mg = synth.make_metagenome(100_000, 150, (("rplB", 277),), seed=3)
