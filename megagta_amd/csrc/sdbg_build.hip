@@ -14,9 +14,11 @@
 //        array, reverse-complement it in registers, count the <= 6 sort items of the position whose first 8 characters fall
 //        into the range (one scan counts every range that is still ahead)
 //     2. prefix sum of the per-workgroup counts
-//     3. item_scan<write>   same scan, keys written (array-of-structs, W words) with wave-aggregated offsets
-//     4. sort: P <= 4 global LSD passes on the P leading key bytes (digit census per tile, row scan, stable LDS-staged scatter
-//        with wave-level match ranking and coalesced run writes), then every segment of equal prefix is finished inside LDS:
+//     3. item_scan<write>   same scan, keys written (array-of-structs, W words) with wave-aggregated offsets, and next to every key
+//        the byte the first global sort pass sorts on (the SIDE array, W <= 7)
+//     4. sort: P <= 4 global LSD passes on the P leading key bytes (digit census per tile FROM THE SIDE BYTES, row scan, stable
+//        LDS-staged scatter with wave-level match ranking and coalesced run writes, which leaves the next pass's side bytes behind:
+//        the keys cross HBM once per pass for the scatter, not twice), then every segment of equal prefix is finished inside LDS:
 //        one counting pass on (segment, next <= 8 bits) with LDS atomics, then every key ranks itself inside its short run of
 //        equal leading bits by comparison (local_sort_kernel); tiles with long runs and segments that did not fit take LSD
 //        passes in LDS (local_lsd_kernel), segments longer than a tile global passes over their own range (segment_sort_kernel)
