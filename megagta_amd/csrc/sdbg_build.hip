@@ -171,123 +171,147 @@ __global__ __launch_bounds__(kScanBlock) void item_scan_kernel(ScanArgs a) {
     // every word a lane of this workgroup can ask for lies inside the array (all but the workgroups of the array's last reads)
     const bool in_bounds = wave_uniform((s_start[r1 - r0] >> 4) + (uint64_t)(W + 1)) < a.n_words;
 
-    for (uint64_t r = r0 + wv; r < r1; r += kScanBlock / 64) {
-        uint64_t s0 = s_start[r - r0];
-        int len = (int)(s_start[r - r0 + 1] - s0);
-        if (len < k + 1) continue;                                     // s2.cpp:262-264
-        int npos = len - k;
-        if (lane == 0) kmers += (unsigned long long)npos;
-        for (int c0 = 0; c0 < npos; c0 += 64) {
-            int p = c0 + lane;
-            bool active = p < npos;
-            bool run_first = p == 0, run_last = p == npos - 1;
-            if (active && a.is_solid && r < a.n_short) {               // solid runs inside the read (s2.cpp:276,280,288)
-                auto sol = [&](int pp) {
-                    uint64_t bit = (uint64_t)a.num_k1_per_read * r + (uint64_t)pp;
-                    return (bool)((a.is_solid[bit >> 6] >> (bit & 63)) & 1);
-                };
-                active = sol(p);
-                if (active) {
-                    run_first = p == 0 || !sol(p - 1);
-                    run_last = p == npos - 1 || !sol(p + 1);
-                }
-            }
-            int cnt = 0;
-            uint32_t fields = 0;                                       // count mode, few ranges: items of this position per range, 4 bits each
-            uint32_t mask = 0;                                         // write mode: bit t = item type t of the position is wanted
-            uint32_t e[W], rc[W];
+    // one round of 64 positions: lane = position p of read r (s0 = its first character, npos = its positions); `active` lanes have one
+    auto positions = [&](bool active, uint64_t r, uint64_t s0, int p, int npos) {
+        bool run_first = p == 0, run_last = p == npos - 1;
+        if (active && a.is_solid && r < a.n_short) {               // solid runs inside the read (s2.cpp:276,280,288)
+            auto sol = [&](int pp) {
+                uint64_t bit = (uint64_t)a.num_k1_per_read * r + (uint64_t)pp;
+                return (bool)((a.is_solid[bit >> 6] >> (bit & 63)) & 1);
+            };
+            active = sol(p);
             if (active) {
-                // edge = characters [p, p+k] of the read
-                uint64_t q = s0 + (uint64_t)p;
-                uint64_t wi = q >> 4;
-                int sh = (int)(q & 15) * 2;
-                uint32_t raw[W + 1];
-                if (in_bounds) {
-#pragma unroll
-                    for (int j = 0; j <= W; ++j) raw[j] = a.packed[wi + j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
-                }
-#pragma unroll
-                for (int j = 0; j < W; ++j) e[j] = (uint32_t)(((((uint64_t)raw[j]) << 32) | (uint64_t)raw[j + 1]) >> (32 - sh)) & m_edge[j];
-                // reverse complement (MegahitKmer::ReverseComplement, megahit_kmer.h:115-174)
-#pragma unroll
-                for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
-                shl_bits<W>(rc, pad_bits);
-                bool pal = even;                                       // s2.cpp:278 (an edge of odd length is never its own reverse complement)
-                if (even) {
-#pragma unroll
-                    for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
-                }
-                // the bucket (first 8 characters of the key, s2.cpp:832) is known before the key is built: most keys of a
-                // narrow bucket range (memory-bound passes, multi-GPU shares) are dropped after three instructions
-                auto push = [&](int t, const uint32_t (&src)[W], int from) {
-                    const uint32_t b = ((src[0] << (2 * from)) >> 16);   // characters [from, from + 8), from <= 2
-                    if (b < a.b_lo || b >= a.b_hi) return;
-                    if (WRITE) mask |= 1u << t;
-                    else if (multi) {
-                        const uint32_t x = b - a.b_lo;                  // (b - b_lo) / multi_width: both at most 2^16
-                        uint32_t range;
-                        if (magic24) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(range) : "v"(x), "v"((uint32_t)multi_magic));   // full rate (v_mul_hi_u32: a quarter)
-                        else range = (uint32_t)(((uint64_t)x * multi_magic) >> 32);
-                        if (few) fields += 1u << (4 * range);
-                        else atomicAdd(&s_range_cnt[range], 1u);
-                    }
-                    ++cnt;
-                };
-                if (run_first) {                                       // left $  (s2.cpp:531-540)
-                    push(0, e, 0);
-                    if (!pal) push(1, rc, 2);
-                }
-                push(2, e, 1);                                         // solid   (s2.cpp:543-550)
-                if (!pal) push(3, rc, 1);
-                if (run_last) {                                        // right $ (s2.cpp:553-562)
-                    push(4, e, 2);
-                    if (!pal) push(5, rc, 0);
-                }
+                run_first = p == 0 || !sol(p - 1);
+                run_last = p == npos - 1 || !sol(p + 1);
             }
-            if (!WRITE) {
-                my_count += (uint32_t)cnt;
-                if (few) {
+        }
+        int cnt = 0;
+        uint32_t fields = 0;                                       // count mode, few ranges: items of this position per range, 4 bits each
+        uint32_t mask = 0;                                         // write mode: bit t = item type t of the position is wanted
+        uint32_t e[W], rc[W];
+        if (active) {
+            // edge = characters [p, p+k] of the read
+            uint64_t q = s0 + (uint64_t)p;
+            uint64_t wi = q >> 4;
+            int sh = (int)(q & 15) * 2;
+            uint32_t raw[W + 1];
+            if (in_bounds) {
 #pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        if (g < (int)a.multi_n) acc[g] += (fields >> (4 * g)) & 15u;
-                }
+                for (int j = 0; j <= W; ++j) raw[j] = a.packed[wi + j];
             } else {
-                const uint32_t inc = wave_incl_scan((uint32_t)cnt);
-                const uint32_t tot = __shfl(inc, 63, 64);
-                if (tot) {
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&s_cursor, tot);
-                    const uint64_t first = base + (uint64_t)wave_uniform(wbase);   // the wave's slots [first, first + tot): a scalar
-                    char *const wave_out = reinterpret_cast<char *>(out + first);
-                    uint8_t *const wave_side = a.side ? a.side + first : nullptr;
-                    uint32_t slot = inc - (uint32_t)cnt;                    // < 6 * 64
-                    // every wanted item straight to its slot (no staging array: a lane-varying index into one costs a waterfall loop per store).
-                    // key = characters [from, from + n) of src, flags in the low 4 bits: (n == k) << 3 | prev   [cx1_read2sdbg_s2.cpp:613-671]
-                    auto put = [&](int t, const uint32_t (&src)[W], int from, const uint32_t (&keep)[W], uint32_t flags) {
-                        if (!((mask >> t) & 1u)) return;
-                        Key<W> key;
 #pragma unroll
-                        for (int j = 0; j < W; ++j) {
-                            const uint32_t nx = j + 1 < W ? src[j + 1 < W ? j + 1 : j] : 0u;
-                            key.w[j] = (from ? ((src[j] << (2 * from)) | (nx >> (32 - 2 * from))) : src[j]) & keep[j];
-                        }
-                        key.w[W - 1] |= flags;
-                        *reinterpret_cast<Key<W> *>(wave_out + slot * (uint32_t)sizeof(Key<W>)) = key;
-                        if (wave_side) wave_side[slot] = (uint8_t)((key.w[0] - a.side_bias) >> a.side_shift);
-                        ++slot;
-                    };
-                    const uint32_t e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3u, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3u;
-                    put(0, e, 0, m_k, 8u | (uint32_t)kDollar);
-                    put(1, rc, 2, m_k1, r1c);
-                    put(2, e, 1, m_k, 8u | e0);
-                    put(3, rc, 1, m_k, 8u | r0c);
-                    put(4, e, 2, m_k1, e1);
-                    put(5, rc, 0, m_k, 8u | (uint32_t)kDollar);
-                }
+                for (int j = 0; j <= W; ++j) raw[j] = (wi + j < a.n_words) ? a.packed[wi + j] : 0u;
             }
+#pragma unroll
+            for (int j = 0; j < W; ++j) e[j] = (uint32_t)(((((uint64_t)raw[j]) << 32) | (uint64_t)raw[j + 1]) >> (32 - sh)) & m_edge[j];
+            // reverse complement (MegahitKmer::ReverseComplement, megahit_kmer.h:115-174)
+#pragma unroll
+            for (int j = 0; j < W; ++j) rc[j] = rev_chars(~e[W - 1 - j]);
+            shl_bits<W>(rc, pad_bits);
+            bool pal = even;                                       // s2.cpp:278 (an edge of odd length is never its own reverse complement)
+            if (even) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) pal = pal && (e[j] == rc[j]);
+            }
+            // the bucket (first 8 characters of the key, s2.cpp:832) is known before the key is built: most keys of a
+            // narrow bucket range (memory-bound passes, multi-GPU shares) are dropped after three instructions
+            auto push = [&](int t, const uint32_t (&src)[W], int from) {
+                const uint32_t b = ((src[0] << (2 * from)) >> 16);   // characters [from, from + 8), from <= 2
+                if (b < a.b_lo || b >= a.b_hi) return;
+                if (WRITE) mask |= 1u << t;
+                else if (multi) {
+                    const uint32_t x = b - a.b_lo;                  // (b - b_lo) / multi_width: both at most 2^16
+                    uint32_t range;
+                    if (magic24) asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(range) : "v"(x), "v"((uint32_t)multi_magic));   // full rate (v_mul_hi_u32: a quarter)
+                    else range = (uint32_t)(((uint64_t)x * multi_magic) >> 32);
+                    if (few) fields += 1u << (4 * range);
+                    else atomicAdd(&s_range_cnt[range], 1u);
+                }
+                ++cnt;
+            };
+            if (run_first) {                                       // left $  (s2.cpp:531-540)
+                push(0, e, 0);
+                if (!pal) push(1, rc, 2);
+            }
+            push(2, e, 1);                                         // solid   (s2.cpp:543-550)
+            if (!pal) push(3, rc, 1);
+            if (run_last) {                                        // right $ (s2.cpp:553-562)
+                push(4, e, 2);
+                if (!pal) push(5, rc, 0);
+            }
+        }
+        if (!WRITE) {
+            my_count += (uint32_t)cnt;
+            if (few) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (g < (int)a.multi_n) acc[g] += (fields >> (4 * g)) & 15u;
+            }
+        } else {
+            const uint32_t inc = wave_incl_scan((uint32_t)cnt);
+            const uint32_t tot = __shfl(inc, 63, 64);
+            if (tot) {
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_cursor, tot);
+                const uint64_t first = base + (uint64_t)wave_uniform(wbase);   // the wave's slots [first, first + tot): a scalar
+                char *const wave_out = reinterpret_cast<char *>(out + first);
+                uint8_t *const wave_side = a.side ? a.side + first : nullptr;
+                uint32_t slot = inc - (uint32_t)cnt;                    // < 6 * 64
+                // every wanted item straight to its slot (no staging array: a lane-varying index into one costs a waterfall loop per store).
+                // key = characters [from, from + n) of src, flags in the low 4 bits: (n == k) << 3 | prev   [cx1_read2sdbg_s2.cpp:613-671]
+                auto put = [&](int t, const uint32_t (&src)[W], int from, const uint32_t (&keep)[W], uint32_t flags) {
+                    if (!((mask >> t) & 1u)) return;
+                    Key<W> key;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const uint32_t nx = j + 1 < W ? src[j + 1 < W ? j + 1 : j] : 0u;
+                        key.w[j] = (from ? ((src[j] << (2 * from)) | (nx >> (32 - 2 * from))) : src[j]) & keep[j];
+                    }
+                    key.w[W - 1] |= flags;
+                    *reinterpret_cast<Key<W> *>(wave_out + slot * (uint32_t)sizeof(Key<W>)) = key;
+                    if (wave_side) wave_side[slot] = (uint8_t)((key.w[0] - a.side_bias) >> a.side_shift);
+                    ++slot;
+                };
+                const uint32_t e0 = e[0] >> 30, e1 = (e[0] >> 28) & 3u, r0c = rc[0] >> 30, r1c = (rc[0] >> 28) & 3u;
+                put(0, e, 0, m_k, 8u | (uint32_t)kDollar);
+                put(1, rc, 2, m_k1, r1c);
+                put(2, e, 1, m_k, 8u | e0);
+                put(3, rc, 1, m_k, 8u | r0c);
+                put(4, e, 2, m_k1, e1);
+                put(5, rc, 0, m_k, 8u | (uint32_t)kDollar);
+            }
+        }
+    };
+    // The reads of a wave all of one length (the common case) and no solid bits: their positions are numbered through, 64 per round --
+    // reads of 150 bp at k = 44 have 106 positions: 26.5 rounds for the wave's 16 reads instead of 32 (the second round of a read of its
+    // own has 42 of 64 lanes at work).  Else: a read at a time.
+    constexpr int kWaves = kScanBlock / 64, kReadsPerWave = kReadsPerBlock / kWaves;
+    const uint32_t n_mine = r0 + wv < r1 ? (uint32_t)((r1 - r0 - wv + kWaves - 1) / kWaves) : 0u;   // reads r0 + wv + kWaves i, i < n_mine
+    uint32_t my_len = 0;
+    if ((uint32_t)lane < n_mine) my_len = (uint32_t)(s_start[wv + kWaves * lane + 1] - s_start[wv + kWaves * lane]);
+    const uint32_t len0 = wave_uniform(my_len);
+    const bool uniform = !a.is_solid && n_mine > 0 && len0 >= (uint32_t)(k + 1) && len0 - (uint32_t)k <= 4096u &&
+                         __ballot((uint32_t)lane < n_mine && my_len != len0) == 0;
+    static_assert(kReadsPerWave <= 64, "one lane per read of the wave");
+    if (uniform) {
+        const uint32_t npos = len0 - (uint32_t)k, total = npos * n_mine;     // <= 4096 * 16
+        const uint32_t magic = (uint32_t)(((1ull << 32) + npos - 1) / npos);  // idx / npos for idx < 2^16 (npos = 1: magic wraps, handled)
+        if (lane == 0) kmers += (unsigned long long)total;
+        for (uint32_t v = 0; v < total; v += 64) {
+            const uint32_t idx = v + (uint32_t)lane;
+            const bool active = idx < total;
+            const uint32_t i = npos == 1 ? idx : __umulhi(idx, magic), p = idx - i * npos;
+            const uint32_t slot = active ? wv + kWaves * i : wv;           // read r0 + slot
+            positions(active, r0 + slot, s_start[slot], (int)p, (int)npos);
+        }
+    } else {
+        for (uint64_t r = r0 + wv; r < r1; r += kWaves) {
+            const uint64_t s0 = s_start[r - r0];
+            const int len = (int)(s_start[r - r0 + 1] - s0);
+            if (len < k + 1) continue;                                     // s2.cpp:262-264
+            const int npos = len - k;
+            if (lane == 0) kmers += (unsigned long long)npos;
+            for (int c0 = 0; c0 < npos; c0 += 64) positions(c0 + lane < npos, r, s0, c0 + lane, npos);
         }
     }
     if (!WRITE) {
