@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -711,7 +712,10 @@ struct SideShared {
     uint32_t toff[257];                // place in `bytes` of the tile's first key of a digit value
 };
 
-template <int W, bool BIASED = false, bool SIDE = false>
+// STABLE = false: keys of one digit value may leave in any order -- all the FIRST pass of an LSD sort needs (nothing is ordered yet).
+// The rank inside the wave's chunk then comes from an LDS atomic on the wave's counter instead of the eight ballots of wave_match,
+// which are 45 % of the stable kernel's vector instructions (54 of ~120 per key).
+template <int W, bool BIASED = false, bool SIDE = false, bool STABLE = true>
 __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key<W> *in, Key<W> *out, uint64_t n, Digit d, SideShared *ss = nullptr,
                                                  Digit d_next = Digit{0, 0, 0}) {
     constexpr int kItemsPerThread = ScatterCfg<W>::kIpt, kSubTile = ScatterCfg<W>::kSub, kWaveChunk = ScatterCfg<W>::kChunk;   // (shadow the 4096-key constants)
@@ -733,20 +737,34 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
         // phase 1: rank inside the wave chunk: digit + peers of every key, then the wave's running counts round by round
         uint32_t dr[kItemsPerThread], cnt[kItemsPerThread];   // digit | rank-in-wave-chunk << 8 | valid << 31
         get_digits<W, kItemsPerThread, BIASED>(key, d, dr);
+        if constexpr (STABLE) {
 #pragma unroll
-        for (int it = 0; it < kItemsPerThread; ++it) {
-            uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
-            bool valid = j < n_valid;
-            uint32_t dg = valid ? dr[it] : 0u, rank;
-            wave_match(dg, d.bits, valid, rank, cnt[it]);
-            dr[it] = dg | (rank << 8) | ((uint32_t)valid << 31);
-        }
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
+                bool valid = j < n_valid;
+                uint32_t dg = valid ? dr[it] : 0u, rank;
+                wave_match(dg, d.bits, valid, rank, cnt[it]);
+                dr[it] = dg | (rank << 8) | ((uint32_t)valid << 31);
+            }
 #pragma unroll
-        for (int it = 0; it < kItemsPerThread; ++it) {
-            if (dr[it] >> 31) {
-                const uint32_t dg = dr[it] & 255u, rank = (dr[it] >> 8) & 0xFFu, prev = whist[dg];
-                if (rank == cnt[it] - 1) whist[dg] = (uint16_t)(prev + cnt[it]);   // highest peer lane publishes the new count
-                dr[it] += prev << 8;
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                if (dr[it] >> 31) {
+                    const uint32_t dg = dr[it] & 255u, rank = (dr[it] >> 8) & 0xFFu, prev = whist[dg];
+                    if (rank == cnt[it] - 1) whist[dg] = (uint16_t)(prev + cnt[it]);   // highest peer lane publishes the new count
+                    dr[it] += prev << 8;
+                }
+                wave_lds_fence();
+            }
+        } else {
+            uint32_t *const wh32 = reinterpret_cast<uint32_t *>(whist);      // two 16-bit counters per word: a wave's chunk holds <= 512 keys
+#pragma unroll
+            for (int it = 0; it < kItemsPerThread; ++it) {
+                const uint32_t j = (uint32_t)wv * kWaveChunk + (uint32_t)it * 64 + (uint32_t)lane;
+                const bool valid = j < n_valid;
+                const uint32_t dg = valid ? dr[it] : 0u;
+                uint32_t taken = 0;
+                if (valid) taken = (atomicAdd(&wh32[dg >> 1], 1u << (16u * (dg & 1u))) >> (16u * (dg & 1u))) & 0xFFFFu;   // keys of the value before this one, in any order
+                dr[it] = dg | (taken << 8) | ((uint32_t)valid << 31);
             }
             wave_lds_fence();
         }
@@ -834,7 +852,7 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 // side digits only where the tile's bytes fit the LDS next to the staged keys (W <= 7 key words)
 template <int W> constexpr bool kSideFits = sizeof(ScatterShared<W>) + sizeof(SideShared) + 1024 <= 160 * 1024;
 
-template <int W, bool BIASED, bool SIDE = false>
+template <int W, bool BIASED, bool SIDE = false, bool STABLE = true>
 __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
                                                                       const uint64_t *totals, uint8_t *side = nullptr,
@@ -863,7 +881,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Ke
         __syncthreads();
         if (tile_base >= n) return;
         const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
-        scatter_subtiles<W, BIASED, true>(sh, in + tile_base, out, cnt, d, &ss, d_next);
+        scatter_subtiles<W, BIASED, true, STABLE>(sh, in + tile_base, out, cnt, d, &ss, d_next);
         __syncthreads();
         // the tile's bytes, run by run: a wave per 16 digit values, consecutive lanes consecutive bytes
         const int lane = lane_id(), wv = wave_id();
@@ -876,7 +894,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Ke
         __syncthreads();
         if (tile_base >= n) return;
         const uint64_t cnt = (n - tile_base) < (uint64_t)kBlockTile ? (n - tile_base) : (uint64_t)kBlockTile;
-        scatter_subtiles<W, BIASED, false>(sh, in + tile_base, out, cnt, d);
+        scatter_subtiles<W, BIASED, false, STABLE>(sh, in + tile_base, out, cnt, d);
     }
 }
 
@@ -1802,7 +1820,8 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     const int P = tp.P, T = tp.T();
     uint8_t *d_side = side_mode > 0 && P >= 2 && kSideFits<WT> ? pool_get<uint8_t>(ctx, S_SIDE, n_items + 64) : nullptr;
     bool side_valid = first_side_done && d_side;                        // d_side holds the digits of the pass about to run
-    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg, bool have_census, const Digit *dg_next) {
+    static const bool unstable_first = !(getenv("MGTA_SORT_UNSTABLE_FIRST") && atoi(getenv("MGTA_SORT_UNSTABLE_FIRST")) == 0);   // (measurements)
+    auto global_pass = [&](Key<WT> *from, Key<WT> *to, uint64_t cnt, const Digit &dg, bool have_census, const Digit *dg_next, bool unstable_ok) {
         uint64_t tiles = (cnt + kBlockTile - 1) / kBlockTile;
         if (!have_census) {
             if (side_valid) {
@@ -1829,18 +1848,23 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
         const bool write_side = d_side && dg_next;
         const Digit dn = dg_next ? *dg_next : Digit{0, 0, 0};
         const dim3 grid((unsigned)tiles), block(kSortThreads);
-        bool launched = false;
-        if constexpr (kSideFits<WT>) {
-            if (write_side) {
-                if (dg.bias) hipLaunchKernelGGL((radix_scatter_kernel<WT, true, true>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, d_side, dn);
-                else hipLaunchKernelGGL((radix_scatter_kernel<WT, false, true>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, d_side, dn);
-                launched = true;
+        // (the first pass of the sort orders nothing that was ordered before: its ranks need not be stable)
+        auto launch = [&](auto biased, auto side, auto stable) {
+            hipLaunchKernelGGL((radix_scatter_kernel<WT, decltype(biased)::value, decltype(side)::value, decltype(stable)::value>), grid, block, 0, stream, from, to, cnt,
+                               dg, tiles, d_hist, d_totals, decltype(side)::value ? d_side : nullptr, dn);
+        };
+        auto pick_stable = [&](auto biased, auto side) {
+            if (unstable_ok) launch(biased, side, std::false_type{});
+            else launch(biased, side, std::true_type{});
+        };
+        auto pick_side = [&](auto biased) {
+            if constexpr (kSideFits<WT>) {
+                if (write_side) { pick_stable(biased, std::true_type{}); return; }
             }
-        }
-        if (!launched) {
-            if (dg.bias) hipLaunchKernelGGL((radix_scatter_kernel<WT, true, false>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, nullptr, dn);
-            else hipLaunchKernelGGL((radix_scatter_kernel<WT, false, false>), grid, block, 0, stream, from, to, cnt, dg, tiles, d_hist, d_totals, nullptr, dn);
-        }
+            pick_stable(biased, std::false_type{});
+        };
+        if (dg.bias) pick_side(std::true_type{});
+        else pick_side(std::false_type{});
         side_valid = write_side;
         if (scatter_ev) {
             MGTA_HIP_CHECK(hipEventRecord(e1, stream));
@@ -1857,7 +1881,7 @@ static Key<WT> *device_sort(mgta_ctx *ctx, hipStream_t stream, Key<WT> *a, Key<W
     };
     for (int i = P - 1; i >= 0; --i) {
         const Digit dg = pass_digit(i), dn = i > 0 ? pass_digit(i - 1) : Digit{0, 0, 0};
-        if (global_pass(src, dst, n_items, dg, first_census_done && i == P - 1, i > 0 ? &dn : nullptr)) return nullptr;
+        if (global_pass(src, dst, n_items, dg, first_census_done && i == P - 1, i > 0 ? &dn : nullptr, unstable_first && i == P - 1)) return nullptr;
         if (side_failed) return nullptr;
         std::swap(src, dst);
     }
