@@ -852,6 +852,16 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 // side digits only where the tile's bytes fit the LDS next to the staged keys (W <= 7 key words)
 template <int W> constexpr bool kSideFits = sizeof(ScatterShared<W>) + sizeof(SideShared) + 1024 <= 160 * 1024;
 
+// tile of workgroup b of n when workgroup b runs on XCD b % 8 (MGTA_XCD_TILES: 1 = contiguous eighths per XCD, 0 = tile b)
+#ifndef MGTA_XCD_TILES
+#define MGTA_XCD_TILES 1
+#endif
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
+    if (!MGTA_XCD_TILES || n < 64) return b;
+    const uint32_t x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + idx;
+}
+
 template <int W, bool BIASED, bool SIDE = false, bool STABLE = true>
 __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
                                                                       uint64_t n_tiles, const uint64_t *rowoff,
@@ -860,17 +870,20 @@ __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Ke
     __shared__ ScatterShared<W> sh;
     __shared__ uint64_t s64[kSortThreads / 64 + 1];
     const int tid = threadIdx.x;
+    // workgroups go to the 8 XCDs in turn: XCD x takes the x-th eighth of the tiles, so that the tiles that run side by side on one
+    // L2 are neighbours (their runs of a digit value are adjacent in the output: lines shared by two tiles are completed in one L2)
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
     // global base of every digit value for this tile = scan(totals)[digit] + rowoff[digit][tile]
     uint64_t t = tid < 256 ? totals[tid] : 0;
     uint64_t ex = block_excl_scan64<kSortThreads>(t, s64, nullptr);
-    const uint64_t my_off = tid < 256 ? rowoff[(uint64_t)tid * n_tiles + blockIdx.x] : 0;
+    const uint64_t my_off = tid < 256 ? rowoff[(uint64_t)tid * n_tiles + tile] : 0;
     if (tid < 256) sh.gbase[tid] = ex + my_off;
-    const uint64_t tile_base = (uint64_t)blockIdx.x * kBlockTile;
+    const uint64_t tile_base = (uint64_t)tile * kBlockTile;
     if constexpr (SIDE) {
         __shared__ SideShared ss;
         // keys of the tile per digit value: the next tile's row offset (the row total behind the last tile) minus this tile's
         uint64_t c = 0;
-        if (tid < 256) c = (blockIdx.x + 1 < n_tiles ? rowoff[(uint64_t)tid * n_tiles + blockIdx.x + 1] : t) - my_off;
+        if (tid < 256) c = (tile + 1 < n_tiles ? rowoff[(uint64_t)tid * n_tiles + tile + 1] : t) - my_off;
         __syncthreads();                                                 // s64 is free again
         const uint64_t place = block_excl_scan64<kSortThreads>(c, s64, nullptr);
         if (tid < 256) {
