@@ -502,6 +502,16 @@ __device__ __forceinline__ void get_digits(const Key<W> (&key)[N], Digit d, uint
     for (int i = 0; i < N; ++i) dg[i] = __builtin_amdgcn_alignbit(hi[i], lo[i], (uint32_t)off) & mask;
 }
 
+// tile of workgroup b of n when workgroup b runs on XCD b % 8 (MGTA_XCD_TILES: 1 = contiguous eighths per XCD, 0 = tile b)
+#ifndef MGTA_XCD_TILES
+#define MGTA_XCD_TILES 1
+#endif
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
+    if (!MGTA_XCD_TILES || n < 64) return b;
+    const uint32_t x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + idx;
+}
+
 // census: hist[digit * n_tiles + tile]
 template <int W>
 __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W> *keys, uint64_t n, Digit d, uint64_t n_tiles,
@@ -509,7 +519,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W>
     __shared__ uint32_t h[256];
     for (int i = threadIdx.x; i < 256; i += kSortThreads) h[i] = 0;
     __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * kBlockTile;
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);     // (neighbouring tiles' counters share lines: one L2 writes them)
+    uint64_t base = (uint64_t)tile * kBlockTile;
     int wi = W - 1 - (d.pos >> 5), off = d.pos & 31;
     bool straddle = off + d.bits > 32 && wi > 0;
     uint32_t mask = (1u << d.bits) - 1u;
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_kernel(const Key<W>
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + tile] = h[i];
 }
 
 // The same census from the SIDE array of the previous scatter (one byte per key: the digit this pass sorts on, written next to the
@@ -531,7 +542,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_side_kernel(const u
     __shared__ uint32_t h[256];
     for (int i = threadIdx.x; i < 256; i += kSortThreads) h[i] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * kBlockTile;                 // a multiple of 32768: 16-byte loads are aligned
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
+    const uint64_t base = (uint64_t)tile * kBlockTile;                       // a multiple of 32768: 16-byte loads are aligned
     constexpr int kPerThread = kBlockTile / kSortThreads;                    // 32 bytes = two 16-byte loads, consecutive threads consecutive
 #pragma unroll
     for (int half = 0; half < kPerThread / 16; ++half) {
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_census_side_kernel(const u
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
+    for (int i = threadIdx.x; i < 256; i += kSortThreads) hist[(uint64_t)i * n_tiles + tile] = h[i];
 }
 
 // Closed-form key generation (see item_write_closed_kernel) cut along the census tiles of the first global sort pass: workgroup t
@@ -851,16 +863,6 @@ __device__ __forceinline__ void scatter_subtiles(ScatterShared<W> &sh, const Key
 // stable scatter of one 32768-key tile by the current digit
 // side digits only where the tile's bytes fit the LDS next to the staged keys (W <= 7 key words)
 template <int W> constexpr bool kSideFits = sizeof(ScatterShared<W>) + sizeof(SideShared) + 1024 <= 160 * 1024;
-
-// tile of workgroup b of n when workgroup b runs on XCD b % 8 (MGTA_XCD_TILES: 1 = contiguous eighths per XCD, 0 = tile b)
-#ifndef MGTA_XCD_TILES
-#define MGTA_XCD_TILES 1
-#endif
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
-    if (!MGTA_XCD_TILES || n < 64) return b;
-    const uint32_t x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
-    return x * q + (x < r ? x : r) + idx;
-}
 
 template <int W, bool BIASED, bool SIDE = false, bool STABLE = true>
 __global__ __launch_bounds__(kSortThreads, 4) void radix_scatter_kernel(const Key<W> *in, Key<W> *out, uint64_t n, Digit d,
