@@ -281,6 +281,8 @@ typedef struct mgta_astar_stats {
                                                            * > 0: later seeds may have searched where they could have followed a cached path) */
     int64_t hmm_in_lds;                                   /* 1: the HMM tables were staged in LDS; 0: (M + 1)(A + 11) * 8 B beside the heap tops
                                                            * exceed the CU's 160 KB (models longer than ~400 columns): read from device memory */
+    int64_t n_over_limit;                                 /* search sides that outgrew the library's page tables (2 GB per array, ~33 M nodes) and are
+                                                           * reported as failed searches (ok = 0, no extension); named on stderr.  0 in every measured run */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */
@@ -315,6 +317,23 @@ int mgta_astar_batch_packed(mgta_sdbg *, const mgta_hmm *fwd, const mgta_hmm *re
                             int prune_len, double low_cov_penalty, int cache_mode, char **contigs, uint64_t *offsets, mgta_astar_side *sides,
                             mgta_astar_stats *stats);
 int mgta_ctx_set_search_share(mgta_ctx *, int num, int den);     /* this context's search batches use num/den of the CUs (default 1/1) */
+
+/* ---- measurement: the device's random 128-byte line ceiling -------------------------------------------------------------------------
+ * Not part of the reference's interface: the yardstick the search's roofline is priced against (bench.py `search.roofline`).  The A*
+ * expansion (hmm_graph_search.h:191-343) and the succinct-graph walks under it (succinct_dbg.cpp:78-97, rank_and_select.h:153-280)
+ * are chains of random 128-byte line reads.  Every configuration is run once over a table of `table_bytes` (>= 8 GB to leave every
+ * cache behind) with the kernels' own access shape: groups of 8 lanes read one aligned line each (16 B per lane); a wavefront carries
+ * `groups` groups, each with `unroll` independent lines in flight, `waves_per_cu` wavefronts per CU.  dependent = 1 chases pointers
+ * (the next line's index is read from the line just fetched): ns_per_step is then the loaded latency of one dependent line.
+ * In: waves_per_cu 1..32, groups 1..8, unroll 1|2|4|8, dependent 0|1, steps >= 1.  Out: the rest. */
+typedef struct mgta_line_probe {
+    int32_t waves_per_cu, groups, unroll, dependent;
+    uint64_t steps;                  /* line reads per group and chain */
+    int32_t lines_in_flight_per_cu, pad_;
+    uint64_t lines;                  /* lines read by the launch */
+    double ms, gb_per_s, ns_per_step;
+} mgta_line_probe;
+int mgta_probe_random_lines(mgta_ctx *, uint64_t table_bytes, mgta_line_probe *cfg, int n_cfg);
 
 #ifdef __cplusplus
 }

@@ -52,10 +52,19 @@ class AstarStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double), ("n_grown", C.c_int64), ("n_rehash", C.c_int64),
                 ("n_recycled", C.c_int64), ("pool_bytes", C.c_uint64), ("pool_used", C.c_uint64), ("n_resumes", C.c_int64),
                 ("reserve_bytes", C.c_uint64), ("reserve_used", C.c_uint64), ("max_search_nodes", C.c_int64),
-                ("max_search_expansions", C.c_int64), ("order_abandoned", C.c_int64), ("n_cache_drops", C.c_int64), ("hmm_in_lds", C.c_int64)]
+                ("max_search_expansions", C.c_int64), ("order_abandoned", C.c_int64), ("n_cache_drops", C.c_int64), ("hmm_in_lds", C.c_int64), ("n_over_limit", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class LineProbe(C.Structure):
+    _fields_ = [("waves_per_cu", C.c_int32), ("groups", C.c_int32), ("unroll", C.c_int32), ("dependent", C.c_int32), ("steps", C.c_uint64),
+                ("lines_in_flight_per_cu", C.c_int32), ("pad_", C.c_int32), ("lines", C.c_uint64), ("ms", C.c_double), ("gb_per_s", C.c_double),
+                ("ns_per_step", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
 
 
 EDGE_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint16), C.c_int64,
@@ -113,6 +122,7 @@ SYMBOLS = {
     "mgta_hmm_load": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_void_p)]),
     "mgta_hmm_free": (None, [C.c_void_p]),
+    "mgta_probe_random_lines": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(LineProbe), C.c_int]),
     "mgta_astar_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_double,
                                   C.c_int, CONTIG_SINK, C.c_void_p, C.POINTER(AstarStats)]),
 }

@@ -72,6 +72,16 @@ class Context:
     def set_mem_limit(self, nbytes: int):
         check(self._L.mgta_ctx_set_mem_limit(self.h, nbytes), "mgta_ctx_set_mem_limit")
 
+    def probe_random_lines(self, table_bytes: int, configs) -> list[dict]:
+        """The device's random 128-byte line rate / dependent-line latency (mgta_probe_random_lines).  configs: iterable of
+        (waves_per_cu, groups, unroll, dependent, steps); one dict per configuration (lines_in_flight_per_cu, gb_per_s, ns_per_step, ...)."""
+        configs = list(configs)
+        arr = (_lib.LineProbe * len(configs))()
+        for c, (w, g, u, d, steps) in zip(arr, configs):
+            c.waves_per_cu, c.groups, c.unroll, c.dependent, c.steps = int(w), int(g), int(u), int(d), int(steps)
+        check(self._L.mgta_probe_random_lines(self.h, int(table_bytes), arr, len(configs)), "mgta_probe_random_lines")
+        return [c.as_dict() for c in arr]
+
     def keep_stream(self, on=True):
         """whole-range builds leave their whole edge stream on the device, also when they take several memory-bound passes.  on = 2: and the
         records / tip labels of a pass are not copied to the host for the sink (`detach_stream` brings the whole stream over afterwards)"""

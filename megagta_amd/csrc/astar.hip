@@ -255,6 +255,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         std::vector<int64_t> todo[2];
         for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
         std::vector<int32_t> h_status((size_t)n * 2);
+        std::vector<char> over_limit_seen((size_t)n * 2, 0);
         size_t free_b = 0, total_b = 0;
         MGTA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
 
@@ -521,12 +522,21 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             if (gated && h_lim[13])
                 fprintf(stderr, "[megagta_amd] search: %llu path entries found no room in the shared cache (%.1f GB per direction): later seeds may have searched "
                         "where they could have followed a path -- which ones depends on timing\n", h_lim[13], d_cache[0].bytes / 1e9);
+            // a search that reached the page tables' limit is terminal at once (more memory or another pass cannot help, and the searches
+            // behind it have seen nothing of it).  It is ONE seed's side: reported as a failed search (ok = 0, no extension on that side,
+            // named on stderr and counted in mgta_astar_stats.n_over_limit) while the batch goes on -- a multi-k run of hours is not thrown
+            // away for it (advisor r5).  MEGAGTA_SEARCH_STRICT_LIMIT=1: the batch fails with MGTA_EOVERFLOW instead.
             for (int64_t s = 0; s < n * 2; ++s)
-                if (h_status[(size_t)s] == 5) {      // (terminal at once: more memory or another pass cannot help, and the searches behind it have seen nothing of it)
-                    set_error("search %lld (seed %lld, %s) outgrew the library's limit of %d pages of %d KB per array (~%lld M nodes): the reference's pool has no "
-                              "bound (pool_st.h:43), this build's page tables do", (long long)s, (long long)(s / 2), (s & 1) ? "left" : "right", kMaxPages,
-                              1 << (kPageLog - 10), (long long)(((uint64_t)kMaxPages << (kPageLog - 6)) >> 20));
-                    return MGTA_EOVERFLOW;
+                if (h_status[(size_t)s] == 5 && !over_limit_seen[(size_t)s]) {
+                    over_limit_seen[(size_t)s] = 1;     // (named and counted once, however many passes the batch takes)
+                    char msg[384];
+                    snprintf(msg, sizeof(msg), "search %lld (seed %lld, %s) outgrew the library's limit of %d pages of %d KB per array (~%lld M nodes): the reference's pool has no "
+                             "bound (pool_st.h:43), this build's page tables do", (long long)s, (long long)(s / 2), (s & 1) ? "left" : "right", kMaxPages,
+                             1 << (kPageLog - 10), (long long)(((uint64_t)kMaxPages << (kPageLog - 6)) >> 20));
+                    const char *strict = getenv("MEGAGTA_SEARCH_STRICT_LIMIT");
+                    if (strict && atoi(strict) != 0) { set_error("%s", msg); return MGTA_EOVERFLOW; }
+                    fprintf(stderr, "[megagta_amd] search: %s -- this side of the seed is reported as a failed search, the batch goes on\n", msg);
+                    ++ST.n_over_limit;
                 }
             size_t left = 0, starved_out = 0;
             for (int d = 0; d < 2; ++d) {

@@ -20,13 +20,20 @@
 
 namespace mgta {
 
-constexpr int kAstarWaves = 8;                 // waves per workgroup (one workgroup per CU: the HMM tables take most of the LDS)
+#ifndef MGTA_ASTAR_WAVES
+#define MGTA_ASTAR_WAVES 8
+#endif
+constexpr int kAstarWaves = MGTA_ASTAR_WAVES;                 // waves per workgroup (one workgroup per CU: the HMM tables take most of the LDS)
 constexpr int kAstarThreads = kAstarWaves * 64;
 constexpr uint32_t kNone = 0x7FFFFFFFu;
 constexpr int kMaxKmer = 160;
 // heap slots of a search kept in LDS: the root block and its eight child blocks (six tree levels); with 8 lanes per search (twice the
 // searches per workgroup) the root block and four child blocks, so that the HMM tables of a 360-column model still fit beside them
+#ifdef MGTA_ASTAR_LDS_HEAP
+constexpr uint32_t lds_heap_slots(int G) { return MGTA_ASTAR_LDS_HEAP; }
+#else
 constexpr uint32_t lds_heap_slots(int G) { return G >= 16 ? 72u : 40u; }
+#endif
 constexpr int kUnitLog = 12;                   // pool offsets are kept in 4 KB units
 constexpr int kNumClasses = 28;                // chunk size classes: 4 KB << c
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;

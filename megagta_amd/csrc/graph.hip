@@ -195,17 +195,19 @@ static int graph_begin(mgta_ctx *ctx, int k, int64_t size, const int64_t *bucket
     if (n_lines >= 0xFFFFFFFFull) { set_error("graph too large for 32-bit line samples"); return MGTA_EUNSUPPORTED; }
     d.n_lines = n_lines;
     B.n_lines = n_lines; B.size = size;
-    if (adopt_lines) g->lines = std::move(*adopt_lines);
-    else {
+    if (!adopt_lines) {
         g->lines.alloc((n_lines + 1) * sizeof(GLine), &ctx->live_bytes, &ctx->peak_bytes);
         MGTA_HIP_CHECK(hipMemsetAsync(g->lines.p, 0, (n_lines + 1) * sizeof(GLine), st));
     }
     g->tips.alloc((size_t)n_tip_words * 4 + 16, &ctx->live_bytes, &ctx->peak_bytes);
     if (n_tip_words && tips)
         MGTA_HIP_CHECK(hipMemcpyAsync(g->tips.p, tips, (size_t)n_tip_words * 4, tips_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (size > 0) B.d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
+    // the caller's buffer changes hands only once nothing in here can fail any more: an allocation that throws above leaves the stream where
+    // it was, still valid (advisor r5)
+    if (adopt_lines) g->lines = std::move(*adopt_lines);
     d.lines = g->lines.as<GLine>();
     d.tip_labels = g->tips.as<uint32_t>();
-    if (size > 0) B.d_cnt.alloc(n_lines * 6 * 4, &ctx->live_bytes, &ctx->peak_bytes);
     return MGTA_OK;
 }
 static void graph_pack(GraphBuild &B, const uint16_t *dev_recs, int64_t rec_base, uint64_t line_lo, uint64_t line_hi) {
@@ -586,13 +588,19 @@ int mgta_sdbg_load_resident(mgta_ctx *ctx, mgta_sdbg **out) {
                 const int rc = graph_begin(ctx, ctx->last_k, size, ctx->acc_items.data(), static_cast<const uint32_t *>(ctx->last_tips),
                                            (int64_t)ctx->last_n_tips * ctx->last_words_per_tip, ctx->last_words_per_tip, true, B, &ctx->acc_rec);
                 if (rc != MGTA_OK) return rc;
-                graph_pack(B, B.g->lines.as<uint16_t>(), 0, 0, B.n_lines);
-                MGTA_HIP_CHECK(hipMemsetAsync(B.g->lines.as<GLine>() + n_lines, 0, sizeof(GLine), ctx->stream));   // (the line past the end reads as empty)
-                MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                // the stream is gone: it IS the graph now
-                ctx->acc_tips.release(); ctx->acc_valid = false;
-                ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0;
-                return graph_finish(B, out);
+                // from here on the stream's buffer belongs to the graph under construction: whatever happens below, the context must not
+                // go on naming it (a failure frees it with B; a retry or an export would read freed memory)
+                auto forget_stream = [&]() {
+                    ctx->acc_tips.release(); ctx->acc_valid = false;
+                    ctx->last_rec = nullptr; ctx->last_tips = nullptr; ctx->last_first = nullptr; ctx->last_n_rec = 0; ctx->last_n_tips = 0; ctx->last_k = 0;
+                };
+                try {
+                    graph_pack(B, B.g->lines.as<uint16_t>(), 0, 0, B.n_lines);
+                    MGTA_HIP_CHECK(hipMemsetAsync(B.g->lines.as<GLine>() + n_lines, 0, sizeof(GLine), ctx->stream));   // (the line past the end reads as empty)
+                    MGTA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    forget_stream();                               // the stream is gone: it IS the graph now
+                    return graph_finish(B, out);
+                } catch (const HipError &) { forget_stream(); throw; }
             }
         }
         if (ctx->acc_valid)      // a multi-pass build that kept its whole stream (mgta_ctx_keep_stream): records per bucket are on the host

@@ -63,7 +63,7 @@ void PackedReads::append_packed(const uint32_t *w, size_t n, bool reverse) {
     };
     if (reverse) {
         if (nw) push_bits(rev16(w[nw - 1]), 2 * tail);                  // its characters end up in the low 2 * tail bits
-        for (size_t j = nw - 1; j-- > 0;) push_bits(rev16(w[j]), 32);
+        for (size_t j = nw; j-- > 1;) push_bits(rev16(w[j - 1]), 32);   // (nw = 0, an empty read: nothing -- `nw - 1` would wrap)
     } else {
         for (size_t j = 0; j + 1 < nw; ++j) push_bits(w[j], 32);
         if (nw) push_bits(tail == 16 ? w[nw - 1] : w[nw - 1] >> (32 - 2 * tail), 2 * tail);
@@ -127,7 +127,7 @@ void PackedReads::append_packed_many(const uint32_t *const *w, const uint32_t *l
         const int tail = (int)(nb - (nw ? (nw - 1) * 16 : 0));
         if (reverse) {
             if (nw) { bo.put(bit, rev16(s[nw - 1]), 2 * tail); bit += 2 * tail; }
-            for (size_t j = nw - 1; j-- > 0;) { bo.put(bit, rev16(s[j]), 32); bit += 32; }
+            for (size_t j = nw; j-- > 1;) { bo.put(bit, rev16(s[j - 1]), 32); bit += 32; }   // (safe for nw = 0: buildlib keeps empty records)
         } else {
             for (size_t j = 0; j + 1 < nw; ++j) { bo.put(bit, s[j], 32); bit += 32; }
             if (nw) bo.put(bit, tail == 16 ? s[nw - 1] : s[nw - 1] >> (32 - 2 * tail), 2 * tail);

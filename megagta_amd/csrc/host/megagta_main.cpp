@@ -132,7 +132,16 @@ static PackedReads &lib_get(const std::string &bin_path, const std::string &lib_
     }
     mk = g_sess.lib_mark;
     // the contigs this worker's own denovo has just made: taken from their text in memory (the file may still be on its way to the disk)
-    const bool from_memory = g_sess.active && !extra.empty() && extra == g_sess.ctext_path;
+    // (the same FILE however it is spelled -- relative, `//`, a symlinked directory: compared by device + inode once the writer has
+    // created it, by name before; advisor r5)
+    auto same_file = [](const std::string &a, const std::string &b) {
+        if (a == b) return true;
+        struct stat sa, sb;
+        return !a.empty() && !b.empty() && stat(a.c_str(), &sa) == 0 && stat(b.c_str(), &sb) == 0 && sa.st_dev == sb.st_dev && sa.st_ino == sb.st_ino;
+    };
+    const bool from_memory = g_sess.active && !extra.empty() && !g_sess.ctext_path.empty() && same_file(extra, g_sess.ctext_path);
+    // any other extra file is read from the disk: never while the background writer may still be in the middle of one
+    if (g_sess.active && !extra.empty() && !from_memory && g_sess.cwriter.joinable() && contigs_join(false) != 0) die("the contigs of the last denovo are incomplete");
     const std::string key = extra.empty() ? std::string() : from_memory ? "mem|" + extra : file_key(extra);
     if (g_sess.active && g_sess.have_extra && g_sess.extra_key == key) {
         logf("library%s: still in memory", extra.empty() ? "" : " + contigs");
@@ -735,16 +744,19 @@ static int main_denovo(int argc, char **argv) {
          "total length %lld (%.1f ms)", (long long)st.n_tips, st.ms_tips, (long long)st.n_bubbles, (long long)st.n_bubble_candidates,
          (long long)st.n_bubble_rounds, st.ms_bubbles, (long long)st.n_paths, (long long)st.n_contigs, (long long)st.total_len, st.ms_unitigs);
     const std::string cpath = out_prefix + ".contigs.fa";
-    auto write_contigs = [cpath](const char *text, uint64_t n) {
+    const long long info_n = (long long)st.n_contigs, info_len = (long long)st.total_len;
+    auto write_contigs = [cpath, info_n, info_len](const char *text, uint64_t n) {
         FILE *f = fopen(cpath.c_str(), "w");
         if (!f) die("cannot write %s", cpath.c_str());
         if (n && fwrite(text, 1, n, f) != n) die("short write to %s", cpath.c_str());
         if (fclose(f) != 0) die("short write to %s", cpath.c_str());
+        // the .info file LAST: whoever finds it finds a complete contigs file beside it
+        f = fopen((cpath + ".info").c_str(), "w");
+        if (!f) die("cannot write %s.info", cpath.c_str());
+        fprintf(f, "%lld %lld\n", info_n, info_len);                                    // assembler.cpp:162
+        if (fclose(f) != 0) die("short write to %s.info", cpath.c_str());
     };
-    FILE *f = fopen((cpath + ".info").c_str(), "w");
-    if (!f) die("cannot write %s.info", cpath.c_str());
-    fprintf(f, "%lld %lld\n", (long long)st.n_contigs, (long long)st.total_len);        // assembler.cpp:162
-    fclose(f);
+    (void)remove((cpath + ".info").c_str());                                            // (an earlier run's: it would vouch for a file being rewritten)
     if (g_sess.active && !getenv("MEGAGTA_SYNC_WRITES")) {
         // the worker: the text stays for the step that takes these contigs, the file is written behind it (joined by "sync" before the
         // driver's checkpoint says "assembled", and before anything reads the file)

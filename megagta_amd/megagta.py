@@ -477,36 +477,45 @@ def filter_and_translate_side_by_side(k):
 
     def chain(gene):
         d = opt.out_dir + "contigs/" + gene
-        os.makedirs(d, exist_ok=True)
         lines = []
+        results[gene] = lines                            # (set first: whatever happens below, the gene has an entry)
         for cmd, fin_path, fout_path in (([opt.bin, "filterbylen", str(opt.min_contig_len)], graph_prefix(k) + "_raw_contigs_" + gene + ".fasta", d + "/nucl_merged.fasta"),
                                          ([opt.bin, "translate", d + "/nucl_merged.fasta"], None, d + "/prot_merged.fasta")):
-            with open(fout_path, "wb") as fout:
-                fin = open(fin_path, "rb") if fin_path else None
-                try:
-                    p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE)
-                finally:
-                    if fin:
-                        fin.close()
-            lines.append((" ".join(cmd), p.stderr.decode(errors="replace"), p.returncode))
-            if p.returncode != 0:
+            # an exception in this thread (the raw contigs missing, the output not writable, the binary not startable) is a failed
+            # step like a non-zero exit code: it must not leave the gene without its two result lines (advisor r5)
+            try:
+                os.makedirs(d, exist_ok=True)
+                with open(fout_path, "wb") as fout:
+                    fin = open(fin_path, "rb") if fin_path else None
+                    try:
+                        p = subprocess.run(cmd, stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+                    finally:
+                        if fin:
+                            fin.close()
+                lines.append((" ".join(cmd), p.stderr.decode(errors="replace"), p.returncode))
+            except Exception as e:                       # noqa: BLE001 -- reported as the step's failure by the main thread
+                lines.append((" ".join(cmd), "%s: %s" % (type(e).__name__, e), 1))
+            if lines[-1][2] != 0:
                 break
-        results[gene] = lines
 
     threads = [threading.Thread(target=chain, args=(gene,)) for gene in opt.gene_info]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
+    steps = ("Filtering contigs with minimum length = %d" % opt.min_contig_len, "Translating nucl contigs to aa contigs")
     for gene in opt.gene_info:
-        for what, (cmd, err, ret) in zip(("Filtering contigs with minimum length = %d" % opt.min_contig_len, "Translating nucl contigs to aa contigs"), results.get(gene, [])):
+        lines = results.get(gene, [])
+        for what, (cmd, err, ret) in zip(steps, lines):
             logging.info("--- [%s] %s ---" % (datetime.now().strftime("%c"), what))
             logging.debug("cmd: " + cmd)
             for line in err.splitlines():
-                logging.debug(line.rstrip())
+                (logging.debug if ret == 0 else logging.error)(line.rstrip())
             if ret != 0:
-                fail_step("running \"%s\"" % what, ret)
+                fail_step("running \"%s\" for %s" % (what, gene), ret)
             write_cp()
+        if len(lines) != len(steps):                     # exactly two result lines per gene, or the run stops here (never a silent exit 0
+            fail_step("running \"%s\" for %s (no result)" % (steps[len(lines)], gene), 1)   # with the gene's files and checkpoints missing)
 
 
 def search_contigs(k):

@@ -226,6 +226,25 @@ def test_driver_checkpoint_order_of_the_last_step(tmp_path, monkeypatch):
     assert "again" not in calls and drv.cp == 1
 
 
+def test_side_by_side_filters_fail_the_run_when_a_chain_throws(tmp_path, monkeypatch):
+    """the per-gene filter chains run in threads: an exception inside one (here: the raw contigs of one gene do not exist) must end the
+    run as a failed step -- not leave the gene without result lines, skip its checkpoints and exit 0 (advisor r5)"""
+    import importlib
+    import pytest
+    from megagta_amd import megagta as drv
+    drv = importlib.reload(drv)
+    drv.opt.out_dir = str(tmp_path) + "/"
+    drv.opt.temp_dir = drv.opt.out_dir + "tmp/"
+    os.makedirs(drv.opt.temp_dir)
+    drv.opt.gene_info = {"rplB": ("f", "r", "a"), "nirK": ("f", "r", "a")}
+    drv.opt.bin = "/bin/cat"                               # `cat filterbylen 250 < raw > nucl`: fails on its arguments, like any bad step
+    os.makedirs(os.path.dirname(drv.graph_prefix(44)))
+    open(drv.graph_prefix(44) + "_raw_contigs_rplB.fasta", "w").write(">a\nACGT\n")   # nirK's file is missing: open() raises in its thread
+    with pytest.raises(SystemExit) as e:
+        drv.filter_and_translate_side_by_side(44)
+    assert e.value.code != 0
+
+
 def test_search_plan_is_one_table_for_the_binary_and_the_ranks(monkeypatch):
     """the ordered-commit window and the cost term are chosen by the number of seeds of a gene's batch: `megagta search` (C++,
     `megagta searchplan N...` prints its choice, host only) and the multi-GPU ranks (search_dist.window_and_rate) must agree, with and

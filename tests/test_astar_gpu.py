@@ -34,6 +34,35 @@ def toy(ctx, golden_dir):
     return g, fw, rv, d
 
 
+class _Meta20k:
+    """the 20 k-read metagenome of five tests below, made ONCE per module: reads, the device graph, the two models, 400 synthetic seeds
+    (the first 300 are test_vs_oracle_bigger_graph's) and -- built when first asked for -- the oracle's graph of the same reads"""
+
+    def __init__(self, ctx, tmpdir):
+        from megagta_amd import api
+        mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
+        self.mg = mg
+        self.packed, self.start = synth.pack_reads_for_build(mg.reads)
+        stream = ctx.build_sdbg(ctx.upload_reads(self.packed, self.start), 44)
+        synth.write_gene_models(mg.genes, tmpdir)
+        self.fpath, self.rpath = os.path.join(tmpdir, "rplB", "for_enone.hmm"), os.path.join(tmpdir, "rplB", "rev_enone.hmm")
+        self.seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
+        self.g = api.Graph(ctx, stream)
+        self.fw, self.rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(self.fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(self.rpath))
+        self.kmers, self.states = [s[0] for s in self.seeds], [s[1] - 1 for s in self.seeds]
+        self._og = None
+
+    def oracle_graph(self, oracle):
+        if self._og is None:
+            self._og = oracle.Graph(oracle.Stream.build(self.packed, self.start, 44, threads=8))
+        return self._og
+
+
+@pytest.fixture(scope="module")
+def meta20k(ctx, tmp_path_factory):
+    return _Meta20k(ctx, str(tmp_path_factory.mktemp("meta20k")))
+
+
 def request_id(mode):
     return {(16, 0): "g16", (64, 0): "g64", (16, 7): "g16-grow", (64, 7): "g64-grow", (8, 0): "g8", (8, 7): "g8-grow"}[tuple(mode)]
 
@@ -109,24 +138,15 @@ def test_models_beyond_the_lds_vs_reference(ctx, golden_dir, tmp_path, case, sea
     assert st["max_search_expansions"] > 10000                        # (these searches are long ones: ~10^5 expansions per seed)
 
 
-def test_giving_up_the_order_is_opt_in_and_says_so(ctx, oracle, monkeypatch):
+def test_giving_up_the_order_is_opt_in_and_says_so(ctx, oracle, monkeypatch, meta20k):
     """advisor r4: a batch whose searches in flight outgrow their pool used to give up the ORDER of its cache sharing on its own (timing-
     dependent contigs by default on large inputs, and a branch no test ran).  Now the order is held unless MEGAGTA_SEARCH_ALLOW_UNORDERED=1:
     the same starved pool gives the roomy run's result without it, and with it the batch says `order_abandoned`, every search still ends,
     and every contig is a path of the graph through its seed k-mer (which of the admissible paths: a matter of timing, as in the reference's
     multi-thread search, search.cpp:182-189)"""
     from megagta_amd import api
-    import tempfile
-    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
-    packed, start = synth.pack_reads_for_build(mg.reads)
-    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
-    with tempfile.TemporaryDirectory() as td:
-        synth.write_gene_models(mg.genes, td)
-        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
-        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
-        g = api.Graph(ctx, stream)
-        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
-        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+    g, fw, rv, kmers, states, packed, start = meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states, meta20k.packed, meta20k.start
+    if True:
         monkeypatch.delenv("MEGAGTA_SEARCH_ALLOW_UNORDERED", raising=False)
         want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)          # roomy, ordered; prune 0: the largest searches
         assert st0["order_abandoned"] == 0
@@ -144,7 +164,7 @@ def test_giving_up_the_order_is_opt_in_and_says_so(ctx, oracle, monkeypatch):
         # opted in: the batch gave the order up (thousands of refused requests) and said so; every seed has its contig, every contig is a walk
         # in the graph that contains its seed
         assert st2["order_abandoned"] == 1, st2
-        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        og = meta20k.oracle_graph(oracle)
         n_checked = 0
         for r, km in zip(free, kmers):
             c = r.contig(km)
@@ -157,21 +177,15 @@ def test_giving_up_the_order_is_opt_in_and_says_so(ctx, oracle, monkeypatch):
         assert n_checked > 1000
 
 
-def test_vs_oracle_bigger_graph(ctx, oracle):
+def test_vs_oracle_bigger_graph(ctx, oracle, meta20k):
     """1 gene, 20k reads, synthetic seeds (incl. k-mers absent from the graph): GPU == oracle per seed"""
     from megagta_amd import api
-    import tempfile
-    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
-    packed, start = synth.pack_reads_for_build(mg.reads)
-    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
-    with tempfile.TemporaryDirectory() as td:
-        synth.write_gene_models(mg.genes, td)
-        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
-        seeds = synth.synthetic_seeds(mg.genes[0], 45, 300, seed=4)
-        g = api.Graph(ctx, stream)
-        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+    g, fw, rv, fpath, rpath = meta20k.g, meta20k.fw, meta20k.rv, meta20k.fpath, meta20k.rpath
+    seeds = meta20k.seeds[:300]                                      # (synthetic_seeds(.., 300, seed=4) is a prefix of the 400)
+    assert seeds == synth.synthetic_seeds(meta20k.mg.genes[0], 45, 300, seed=4)
+    if True:
         res, st = api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5)
-        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        og = meta20k.oracle_graph(oracle)
         S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), 20, 0.5)
         nexp = 0
         for (kmer, pos), r in zip(seeds, res):
@@ -242,23 +256,15 @@ def test_warm_sequential_equals_reference_search_1thread(toy, search_mode):
 
 @pytest.mark.parametrize("window,rate", [(1, 0), (4, 0), (64, 0), (1, 1), (4, 16), (16, 64), (64, 4), (8, -1), (32, -3),   # rate < 0: c * |rate| seeds
                                          (4, (1, 64, 16)), (16, (4, 500, 64)), (2, (2, 1, 2000))])                      # (rate, knee, rate beyond the knee)
-def test_windowed_warm_vs_oracle(ctx, oracle, window, rate):
+def test_windowed_warm_vs_oracle(ctx, oracle, window, rate, meta20k):
     """cache_mode B (+ cost rate R): the path seed j found with c_j expansions is seen by the seeds >= j + B + c_j // R (R = 0: no cost term;
     (R, K, R2): c_j // R up to K expansions, K // R + (c_j - K) // R2 beyond -- mgta_ctx_set_search_cost_curve);
     deterministic whatever the GPU scheduling; == the oracle run sequentially with the same rule"""
     from megagta_amd import api
-    import tempfile
-    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
-    packed, start = synth.pack_reads_for_build(mg.reads)
-    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
-    with tempfile.TemporaryDirectory() as td:
-        synth.write_gene_models(mg.genes, td)
-        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
-        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
-        g = api.Graph(ctx, stream)
-        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
+    g, fw, rv, fpath, rpath, seeds = meta20k.g, meta20k.fw, meta20k.rv, meta20k.fpath, meta20k.rpath, meta20k.seeds
+    if True:
         runs = [api.astar_search(g, fw, rv, [s[0] for s in seeds], [s[1] - 1 for s in seeds], 20, 0.5, cache_mode=window, cost_rate=rate) for _ in range(2)]
-        og = oracle.Graph(oracle.Stream.build(packed, start, 44, threads=8))
+        og = meta20k.oracle_graph(oracle)
         S = oracle.Searcher(og, oracle.Hmm(fpath), oracle.Hmm(rpath), 20, 0.5)
         S.clear_cache()
         S.set_window(window)
@@ -274,21 +280,12 @@ def test_windowed_warm_vs_oracle(ctx, oracle, window, rate):
                         assert got["real_score"] == ref.real_score and got["fval"] == ref.fval
 
 
-def test_window_mode_grows_in_place_instead_of_failing(ctx):
+def test_window_mode_grows_in_place_instead_of_failing(ctx, meta20k):
     """the CLI's default mode (ordered-commit window) with base arenas of 128 nodes: every search outgrows its arena many times over
     (round 1 returned MGTA_EOVERFLOW from this mode when a search passed 2^18 nodes); results == the same run with roomy arenas"""
     from megagta_amd import api
-    import tempfile
-    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
-    packed, start = synth.pack_reads_for_build(mg.reads)
-    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
-    with tempfile.TemporaryDirectory() as td:
-        synth.write_gene_models(mg.genes, td)
-        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
-        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
-        g = api.Graph(ctx, stream)
-        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
-        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+    g, fw, rv, kmers, states = meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states
+    if True:
         want, st0 = api.astar_search(g, fw, rv, kmers, states, 0, 0.5, cache_mode=8)          # prune 0: the largest searches
         try:
             ctx.set_search_arena(7, 0)
@@ -302,22 +299,13 @@ def test_window_mode_grows_in_place_instead_of_failing(ctx):
             assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
 
 
-def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx):
+def test_window_mode_with_a_starved_pool_is_still_the_roomy_result(ctx, meta20k):
     """ordered-commit window + a pool far too small for the searches in flight: a starved search gives its memory back and starts again
     IN PLACE (its slot keeps holding the window), the lowest running seed is never the one to yield -- the contigs, scores and
     expansion counts are those of the run with all the room, whatever starved when (advisor r2: re-runs after the pass saw other paths)"""
     from megagta_amd import api
-    import tempfile
-    mg = synth.make_metagenome(20000, 150, (("rplB", 120),), seed=9, reads_per_genome=1000)
-    packed, start = synth.pack_reads_for_build(mg.reads)
-    stream = ctx.build_sdbg(ctx.upload_reads(packed, start), 44)
-    with tempfile.TemporaryDirectory() as td:
-        synth.write_gene_models(mg.genes, td)
-        fpath, rpath = os.path.join(td, "rplB", "for_enone.hmm"), os.path.join(td, "rplB", "rev_enone.hmm")
-        seeds = synth.synthetic_seeds(mg.genes[0], 45, 400, seed=4)
-        g = api.Graph(ctx, stream)
-        fw, rv = api.DeviceHmm(ctx, hmmlib.parse_hmm(fpath)), api.DeviceHmm(ctx, hmmlib.parse_hmm(rpath))
-        kmers, states = [s[0] for s in seeds], [s[1] - 1 for s in seeds]
+    g, fw, rv, kmers, states = meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states
+    if True:
         seen_yield, seen_resume, seen_reserve, sizes = False, False, False, []
         # (pools in KB; a search that outgrows its base arena holds three 2 MB pages at least -- nodes, heap slots, hash bucket -- so the
         # small pools serve one or two searches at a time, through the reserve, resumed passes and the one-search-at-a-time last resort:

@@ -113,6 +113,31 @@ def test_host_read_loaders_match_python_packers(tmp_path, golden_dir):
             assert np.array_equal(s, start) and np.array_equal(w, packed) and n_short == len(reads), (threads, route)
 
 
+def test_host_read_loaders_keep_empty_reads(tmp_path):
+    """records of length 0 (buildlib keeps them: sequence_manager.cpp:375-410 writes `len = 0` and no word) through both host loaders,
+    reversed as `buildgraph` / `findstart` load them: first, in the middle, several in a row, last (advisor r5: `nw - 1` wrapped)"""
+    import numpy as np
+    from megagta_amd import readlib
+    rng = np.random.default_rng(11)
+    lens = [0, 17, 0, 0, 16, 1, 0, 33, 0]
+    reads = [rng.integers(0, 4, n).astype(np.uint8) for n in lens]
+    with open(tmp_path / "e.fa", "w") as f:
+        for i, a in enumerate(reads):
+            f.write(f">e{i}\n" + "".join("ACGT"[c] for c in a) + "\n")
+    open(tmp_path / "e.lib", "w").write(f"e\nse {tmp_path}/e.fa\n")
+    r = subprocess.run([BIN, "buildlib", str(tmp_path / "e.lib"), str(tmp_path / "e")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(tmp_path / "e.lib_info").read().splitlines()[0] == f"{sum(lens)} {len(lens)}"
+    got = readlib.load_lib_bin(str(tmp_path / "e"))
+    assert [g.size for g in got] == lens and all(np.array_equal(a, b) for a, b in zip(got, reads))
+    packed, start = readlib.pack_for_build(reads)
+    for mode in ("lib", "bin"):
+        for threads in ("1", "4"):
+            w, s, max_len, n_short = _libdump(tmp_path, str(tmp_path / "e"), mode, env={"OMP_NUM_THREADS": threads})
+            assert np.array_equal(s, start) and np.array_equal(w, packed), (mode, threads)
+            assert max_len == 33 and n_short == len(lens)
+
+
 def test_filterbylen_and_translate_match_reference(tmp_path):
     """the driver's two text filters (host only): same bytes as the reference binary on multi-line records, CRLF, comments, a record
     shorter than the limit, lengths not divisible by three, no newline at the end"""
