@@ -14,7 +14,7 @@ so every rank ends with the whole stream.  Work is fixed as N g
 One JSON line on rank 0: metric / value / unit per BASELINE.json;
   `roofline`     the dominant kernel of the build (algorithmic bytes / HIP-event duration measured inside the library on its own stream);
   `search`       the A* leg on the graph of that build (graph + HMMs replicated; seeds shard by gene, then round-robin; one all-gather
-                 of contigs): expansions/s, achieved bytes/s against the measured random-line ceiling;
+                 of contigs): expansions/s, achieved bytes/s against the random-line peak the library's own HIP probe measures in the same run;
   `e2e`          reads.fa -> contigs through the driver (`megagta.py -k 30,36,45`, rplB + nirK) on a bounded sample (2 M reads), next to the
                  reference binary behind the same driver on the SAME files (`speedup_same_sample`);
   `parity_1M`    the device's edge stream of the CPU-baseline sample against the reference binary's .sdbg files of it (bit-exact or not);
@@ -297,7 +297,7 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                             c[hashlib.md5(l.strip().upper()).digest()] += 1
                 n_contigs[g] = sum(c.values())
                 content[g] = c
-            if n <= 5_000_000:                                           # (the ours-only point beyond the same-sample size is compared with nothing)
+            if n <= 5_000_000 or os.environ.get("MEGAGTA_E2E_KEEP_CONTENT"):   # (the ours-only point beyond the same-sample size is compared with nothing)
                 contents[tag] = content
             shutil.rmtree(od, ignore_errors=True)
             return dt, n_contigs
@@ -408,21 +408,29 @@ def contig_membership(graph, last_contigs: dict, k: int, n_sample: int = 200_000
     return {"sampled": int(ids.size), "found": int((ids >= 0).sum()), "ids_above_2^32": int((ids >= 2 ** 32).sum()), "max_edge_id": int(ids.max())}
 
 
-def random_line_ceiling(torch, n_lines: int = 1 << 26, probes: int = 1 << 26) -> float:
-    """GB/s of independent random 128-byte line reads over a table far larger than the caches (8 GB): the rate the A* leg's
-    graph / arena accesses are priced against ("achieved random-sector rate vs a measured ceiling")"""
-    tab = torch.empty((n_lines, 32), dtype=torch.int32, device="cuda")
-    tab.random_(0, 100)
-    idx = torch.randint(0, n_lines, (probes,), device="cuda")
-    torch.cuda.synchronize()
-    best = 0.0
-    for _ in range(3):
-        t = time.time()
-        s = tab[idx].sum()
-        torch.cuda.synchronize()
-        best = max(best, probes * 128 / (time.time() - t) / 1e9)
-    del tab, idx, s
-    return best
+def random_line_probe(ctx, table_bytes: int = 8 << 30) -> dict:
+    """What this device sustains on random 128-byte lines, measured by the library's own HIP probe (mgta_probe_random_lines, csrc/probe.hip)
+    with the kernels' access shape -- groups of 8 lanes read one aligned line each -- over a table far larger than every cache:
+    independent lines swept over lines in flight per CU (4 ... 2048) and the loaded latency of ONE dependent line (pointer chase).
+    The A* leg and the graph walks under it are priced against these ("achieved random-sector rate vs a measured
+    pointer-chase ceiling"); the torch gather of rounds 2-5 was not a ceiling (the kernel exceeded it)."""
+    indep = []
+    for lif in (4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048):           # waves/CU x groups x unroll: groups first, then waves, then unroll
+        g = min(8, lif); w = min(32 if lif > 1024 else 16, max(1, lif // g)); u = max(1, lif // (g * w))
+        indep.append((w, g, u, 0))
+    dep = [(1, 1, 1, 1), (8, 8, 1, 1), (16, 8, 1, 1), (32, 8, 1, 1)]    # idle chip; 64 / 128 / 256 chains per CU
+
+    def run(cfgs, target_ms=30.0):
+        first = ctx.probe_random_lines(table_bytes, [(*c, 128) for c in cfgs])           # a short pass sizes the timed one
+        return ctx.probe_random_lines(table_bytes, [(*c, min(1 << 22, max(128, int(128 * target_ms / max(r["ms"], 1e-3))))) for c, r in zip(cfgs, first)])
+
+    ri, rdep = run(indep), run(dep)
+    best = max(ri, key=lambda r: r["gb_per_s"])
+    return {"table_bytes": table_bytes, "access": "groups of 8 lanes x 16 B = one aligned 128-byte line per group",
+            "independent": [{"lines_in_flight_per_cu": r["lines_in_flight_per_cu"], "gb_per_s": r["gb_per_s"]} for r in ri],
+            "dependent": [{"chains_per_cu": r["lines_in_flight_per_cu"], "ns_per_line": r["ns_per_step"], "gb_per_s": r["gb_per_s"]} for r in rdep],
+            "peak_gb_per_s": best["gb_per_s"], "peak_at_lines_in_flight_per_cu": best["lines_in_flight_per_cu"],
+            "idle_dependent_ns": rdep[0]["ns_per_step"]}
 
 
 _T0 = time.time()
@@ -601,6 +609,13 @@ def main():
                 mdist.all_gather_all_genes([m[0] for m in mine_all], [m[1] for m in mine_all], [m[2] for m in mine_all], [m[3] for m in mine_all])
             return tot
 
+        # the yardstick of the leg's roofline first, while its 8 GB table still fits beside the graph (the searches' pool takes the rest)
+        line_probe = None
+        if rank == 0:
+            line_probe = random_line_probe(ctx)
+            note(f"random 128-byte lines: peak {line_probe['peak_gb_per_s']:.0f} GB/s at {line_probe['peak_at_lines_in_flight_per_cu']} lines in flight per CU; "
+                 f"one dependent line {line_probe['idle_dependent_ns']:.0f} ns on the idle chip, "
+                 + ", ".join(f"{r['ns_per_line']:.0f} ns at {r['chains_per_cu']} chains/CU" for r in line_probe["dependent"][1:]))
         # warm-up: the first gene alone at 100 M reads (it obtains the pool at its full size and loads the kernels; a whole step takes
         # most of a minute there)
         w0 = sstep([0] if args.reads > 20_000_000 else None)
@@ -628,34 +643,46 @@ def main():
                   "warmup_expansions": w0["n_expansions"],
                   "pool_used_GB": sst[-1]["pool_used"] / 1e9}
         if rank == 0:
-            # roofline of the leg: algorithmic bytes per expansion (170 B x (1 + d1 + d1 d2), 510 B unbranched) over time, against
-            # the rate this device sustains on independent random 128-byte line reads
-            ceiling = random_line_ceiling(torch)
-            note(f"random-line ceiling {ceiling:.0f} GB/s")
-            search["roofline"] = {"bound": "hbm-latency (random 128-byte lines)", "bytes_per_expansion_algorithmic": 510,
-                                  "achieved": rate * 510 / 1e9, "peak": ceiling, "unit": "GB/s", "frac": rate * 510 / 1e9 / ceiling,
-                                  "peak_note": "measured in this run: 2^26 independent random 128-byte line reads over an 8 GB table",
-                                  "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
-            # what the kernel really moves: L2 misses per expansion from the PMC pass of the round (TCC_MISS_sum over the A* dispatches /
-            # expansions; PMC cannot be collected inline), one 128-byte line each, against the same measured ceiling
+            # roofline of the leg.  Bound: random 128-byte lines (graph lines, heap blocks, hash lines, nodes) -- not the 8 TB/s stream rate and
+            # not an MFMA peak.  `peak` = the most this device delivers on independent random lines (the library's HIP probe, measured in this
+            # run before the searches took their pool); `achieved` = the lines the kernel really misses (TCC_MISS per expansion of the round's
+            # PMC pass x 128 B x this run's rate) when that pass is of this workload and kernel source, else SURVEY.md §8d's algorithmic
+            # 510 B per expansion (170 B x (1 + d1 + d1 d2), unbranched).  Both fractions are <= 1 by construction: the probe saturates the
+            # memory system with the same access shape.  `chase` = what the kernel's OWN concurrency (one dependent chain per search slot)
+            # could reach if an expansion were nothing but its line fetches.
+            lanes = 8 if max(len(x) for x in seeds) >= 32768 else 16
+            slots_per_cu = 8 * (64 // lanes)
+            pk = line_probe["peak_gb_per_s"]
+            chase = min(line_probe["dependent"], key=lambda r: abs(r["chains_per_cu"] - slots_per_cu))
+            rl = {"bound": "hbm (random 128-byte lines)", "bytes_per_expansion_algorithmic": 510, "achieved_algorithmic": rate * 510 / 1e9,
+                  "achieved": rate * 510 / 1e9, "achieved_is": "algorithmic bytes", "peak": pk, "unit": "GB/s", "frac": rate * 510 / 1e9 / pk,
+                  "peak_note": "mgta_probe_random_lines in this run: independent random 128-byte lines over an %d GB table, groups of 8 lanes per line, best of a sweep "
+                               "over 4 ... 2048 lines in flight per CU (reached at %d)" % (line_probe["table_bytes"] >> 30, line_probe["peak_at_lines_in_flight_per_cu"]),
+                  "probe": line_probe,
+                  "chase": {"search_slots_per_cu": slots_per_cu, "chains_per_cu": chase["chains_per_cu"], "ns_per_dependent_line": chase["ns_per_line"],
+                            "gb_per_s": chase["gb_per_s"], "note": "pointer chase at the kernel's own concurrency: one dependent line per search slot at a time"},
+                  "hbm_stream_peak": HBM_PEAK_GBS, "frac_of_stream_peak": rate * 510 / 1e9 / HBM_PEAK_GBS}
             cp = os.path.join(ROOT, "profiles", "astar_counters_latest.json")
             if os.path.exists(cp):
                 try:
                     cj = json.load(open(cp))
-                    lanes = 8 if max(len(x) for x in seeds) >= 32768 else 16
                     same = cj.get("reads") == args.reads and cj.get("graph_k") == k and cj.get("lanes_per_search") == lanes and \
                         cj.get("source_signature") == source_signature(*ASTAR_SOURCES)
                     if same:
                         mpe = cj["TCC_MISS_sum"] / cj["expansions"]
-                        search["roofline"]["traffic"] = {"l2_misses_per_expansion": mpe, "line_bytes": 128, "achieved": rate * mpe * 128 / 1e9, "unit": "GB/s",
-                                                         "frac_of_random_line_ceiling": rate * mpe * 128 / 1e9 / ceiling,
-                                                         "note": "TCC_MISS_sum / expansions of the PMC pass `%s` (collected %s at commit %s) x this run's rate: priced on "
-                                                                 "the lines it actually misses" % (cj.get("command"), cj.get("collected"), cj.get("commit"))}
+                        moved = rate * mpe * 128 / 1e9
+                        rl["traffic"] = {"l2_misses_per_expansion": mpe, "line_bytes": 128, "achieved": moved, "unit": "GB/s",
+                                         "over_algorithmic": mpe * 128 / 510, "frac_of_random_line_peak": moved / pk,
+                                         "frac_of_chase_at_kernel_concurrency": moved / chase["gb_per_s"],
+                                         "note": "TCC_MISS_sum / expansions of the PMC pass `%s` (collected %s at commit %s) x this run's rate: priced on "
+                                                 "the lines it actually misses" % (cj.get("command"), cj.get("collected"), cj.get("commit"))}
+                        rl["achieved"], rl["achieved_is"], rl["frac"] = moved, "lines missed (PMC) x 128 B", moved / pk
                     else:
-                        search["roofline"]["traffic"] = None
-                        search["roofline"]["traffic_source"] = "profiles/astar_counters_latest.json is of another workload, lane group or kernel source: not quoted"
+                        rl["traffic"] = None
+                        rl["traffic_source"] = "profiles/astar_counters_latest.json is of another workload, lane group or kernel source: not quoted"
                 except Exception:
                     pass
+            search["roofline"] = rl
         if rank == 0 and world == 1 and last_contigs:
             search["membership"] = contig_membership(graph, last_contigs, k)
             note(f"membership of the returned contigs' (k+1)-mers in the graph: {search['membership']}")

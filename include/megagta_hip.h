@@ -324,8 +324,10 @@ int mgta_ctx_set_search_share(mgta_ctx *, int num, int den);     /* this context
  * are chains of random 128-byte line reads.  Every configuration is run once over a table of `table_bytes` (>= 8 GB to leave every
  * cache behind) with the kernels' own access shape: groups of 8 lanes read one aligned line each (16 B per lane); a wavefront carries
  * `groups` groups, each with `unroll` independent lines in flight, `waves_per_cu` wavefronts per CU.  dependent = 1 chases pointers
- * (the next line's index is read from the line just fetched): ns_per_step is then the loaded latency of one dependent line.
- * In: waves_per_cu 1..32, groups 1..8, unroll 1|2|4|8, dependent 0|1, steps >= 1.  Out: the rest. */
+ * (the next line's index is read from the line just fetched): ns_per_step is then the loaded latency of one dependent line;
+ * dependent = 2: the same chase with a store to another random line in every step (a store in front of a dependent fetch): 16 bytes
+ * per lane = the whole line; dependent = 3: one lane's 16 bytes = a partial line.
+ * In: waves_per_cu 1..32, groups 1..8, unroll 1|2|4|8, dependent 0..3, steps >= 1.  Out: the rest. */
 typedef struct mgta_line_probe {
     int32_t waves_per_cu, groups, unroll, dependent;
     uint64_t steps;                  /* line reads per group and chain */

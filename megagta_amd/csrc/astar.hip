@@ -63,7 +63,7 @@ void launch_astar(const mgta::AstarArgs &a, int blocks, size_t lds_bytes, bool u
     MGTA_HIP_CHECK(hipGetLastError());
 }
 template <int G> size_t lds_fixed() {
-    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::Grp<G>::kLdsHeap * sizeof(mgta::HeapEnt) + mgta::kPtWords * sizeof(uint32_t));
+    return (size_t)mgta::kAstarWaves * mgta::Grp<G>::kGroups * (mgta::Grp<G>::kLdsHeap * sizeof(mgta::HeapEnt) + mgta::kPtWords * sizeof(uint32_t) + mgta::kStage * sizeof(mgta::HeapEnt));
 }
 }  // namespace
 
@@ -253,7 +253,25 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         ST.hmm_in_lds = use_lds ? 1 : 0;
 
         std::vector<int64_t> todo[2];
+        const int hm_M[2] = {fwd->M, rev->M};
         for (int d = 0; d < 2; ++d) { todo[d].resize(n); for (int64_t s = 0; s < n; ++s) todo[d][s] = s; }
+        // Independent searches (cold) may be taken in any order, and a batch cannot end before its longest search does (one expansion of one
+        // search is a chain of dependent line fetches: tens of microseconds, whatever else the device is doing).  The searches that promise the
+        // most work -- the most model columns still to cover on their side -- are therefore started FIRST (longest processing time first), so
+        // that the long ones run beside the bulk instead of after it.  Results are per seed and do not depend on the order.
+        // MGTA_ASTAR_LPT=0 keeps the seed order.  (Shared-cache batches: the order IS the semantics, never touched.)
+        if (cache_mode == 0) {
+            const char *e = getenv("MGTA_ASTAR_LPT");
+            if (!e || atoi(e) != 0) {
+                for (int d = 0; d < 2; ++d) {
+                    const int Md = hm_M[d];
+                    std::stable_sort(todo[d].begin(), todo[d].end(), [&](int64_t x, int64_t y) {
+                        const int cx = d == 0 ? Md - start_state[x] - klen / 3 : start_state[x], cy = d == 0 ? Md - start_state[y] - klen / 3 : start_state[y];
+                        return cx > cy;
+                    });
+                }
+            }
+        }
         std::vector<int32_t> h_status((size_t)n * 2);
         std::vector<char> over_limit_seen((size_t)n * 2, 0);
         size_t free_b = 0, total_b = 0;
@@ -444,9 +462,13 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             }
             MGTA_HIP_CHECK(hipEventRecord(ev.e[2], st));
             if (G == 8) launch_astar<8>(a, (int)blocks, lds_bytes, use_lds, st);
+#ifndef MGTA_ASTAR_G8_ONLY                                                     /* (experiment builds: one instantiation compiles in a quarter of the time) */
             else if (G == 16) launch_astar<16>(a, (int)blocks, lds_bytes, use_lds, st);
             else if (G == 32) launch_astar<32>(a, (int)blocks, lds_bytes, use_lds, st);
             else launch_astar<64>(a, (int)blocks, lds_bytes, use_lds, st);
+#else
+            else { set_error("this experiment build holds the 8-lane kernel only (MGTA_ASTAR_GROUP=8)"); return MGTA_EUNSUPPORTED; }
+#endif
             MGTA_HIP_CHECK(hipEventRecord(ev.e[3], st));
             // MGTA_ASTAR_MONITOR=<seconds>: while the launch runs, a line on stderr every so often -- where the queues are, how many slots
             // hold a search, the lowest running seed and how far it is, the memory in use.  Copies on a stream of their own: the words are
@@ -584,12 +606,22 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             }
 #ifdef MGTA_ASTAR_PROFILE
         {
-            unsigned long long hp[12];
-            MGTA_HIP_CHECK(hipMemcpy(hp, d_prof.p, 96, hipMemcpyDeviceToHost));
-            const char *nm[12] = {"fetch", "gate", "start", "pop+closed", "grow", "cache+walk", "score+probe", "commit", "(run end)", "result+free", "", ""};
-            unsigned long long tot = 0;
-            for (int q = 0; q < 10; ++q) tot += hp[q];
-            for (int q = 0; q < 10; ++q) fprintf(stderr, "[astar-prof] %-12s %6.2f %%\n", nm[q], 100.0 * hp[q] / (tot ? tot : 1));
+            unsigned long long hp[16];
+            MGTA_HIP_CHECK(hipMemcpy(hp, d_prof.p, 128, hipMemcpyDeviceToHost));
+            // the clock the counts are in (s_memtime ticks per 10 ns of s_memrealtime); [3..8] are sums over the SEARCHES that expanded (per
+            // expansion of one search), the rest per wave (see PROF_DECL in astar_kernel.hpp)
+            const double mhz = hp[12] ? 100.0 * (double)hp[13] / (double)hp[12] : 0.0, exps = (double)(hp[10] ? hp[10] : 1), iters = (double)(hp[11] ? hp[11] : 1);
+            const char *nm[10] = {"fetch", "gate", "start", "pop+closed", "grow", "cache+walk", "score+probe", "commit", "(run end)", "result+free"};
+            double sum = 0;
+            for (int q = 3; q <= 8; ++q) sum += (double)hp[q];
+            fprintf(stderr, "[astar-prof] lanes per search %d; clock of the counts %.0f MHz; %llu expansions in %llu expanding wave iterations (%.2f of %d searches expanding in each); "
+                    "one expansion of one search: %.2f us\n", G, mhz, hp[10], hp[11], exps / iters, 64 / G, mhz > 0 ? sum / exps / mhz : 0.0);
+            for (int q = 3; q <= 8; ++q)
+                fprintf(stderr, "[astar-prof]   %-12s %6.2f %%  %8.3f us per expansion of one search\n", nm[q], 100.0 * hp[q] / (sum > 0 ? sum : 1), mhz > 0 ? (double)hp[q] / exps / mhz : 0.0);
+            for (int q : {0, 1, 2, 9})
+                fprintf(stderr, "[astar-prof]   %-12s %8.3f us per expanding wave iteration (wave-level)\n", nm[q], mhz > 0 ? (double)hp[q] / iters / mhz : 0.0);
+            fprintf(stderr, "[astar-prof]   asleep (every running search of the wave waits for memory): %llu times, %.3f us per expanding wave iteration\n",
+                    hp[15], mhz > 0 ? (double)hp[14] / iters / mhz : 0.0);
         }
 #endif
         // results: records and lengths as they are, the strings packed on the device first

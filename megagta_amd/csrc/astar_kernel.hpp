@@ -51,6 +51,7 @@ constexpr int kPageLog = kPageClass + kUnitLog;
 constexpr int kLdsPages = 16;                  // pages of an array named in LDS (32 MB); beyond: a 4 KB table chunk (1024 pages = 2 GB per array)
 constexpr int kMaxPages = 1024;
 constexpr int kPtWords = 3 * kLdsPages + 4;    // LDS words per search: three page tables + the three table chunks' units (+ 1 spare)
+constexpr uint32_t kStage = 8;                 // open-list entries of one walk pass staged in LDS in commit order (more than these: the lane-by-lane loop)
 constexpr uint32_t kStarveLimit = 1u << 15;    // iterations a search waits for memory before it gives up (about a second)
 constexpr uint32_t kMaxNew = 132;              // children one expansion can open (64 codons x {match, insert} + delete), rounded up
 
@@ -416,6 +417,18 @@ template <int G> struct Grp {
     static constexpr uint64_t kMask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
     __device__ static __forceinline__ uint64_t ballot(bool p, int gbase) { return (__ballot(p) >> gbase) & kMask; }
     template <class T> __device__ static __forceinline__ T bcast(T v, int src, int gbase) { return __shfl(v, gbase + src, 64); }
+    // OR over the lanes of the group, in every lane: DPP inside a row of 16 (quad swaps, then the mirrors: after a step all the lanes of a
+    // block hold the block's OR, so mirroring a half row / a row brings in the other block's), shuffles beyond
+    __device__ static __forceinline__ uint32_t or32(uint32_t x) {
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+        if (G >= 16) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);   // row_mirror
+        if (G >= 32) x |= (uint32_t)__shfl_xor((int)x, 16, 64);
+        if (G >= 64) x |= (uint32_t)__shfl_xor((int)x, 32, 64);
+        return x;
+    }
+    __device__ static __forceinline__ uint64_t or64(uint64_t x) { return ((uint64_t)or32((uint32_t)(x >> 32)) << 32) | or32((uint32_t)x); }
 };
 
 // The open list is libstdc++'s binary heap LOGICALLY (index i, children 2i+1 and 2i+2: the sift sequences below are __push_heap /
@@ -494,12 +507,20 @@ template <int G> struct Heap {
             HeapEnt par;
             par.key = 0; par.fval = 0; par.node = 0;
             bool have_par = false;
+            // vmcnt counts stores and loads together, in order: a round's loads issued BEHIND the round before's stores wait for those stores
+            // to be acknowledged as well.  The entry a lane moves up is therefore stored only after the next round's loads are on their way
+            // (they read deeper levels than anything a round writes: nothing is read stale).
+            bool pend = false;
+            int64_t pend_P = 0;
+            HeapEnt pend_ch;
+            pend_ch.key = 0; pend_ch.fval = 0; pend_ch.node = 0;
             while (hole < half) {
                 const int64_t P = ((hole + 1) << (t - 1)) - 1 + p;    // the node whose two children this lane holds
                 const bool has = t <= levels && P < half;
                 HeapEnt el, er;
                 el.key = 0; el.fval = 0; el.node = 0; er = el;
                 if (has) { el = get((uint64_t)(2 * P + 1)); er = get((uint64_t)(2 * P + 2)); }
+                if (pend) { set((uint64_t)pend_P, pend_ch); pend = false; }
                 const bool pick_left = ent_prio(er) < ent_prio(el);    // second = right child; if (right < left) second = left
                 const uint64_t pl = Grp<G>::ballot(pick_left, gbase);
                 uint64_t path = 0;
@@ -511,15 +532,20 @@ template <int G> struct Heap {
                 }
                 HeapEnt ch;                                                       // the child the parent picks (field by field: no address select)
                 ch.key = pick_left ? el.key : er.key; ch.fval = pick_left ? el.fval : er.fval; ch.node = pick_left ? el.node : er.node;
-                if ((path >> gl) & 1ull) set((uint64_t)P, ch);                    // every node of the path moves up one level
+                if ((path >> gl) & 1ull) { pend = true; pend_P = P; pend_ch = ch; }   // every node of the path moves up one level (stored behind the next round's loads)
                 const int deepest = 63 - __builtin_clzll(path);                   // path != 0: the hole has two children
                 hole = Grp<G>::bcast(pick_left ? 2 * P + 1 : 2 * P + 2, deepest, gbase);
                 par.key = Grp<G>::bcast(ch.key, deepest, gbase); par.fval = Grp<G>::bcast(ch.fval, deepest, gbase); par.node = Grp<G>::bcast(ch.node, deepest, gbase);
                 have_par = true;
                 levels = 3;
             }
-            if ((len & 1) == 0 && hole == (len - 2) / 2) {             // a last, single (left) child
-                const HeapEnt ce = get((uint64_t)(2 * hole + 1));
+            const bool single = (len & 1) == 0 && hole == (len - 2) / 2;
+            HeapEnt ce_early;
+            ce_early.key = 0; ce_early.fval = 0; ce_early.node = 0;
+            if (single) ce_early = get((uint64_t)(2 * hole + 1));
+            if (pend) set((uint64_t)pend_P, pend_ch);
+            if (single) {
+                const HeapEnt ce = ce_early;
                 if (gl == 0) set((uint64_t)hole, ce);
                 hole = 2 * hole + 1;
                 par = ce; have_par = true;
@@ -565,6 +591,34 @@ __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_
         i = (i + 1) & cmask;
     }
     return -1;                                                         // (an insert never goes further than this either)
+}
+// the same look-up in two halves: the first probe's two words are asked for early (their round trip to the coherence point runs under the
+// graph walk), the answer is taken when the codons are filtered
+struct CacheProbe { uint64_t i; unsigned long long k, v; };
+__device__ __forceinline__ CacheProbe cache_probe_issue(const AstarArgs &a, int dir, uint64_t key) {
+    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    CacheProbe p;
+    p.i = mix64(key) & cmask;
+    p.k = ld_agent(&tab[p.i].key);
+    p.v = ld_agent(&tab[p.i].val);
+    return p;
+}
+__device__ __forceinline__ int cache_probe_resolve(const AstarArgs &a, int dir, uint64_t key, int64_t seed, CacheProbe p) {
+    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
+    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
+    for (uint32_t probes = 0; probes <= a.cache_probe_limit; ++probes) {
+        if (p.k == 0) return -1;
+        if (p.k == key) {
+            if (p.v == 0ull) return -1;
+            const unsigned long long v = ~p.v;
+            return (int64_t)(v >> 16) <= seed ? (int)(v & 0xFFFF) : -1;
+        }
+        p.i = (p.i + 1) & cmask;
+        p.k = ld_agent(&tab[p.i].key);
+        p.v = ld_agent(&tab[p.i].val);
+    }
+    return -1;
 }
 __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t visible_from, int em_state) {
     CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
@@ -701,13 +755,31 @@ __device__ __forceinline__ int base_of(char ch) {
            : (ch == 'T' || ch == 't') ? 3 : -1;
 }
 
-#ifdef MGTA_ASTAR_PROFILE   // diagnostic build only: per-phase cycle sums (s_memtime) of every wave
-#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MGTA_ASTAR_PROFILE   // diagnostic build only: per-phase cycle sums (s_memtime)
+// Every lane keeps its own sums (the macros run under the lane's own EXEC mask), flushed by the first lane of every GROUP: [3..8] = cycles a
+// RUNNING search spends in the phases of an expansion, [10] = that search's expanding iterations (so [q] / [10] is "per expansion of one
+// search"); [0] [1] [2] [9] (taking seeds, the gate, starting, results) and [11] = wave iterations with an expansion in them are flushed by
+// lane 0 only (wave-level); [12] / [13] = the wave's lifetime in s_memrealtime (100 MHz) / s_memtime ticks: the clock the counts are in;
+// [14] / [15] sleeps of a wave whose running searches all wait for memory.
+#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+    const unsigned long long prt0_ = __builtin_amdgcn_s_memrealtime(), pmt0_ = pt_; bool prun_ = false;
+#ifdef MGTA_ASTAR_PROFILE_DRAIN   // every phase ends with its own memory operations done: the drain of a phase's stores is charged to that phase, not to the next wait
+#define PROF(i) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; }
+#else
 #define PROF(i) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; }
-#define PROF_FLUSH if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) atomicAdd(&a.prof[q_], pacc_[q_]);
+#endif
+#define PROF_ITER(running) { prun_ = (running); if (prun_) pacc_[10] += 1; if (__ballot(prun_)) pacc_[11] += 1; }
+// (a lane whose search did not expand in this iteration has not passed PROF(3..7): its clock is moved up instead of charging the others' expansion to its "run end")
+#define PROF_IDLE_LANES { if (!prun_) pt_ = __builtin_amdgcn_s_memtime(); }
+#define PROF_FLUSH { if (gl == 0) { for (int q_ = 3; q_ <= 8; ++q_) atomicAdd(&a.prof[q_], pacc_[q_]); atomicAdd(&a.prof[10], pacc_[10]); } \
+    if (lane == 0) { atomicAdd(&a.prof[0], pacc_[0]); atomicAdd(&a.prof[1], pacc_[1]); atomicAdd(&a.prof[2], pacc_[2]); atomicAdd(&a.prof[9], pacc_[9]); \
+    atomicAdd(&a.prof[11], pacc_[11]); atomicAdd(&a.prof[14], pacc_[14]); atomicAdd(&a.prof[15], pacc_[15]); \
+    atomicAdd(&a.prof[12], __builtin_amdgcn_s_memrealtime() - prt0_); atomicAdd(&a.prof[13], __builtin_amdgcn_s_memtime() - pmt0_); } }
 #else
 #define PROF_DECL
 #define PROF(i)
+#define PROF_ITER(running)
+#define PROF_IDLE_LANES
 #define PROF_FLUSH
 #endif
 
@@ -720,7 +792,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     HeapEnt *const s_heap = reinterpret_cast<HeapEnt *>(s_mem);
     constexpr uint32_t kLdsHeapSlots = GX::kLdsHeap;
     uint32_t *const s_seg = reinterpret_cast<uint32_t *>(s_mem + (size_t)SPB * kLdsHeapSlots * sizeof(HeapEnt));
-    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + kPtWords * sizeof(uint32_t)));
+    HeapEnt *const s_stage = reinterpret_cast<HeapEnt *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + kPtWords * sizeof(uint32_t)));
+    (void)s_stage;
+    double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + kPtWords * sizeof(uint32_t) + kStage * sizeof(HeapEnt)));
 
     const int dir = blockIdx.x < a.blocks_dir0 ? 0 : 1;
     HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
@@ -1097,6 +1171,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         }
 
         PROF(2)
+        PROF_ITER(st == S_RUN && starved == 0u)
         // ================= one expansion
         if (st == S_RUN) {
             bool stop = false;
@@ -1112,12 +1187,34 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                     // (the node's edge needs no line of its own any more: the node carries where its Forward lands)
                     uint32_t ts;
                     HashEnt *const tb = hfirst(top.key, ts);
-                    const uint32_t t0 = touch(tb + ts), t1 = touch(node_at(top.node));
+                    // The children of this expansion are STORED into node lines no access has touched yet: a store of part of a line that is not
+                    // in the L2 is acknowledged only once the line has been filled from memory (scripts/probe_table_sizes.py: a dependent fetch
+                    // behind such a store takes 1.3 us instead of 0.66), and vmcnt makes the commit's first fetch wait for it.  The next four node
+                    // lines (eight nodes) are therefore asked for now, under the heap repair: by the time the children are written they are there.
+                    uint32_t tn = 0;
+                    const bool tn_on = gl < 4 && n_nodes + 2u * (uint32_t)gl < cap_nodes;
+                    if (tn_on) tn = touch(node_at(n_nodes + 2u * (uint32_t)gl));
+                    // the popped node and the first entry of its key's probe sequence are FETCHED (not only touched) while the heap is repaired:
+                    // they arrive during the repair's own round trips, and the two dependent L2 reads that used to follow it are gone.  The node
+                    // lands in `curr` itself (dead between two expansions: no register is added); a closed top is popped over as before.
+                    uint4 hv = *reinterpret_cast<const uint4 *>(tb + ts);
+                    curr = load_node(node_at(top.node));
                     H.remove_top(n_heap);
-                    touch_done(t0, t1, t1);
                     --n_heap;
-                    bool found;
-                    hs = hfind(top.key, found, hval);
+                    touch_done(tn, tn, tn);
+                    bool found = false;
+                    {
+                        const uint32_t pm_ = hp_pages ? kHashPerPage - 1u : hmask0;
+                        uint32_t i = ts;
+                        while (true) {
+                            const uint64_t k = (uint64_t)hv.x | ((uint64_t)hv.y << 32);
+                            if (k == 0) { found = false; hval = kNone; break; }
+                            if (k == top.key) { found = true; hval = hv.z; break; }
+                            i = (i + 1) & pm_;
+                            hv = *reinterpret_cast<const uint4 *>(tb + i);
+                        }
+                        hs = tb + i;
+                    }
                     if (found && (hval >> 31)) continue;                               // closed
                     cur = (int32_t)top.node;
                     hkey = top.key;
@@ -1128,7 +1225,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 }
                 if (!have) { partial = 1; ok = 1; goal = inter; stop = true; }        // open list ran dry (:339-341)
                 else {
-                    curr = load_node(node_at((uint32_t)cur));
                     const double cv = (curr.real_score + a.exit_prob[curr.length]) / a.log2v;
                     const bool better = cv > inter_val;
                     if (curr.state_no >= M) {                                          // goal (:259-270)
@@ -1357,19 +1453,34 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
 
                 // ---- commit in the reference's order: open_hash[next] = next (:331) and open.push (:335), codon by codon
                 // (ascending (first edge, second edge), then third edge), match before insert, delete last
-                auto commit = [&](uint64_t key, int fval, uint32_t node) {
+                // (every lane of the group, same arguments) open_hash[key] = node, probing from the key's first slot
+                auto hash_commit = [&](uint64_t key, int fval, uint32_t node) {
+                    bool found; uint32_t val;
+                    HashEnt *const hs = hfind(key, found, val);
+                    if (gl == 0) hash_put(hs, 0u, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
+                    if (!found) ++n_keys;
+                };
+                // a probe whose first entry is already loaded: the entry of `key` (found) or the empty slot the sequence ends at
+                auto resolve_at = [&](uint64_t key, HashEnt *t, uint32_t ii, uint4 v, bool &found, uint32_t &val, int &old_fval) -> HashEnt * {
+                    while (true) {
+                        const uint64_t k = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                        if (k == 0) { found = false; return t + ii; }
+                        if (k == key) { found = true; val = v.z; old_fval = (int)v.w; return t + ii; }
+                        ii = (ii + 1) & pmask;
+                        v = *reinterpret_cast<const uint4 *>(t + ii);
+                    }
+                };
+                auto commit = [&](uint64_t key, int fval, uint32_t node, bool with_hash) {
                     HeapEnt he;
                     he.key = key; he.fval = fval; he.node = node;
-                    if (!first) {
-                        bool found; uint32_t val;
-                        HashEnt *const hs = hfind(key, found, val);
-                        if (gl == 0) hash_put(hs, 0u, key, (found ? (val & 0x80000000u) : 0u) | node, fval);
-                        if (!found) ++n_keys;
+                    if (!first && with_hash) {
+                        hash_commit(key, fval, node);
                         n_opened++;
                     }
                     H.sift_up(n_heap, he);
                     ++n_heap;
                 };
+                constexpr bool kCommitHashes = false;                                  // (match / insert children: written where they were probed)
 
                 // ---- enumeration of the <= 64 codon paths (node_enumerator.h:98-128): lane (i, j) walks two edges and owns the <= 4
                 // third edges that continue from there.  kWalkLanes (i, j) pairs per pass, ascending: with 8 lanes per search the first
@@ -1462,25 +1573,56 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                                 cin.fval = to_fval(10000 * (cin.score + 2.0 * h_i));
                             }
                             bool open_m = use, open_i = use && ins_ok;
+                            // the entry of every child's key (found) or the empty slot its probe ended at (new key): open_hash[next] = next (:331) is
+                            // written from here, by the child's own lane, instead of probing again at commit time
+                            HashEnt *pm = nullptr, *pi = nullptr;
+                            uint32_t val_m = 0, val_i = 0;
+                            bool fnd_m = false, fnd_i = false;
+                            const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
                             if (!first) {                                              // :212-233: the first expansion neither prunes nor looks up
                                 open_m = open_m && admissible(cm.length, cm.negative_count, cm.real_score);
                                 open_i = open_i && admissible(cin.length, cin.negative_count, cin.real_score);
-                                const uint64_t key_m = make_key(cm.node_id, cm.state_no, ST_M), key_i = make_key(cin.node_id, cin.state_no, ST_I);
                                 uint32_t slot_m = 0, slot_i = 0;
                                 uint4 vm = make_uint4(0, 0, 0, 0), vi = vm;
-                                if (open_m) vm = ld_first(key_m, slot_m);
-                                if (open_i) vi = ld_first(key_i, slot_i);
-                                uint32_t om = kNone, oi = kNone;
+                                HashEnt *tm = nullptr, *ti = nullptr;
+                                if (open_m) { tm = hfirst(key_m, slot_m); vm = *reinterpret_cast<const uint4 *>(tm + slot_m); }
+                                if (open_i) { ti = hfirst(key_i, slot_i); vi = *reinterpret_cast<const uint4 *>(ti + slot_i); }
                                 int old_m = 0, old_i = 0;
-                                if (open_m) om = resolve(key_m, slot_m, vm, old_m);
-                                if (open_i) oi = resolve(key_i, slot_i, vi, old_i);
-                                if (om != kNone) open_m = old_m < cm.fval;             // got->second < next (:299-302); equal keys => only fval differs
-                                if (oi != kNone) open_i = old_i < cin.fval;
+                                if (open_m) pm = resolve_at(key_m, tm, slot_m, vm, fnd_m, val_m, old_m);
+                                if (open_i) pi = resolve_at(key_i, ti, slot_i, vi, fnd_i, val_i, old_i);
+                                if (fnd_m && (val_m & kNone) != kNone) open_m = old_m < cm.fval;   // got->second < next (:299-302); equal keys => only fval differs
+                                if (fnd_i && (val_i & kNone) != kNone) open_i = old_i < cin.fval;
                             }
                             const uint64_t mm = GX::ballot(open_m, gbase), mi = GX::ballot(open_i, gbase);
                             const uint32_t idx_m = nbase + (uint32_t)__popcll(mm & lt_mask) + (uint32_t)__popcll(mi & lt_mask);
                             if (open_m) store_node(node_at(idx_m), cm);
                             if (open_i) store_node(node_at(idx_m + (open_m ? 1u : 0u)), cin);
+                            if (!first && (mm | mi) != 0ull) {
+                                // The children's keys are distinct, so their entries are too -- except that two NEW keys of this round may have ended
+                                // their probes at the same empty slot.  A bit per new key (six address bits of its slot), OR-ed over the group:
+                                // fewer bits than new keys = two of them may share a slot, and this round's entries are written one after the
+                                // other, each probing again, as the commit used to (rare: the table is at most half full).
+                                const bool new_m = open_m && !fnd_m, new_i = open_i && !fnd_i;
+                                const uint64_t bit_m = new_m ? 1ull << ((reinterpret_cast<uintptr_t>(pm) >> 4) & 63u) : 0ull;
+                                const uint64_t bit_i = new_i ? 1ull << ((reinterpret_cast<uintptr_t>(pi) >> 4) & 63u) : 0ull;
+                                const uint32_t n_new = (uint32_t)__popcll(GX::ballot(new_m, gbase)) + (uint32_t)__popcll(GX::ballot(new_i, gbase));
+                                const bool clash = n_new > 1u && (uint32_t)__popcll(GX::or64(bit_m | bit_i)) < n_new;
+                                const uint32_t idx_i = idx_m + (open_m ? 1u : 0u);
+                                if (!clash) {
+                                    if (open_m) hash_put(pm, 0u, key_m, (fnd_m ? (val_m & 0x80000000u) : 0u) | idx_m, cm.fval);
+                                    if (open_i) hash_put(pi, 0u, key_i, (fnd_i ? (val_i & 0x80000000u) : 0u) | idx_i, cin.fval);
+                                    n_keys += n_new;
+                                } else {
+                                    uint32_t todo = (uint32_t)(mm | mi);
+                                    while (todo) {
+                                        const int l = __builtin_ctz(todo);
+                                        todo &= todo - 1;
+                                        if ((mm >> l) & 1ull) hash_commit(GX::bcast(key_m, l, gbase), GX::bcast(cm.fval, l, gbase), GX::bcast(idx_m, l, gbase));
+                                        if ((mi >> l) & 1ull) hash_commit(GX::bcast(key_i, l, gbase), GX::bcast(cin.fval, l, gbase), GX::bcast(idx_i, l, gbase));
+                                    }
+                                }
+                                n_opened += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
+                            }
                             nbase += (uint32_t)__popcll(mm) + (uint32_t)__popcll(mi);
                             MM |= (mm & 0xFFFFull) << (16 * k);
                             MI |= (mi & 0xFFFFull) << (16 * k);
@@ -1491,6 +1633,44 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                         PROF(6)
                         const uint64_t anyk = MM | MI;
                         uint32_t lanes_todo = (uint32_t)((anyk | (anyk >> 16) | (anyk >> 32) | (anyk >> 48)) & 0xFFFFull);
+                        // The searches of a wave have their children at different (lane, codon rank) places: walking those places one by one makes
+                        // every search sit through the places of all the others.  Each lane writes its own children's open-list entries to
+                        // the search's LDS stage at their rank in the commit order (lane, then codon rank, match before insert), and the
+                        // pushes then go child by child: the wave's loop is as long as its busiest search's child count.
+                        const uint32_t n_c = (uint32_t)__popcll(MM) + (uint32_t)__popcll(MI);
+                        if (n_c != 0u && n_c <= kStage) {
+                            HeapEnt *const stage = s_stage + (size_t)lslot * kStage;
+                            const uint32_t lo16 = gl < 16 ? (1u << gl) - 1u : 0xFFFFu;
+                            const uint64_t LB = 0x0001000100010001ull * (uint64_t)lo16;
+                            uint32_t r = (uint32_t)__popcll(MM & LB) + (uint32_t)__popcll(MI & LB);
+                            uint32_t kb = n_before;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint32_t mmk = (uint32_t)(MM >> (16 * k)) & 0xFFFFu, mik = (uint32_t)(MI >> (16 * k)) & 0xFFFFu;
+                                const bool hm_ = gl < 16 && ((mmk >> gl) & 1u), hi_ = gl < 16 && ((mik >> gl) & 1u);
+                                if (hm_ || hi_) {
+                                    const int64_t e3 = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+                                    const uint32_t idx = kb + (uint32_t)__popc(mmk & lo16) + (uint32_t)__popc(mik & lo16);
+                                    HeapEnt he;
+                                    if (hm_) {
+                                        he.key = make_key(e3 >> 4, next_state, ST_M); he.fval = k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3; he.node = idx;
+                                        stage[r++] = he;
+                                    }
+                                    if (hi_) {
+                                        he.key = make_key(e3 >> 4, curr.state_no, ST_I); he.fval = k == 0 ? fi0 : k == 1 ? fi1 : k == 2 ? fi2 : fi3; he.node = idx + (hm_ ? 1u : 0u);
+                                        stage[r++] = he;
+                                    }
+                                }
+                                kb += (uint32_t)__popc(mmk) + (uint32_t)__popc(mik);
+                            }
+                            wave_lds_fence();
+                            for (uint32_t c = 0; c < n_c; ++c) {
+                                const HeapEnt he = stage[c];
+                                commit(he.key, he.fval, he.node, kCommitHashes);
+                            }
+                            wave_lds_fence();
+                            lanes_todo = 0u;
+                        }
                         while (lanes_todo) {
                             const int l = __builtin_ctz(lanes_todo);
                             lanes_todo &= lanes_todo - 1;
@@ -1505,9 +1685,9 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                                 if (hm_ || hi_) {
                                     const int64_t e3 = k == 0 ? q0 : k == 1 ? q1 : k == 2 ? q2 : q3;
                                     const uint32_t idx = kbase + (uint32_t)__popc(mmk & below) + (uint32_t)__popc(mik & below);
-                                    if (hm_) commit(make_key(e3 >> 4, next_state, ST_M), GX::bcast(k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3, l, gbase), idx);
+                                    if (hm_) commit(make_key(e3 >> 4, next_state, ST_M), GX::bcast(k == 0 ? fm0 : k == 1 ? fm1 : k == 2 ? fm2 : fm3, l, gbase), idx, kCommitHashes);
                                     if (hi_) commit(make_key(e3 >> 4, curr.state_no, ST_I), GX::bcast(k == 0 ? fi0 : k == 1 ? fi1 : k == 2 ? fi2 : fi3, l, gbase),
-                                                    idx + (hm_ ? 1u : 0u));
+                                                    idx + (hm_ ? 1u : 0u), kCommitHashes);
                                 }
                                 kbase += (uint32_t)__popc(mmk) + (uint32_t)__popc(mik);
                             }
@@ -1527,7 +1707,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 const uint32_t idx_d = nbase;
                 if (del && gl == 0) store_node(node_at(idx_d), cd);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (del) commit(make_key(cd.node_id, cd.state_no, ST_D), cd.fval, idx_d);
+                if (del) commit(make_key(cd.node_id, cd.state_no, ST_D), cd.fval, idx_d, true);
                 n_nodes = nbase + (del ? 1u : 0u);
                 if (first) {
                     first = false;
@@ -1539,11 +1719,16 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             PROF(7)
             if (stop) st = S_DONE;
         }
+        PROF_IDLE_LANES
+        PROF(8)
         if (__ballot(st == S_RUN && starved == 0) == 0ull && __ballot(st == S_RUN) != 0ull) {   // every running search of the wave waits for memory
 #pragma unroll
             for (int z = 0; z < 4; ++z) __builtin_amdgcn_s_sleep(127);
+#ifdef MGTA_ASTAR_PROFILE
+            pacc_[15] += 1;
+#endif
         }
-        PROF(8)
+        PROF(14)
 
         // ================= result: getHighestScoreNode + partialResultFromGoal (hmm_graph_search.h:83-110,345-356)
         const bool finishing = st == S_DONE;

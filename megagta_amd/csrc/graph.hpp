@@ -299,10 +299,13 @@ __device__ __forceinline__ OutSet g_outset_line(const GraphDev &g, const LineR &
     uint64_t li = (a & 1) ? (hh & 0xFFFFFFFFull) : (hh >> 32);           // fwd_hint[a-1]
     LineR A = g_load_line(g, li);
     // (ones of `last` before the NEXT line = before this one + in this one: no need to touch the next line to know that the target is here)
-    const uint64_t next_rank = A.rank_last + (uint64_t)__popcll(A.last);
-    if (li + 1 < g.n_lines && (int64_t)next_rank <= r) {                  // rare: the target is a line or two further
-        do { ++li; } while (li + 1 < g.n_lines && (int64_t)g.lines[li + 1].rank_last <= r);
+    uint64_t next_rank = A.rank_last + (uint64_t)__popcll(A.last);
+    // the target is a line further (now and then two): that line is fetched WHOLE at once -- its own counts say whether the target is in it --
+    // instead of first asking the line behind it for its rank and then fetching the line (two dependent trips)
+    while (li + 1 < g.n_lines && (int64_t)next_rank <= r) {
+        ++li;
         A = g_load_line(g, li);
+        next_rank = A.rank_last + (uint64_t)__popcll(A.last);
     }
     const int xj = select64(A.last, (int)(r - (int64_t)A.rank_last));
     const uint64_t upto = xj == 63 ? ~0ull : ((2ull << xj) - 1ull);      // bits 0 .. xj

@@ -7,7 +7,8 @@
 // access shape the kernels use: a GROUP OF 8 LANES reads one aligned 128-byte line (16 B per lane, one request), a wavefront carries
 // `groups` (1..8) such groups, every group keeps `unroll` (1..8) independent lines in flight, `waves_per_cu` (1..32) waves per CU.
 // Lines in flight per CU = waves_per_cu * groups * unroll.  dependent = 1: the next line's index comes out of the line just read
-// (pointer chase: unroll chains per group), so time / steps is the loaded latency of one dependent line.
+// (pointer chase: unroll chains per group), so time / steps is the loaded latency of one dependent line; dependent = 2: the chase with a
+// 16-byte store to another random line in every step (what a store in front of a dependent fetch costs: vmcnt counts both).
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -29,8 +30,12 @@ __global__ __launch_bounds__(256) void probe_fill_kernel(uint4 *tab, uint64_t n_
     }
 }
 
-template <int U, bool DEP>
-__global__ __launch_bounds__(64) void probe_lines_kernel(const uint4 *__restrict__ tab, uint64_t n_lines, int groups, uint64_t steps, uint64_t salt,
+// DEP: 0 = independent lines, 1 = pointer chase, 2 = pointer chase in which every step also STORES 16 bytes per lane (the group: a whole
+// line) to another random line (3: ONE lane of the group stores its 16 bytes: a partial line) before it
+// reads the next one (vmcnt counts stores and loads together, in order: the load's wait is also the wait for the store's acknowledgement --
+// the shape of the A* commit, where a heap / hash / node store is followed by the next dependent fetch)
+template <int U, int DEP>
+__global__ __launch_bounds__(64) void probe_lines_kernel(uint4 *tab, uint64_t n_lines, int groups, uint64_t steps, uint64_t salt,
                                                          unsigned long long *sink) {
     const int lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
     if (grp >= groups) return;                                         // (whole groups leave: the rest of the wave runs on)
@@ -47,6 +52,11 @@ __global__ __launch_bounds__(64) void probe_lines_kernel(const uint4 *__restrict
         for (int u = 0; u < U; ++u) {
             const uint64_t got = (uint64_t)v[u].x | ((uint64_t)v[u].y << 32);
             acc += got + v[u].z;
+            if (DEP == 2 || (DEP == 3 && sub == 0)) {                   // (the stored element keeps its line's words: the chase reads the same values afterwards)
+                const uint64_t wl = line_of(pmix(got + 0x632BE59BD9B4E019ULL + (uint64_t)u), n_lines), e = wl * 8 + (uint64_t)sub;
+                const uint64_t h = pmix(wl + 0x9E3779B97F4A7C15ULL);
+                tab[e] = make_uint4((uint32_t)h, (uint32_t)(h >> 32), (uint32_t)e, (uint32_t)s);
+            }
             if (DEP) idx[u] = line_of(pmix(got ^ (s + (uint64_t)u)), n_lines);   // the next line is named by the one just read
             else idx[u] = line_of(pmix(salt + gid * 0x100000001B3ULL + (s + 1) * 0xD6E8FEB86659FD93ULL + (uint64_t)u * 0x9E3779B97F4A7C15ULL), n_lines);
         }
@@ -55,9 +65,11 @@ __global__ __launch_bounds__(64) void probe_lines_kernel(const uint4 *__restrict
 }
 
 template <int U>
-void launch_probe(bool dep, int blocks, const uint4 *tab, uint64_t n_lines, int groups, uint64_t steps, uint64_t salt, unsigned long long *sink, hipStream_t st) {
-    if (dep) hipLaunchKernelGGL((probe_lines_kernel<U, true>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
-    else hipLaunchKernelGGL((probe_lines_kernel<U, false>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
+void launch_probe(int dep, int blocks, uint4 *tab, uint64_t n_lines, int groups, uint64_t steps, uint64_t salt, unsigned long long *sink, hipStream_t st) {
+    if (dep == 3) hipLaunchKernelGGL((probe_lines_kernel<U, 3>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
+    else if (dep == 2) hipLaunchKernelGGL((probe_lines_kernel<U, 2>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
+    else if (dep) hipLaunchKernelGGL((probe_lines_kernel<U, 1>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
+    else hipLaunchKernelGGL((probe_lines_kernel<U, 0>), dim3(blocks), dim3(64), 0, st, tab, n_lines, groups, steps, salt, sink);
 }
 
 }  // namespace
@@ -69,7 +81,7 @@ extern "C" int mgta_probe_random_lines(mgta_ctx *ctx, uint64_t table_bytes, mgta
     for (int i = 0; i < n_cfg; ++i) {
         const mgta_line_probe &c = cfg[i];
         const bool u_ok = c.unroll == 1 || c.unroll == 2 || c.unroll == 4 || c.unroll == 8;
-        if (c.waves_per_cu < 1 || c.waves_per_cu > 32 || c.groups < 1 || c.groups > 8 || !u_ok || c.steps < 1) {
+        if (c.waves_per_cu < 1 || c.waves_per_cu > 32 || c.groups < 1 || c.groups > 8 || !u_ok || c.steps < 1 || c.dependent < 0 || c.dependent > 3) {
             set_error("mgta_probe_random_lines: configuration %d: waves_per_cu 1..32, groups 1..8, unroll 1|2|4|8, steps >= 1", i);
             return MGTA_EINVAL;
         }
@@ -94,10 +106,10 @@ extern "C" int mgta_probe_random_lines(mgta_ctx *ctx, uint64_t table_bytes, mgta
             const uint64_t salt = 0x5851F42D4C957F2DULL * (uint64_t)(i + 1);
             hipError_t e = hipEventRecord(e0, st);
             switch (c.unroll) {
-                case 1: launch_probe<1>(c.dependent != 0, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
-                case 2: launch_probe<2>(c.dependent != 0, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
-                case 4: launch_probe<4>(c.dependent != 0, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
-                default: launch_probe<8>(c.dependent != 0, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
+                case 1: launch_probe<1>(c.dependent, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
+                case 2: launch_probe<2>(c.dependent, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
+                case 4: launch_probe<4>(c.dependent, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
+                default: launch_probe<8>(c.dependent, blocks, tab.as<uint4>(), n_lines, c.groups, c.steps, salt, sink.as<unsigned long long>(), st); break;
             }
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipEventRecord(e1, st);

@@ -26,7 +26,8 @@ for lif in (4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048):
     g = min(8, lif); w = min(32 if lif > 1024 else 16, max(1, lif // g)); u = max(1, lif // (g * w))
     indep.append((w, g, u, 0))
 indep += [(8, 8, 1, 0), (32, 8, 1, 0), (32, 8, 2, 0), (32, 8, 4, 0), (8, 8, 8, 0), (16, 8, 8, 0)]
-dep = [(1, 1, 1, 1), (1, 8, 1, 1), (8, 8, 1, 1), (16, 8, 1, 1), (32, 8, 1, 1), (8, 8, 4, 1), (16, 8, 4, 1), (32, 8, 4, 1)]
+dep = [(1, 1, 1, 1), (1, 8, 1, 1), (8, 8, 1, 1), (16, 8, 1, 1), (32, 8, 1, 1), (8, 8, 4, 1), (16, 8, 4, 1), (32, 8, 4, 1),
+       (1, 1, 1, 2), (1, 8, 1, 2), (8, 8, 1, 2), (16, 8, 1, 2)]           # ... and the chase with a 16-byte store to a random line in every step
 res_i = run(indep)
 res_d = run(dep)
 print(f"table {gb:.0f} GB of 128-byte lines; groups of 8 lanes read one line each")
@@ -35,7 +36,7 @@ for r in res_i:
     print(f"   {r['waves_per_cu']:3d} {r['groups']:2d} {r['unroll']:2d} | {r['lines_in_flight_per_cu']:5d} | {r['gb_per_s']:8.1f} | {r['gb_per_s'] / 128:6.2f}")
 print("dependent chains:   waves/CU groups chains | chains/CU |  ns per dependent line | GB/s")
 for r in res_d:
-    print(f"   {r['waves_per_cu']:3d} {r['groups']:2d} {r['unroll']:2d} | {r['lines_in_flight_per_cu']:5d} | {r['ns_per_step']:8.1f} | {r['gb_per_s']:8.1f}")
+    print(f"   {r['waves_per_cu']:3d} {r['groups']:2d} {r['unroll']:2d} | {r['lines_in_flight_per_cu']:5d} | {r['ns_per_step']:8.1f} | {r['gb_per_s']:8.1f}" + ("   (+ a store per step)" if r["dependent"] == 2 else ""))
 best = max(res_i, key=lambda r: r["gb_per_s"])
 doc = {"table_bytes": tb, "independent": res_i, "dependent": res_d, "peak_gb_per_s": best["gb_per_s"],
        "peak_at_lines_in_flight_per_cu": best["lines_in_flight_per_cu"], "idle_dependent_ns": res_d[0]["ns_per_step"]}

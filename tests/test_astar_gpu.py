@@ -200,6 +200,39 @@ def test_vs_oracle_bigger_graph(ctx, oracle, meta20k):
         assert st["n_expansions"] == nexp and nexp > 10000
 
 
+def test_longest_first_order_of_cold_batches_changes_no_result(ctx, meta20k, monkeypatch):
+    """independent (cold) searches are started in descending order of the model columns their side has to cover (the long ones run beside
+    the bulk, not after it): per seed the contigs, scores and counts are those of the run in seed order (MGTA_ASTAR_LPT=0)"""
+    from megagta_amd import api
+    monkeypatch.setenv("MGTA_ASTAR_LPT", "0")
+    want, st0 = api.astar_search(meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states, 20, 0.5)
+    monkeypatch.delenv("MGTA_ASTAR_LPT")
+    got, st1 = api.astar_search(meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states, 20, 0.5)
+    assert st0["n_expansions"] == st1["n_expansions"] > 10000
+    for a, b, km in zip(got, want, meta20k.kmers):
+        assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
+
+
+def test_random_line_probe_reports_rates_and_latencies(ctx):
+    """mgta_probe_random_lines (the yardstick of the search leg's roofline, csrc/probe.hip) on a small table: every configuration reads the lines it
+    says, independent reads are faster than a pointer chase, a chase with a store in every step is no faster than the bare chase, and bad
+    configurations are refused"""
+    from megagta_amd import api
+    cfgs = [(4, 8, 4, 0, 512), (4, 8, 1, 1, 512), (4, 8, 1, 2, 512), (4, 8, 1, 3, 512), (1, 1, 1, 1, 2048)]
+    res = ctx.probe_random_lines(256 << 20, cfgs)
+    n_cu = res[0]["lines"] // (4 * 8 * 4 * 512)
+    assert n_cu >= 8
+    for (w, g, u, d, steps), r in zip(cfgs, res):
+        assert r["lines"] == n_cu * w * g * u * steps and r["lines_in_flight_per_cu"] == w * g * u
+        assert r["ms"] > 0 and r["gb_per_s"] > 0 and r["ns_per_step"] > 0
+    assert res[0]["gb_per_s"] > 2 * res[1]["gb_per_s"]                  # 128 independent lines in flight per CU against 32 dependent chains
+    assert res[4]["ns_per_step"] > 100                                  # one dependent line on an idle chip: hundreds of nanoseconds
+    assert res[2]["ns_per_step"] > 0.9 * res[1]["ns_per_step"]
+    for bad in ((0, 8, 1, 0, 16), (4, 9, 1, 0, 16), (4, 8, 3, 0, 16), (4, 8, 1, 4, 16), (4, 8, 1, 0, 0)):
+        with pytest.raises(api.MegaGtaError):
+            ctx.probe_random_lines(256 << 20, [bad])
+
+
 def test_bad_seed_is_loud(toy):
     from megagta_amd import api
     g, fw, rv, d = toy
