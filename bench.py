@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s, ~6.3 TB/s achievable)
 REF = os.path.join(ROOT, "oracle", "_ref", "megagta")
 DRIVER = os.path.join(ROOT, "megagta_amd", "megagta.py")
+RECORDED_REFERENCE = os.path.join(ROOT, "profiles", "r06", "e2e_10M_reference.json")   # scripts/e2e_reference_at_size.py: ours and the reference on 10 M reads
 
 
 def host_cores() -> dict:
@@ -254,7 +255,7 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                 out_[g] = (sum((ca & cb).values()) / nb) if nb else (1.0 if not ca else 0.0)
             return out_
 
-        def run(n, tag, extra, env=None):
+        def ensure_set(n):
             if n not in sets:
                 mg = synth.make_metagenome_device(n, 150, gene_specs, seed=1000 + n % 997, device=device, host_sample=n)
                 d = os.path.join(tmp, f"set_{n}")
@@ -262,6 +263,9 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                 write_fasta_fast(mg.sample_reads, os.path.join(d, "reads.fa"))
                 sets[n] = (os.path.join(d, "reads.fa"), gl_, [g.name for g in mg.genes])
                 del mg
+
+        def run(n, tag, extra, env=None):
+            ensure_set(n)
             fa, gl, names = sets[n]
             od = os.path.join(tmp, "out_" + tag)
             t = time.time()
@@ -312,9 +316,16 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             out["ours_unordered_cache"] = {"reads": n_ours, "seconds": dtu, "reads_per_s": n_ours / dtu, "contigs": ncu,
                                            "note": "MEGAGTA_CACHE_WINDOW=-1: every search sees whatever paths are in the cache when it looks, as the "
                                                    "reference's multi-thread `search` does; which of several equally scored paths a seed takes depends on timing"}
-        if n_ref > 0 and os.path.exists(REF):
-            # the reference binary behind the same driver.  Its best thread count is found on the small set (16 / 32; every core was
-            # 3.7x slower than 32 in round 2, 64 threads 1.2x slower in round 4), then it runs ONCE on the SAME files as ours above: one equal-work ratio, nothing else
+        # The reference binary behind the same driver (CPU only) and our larger run (GPU + a few host threads) use different parts of the box: they
+        # run SIDE BY SIDE (half of the driver's 443 s was the reference on the host while the GPU idled).  The reference has its
+        # `-t` threads to itself as long as the host has cores for both (64 on the pool's boxes: 32 + ours' 16); MEGAGTA_E2E_SERIAL=1 runs them one
+        # after the other as rounds 2-5 did.
+        import threading
+        ref_box = {}
+
+        def reference_leg():
+            # Its best thread count is found on the small set (16 / 32; every core was 3.7x slower than 32 in round 2, 64 threads 1.2x slower
+            # in round 4), then it runs ONCE on the SAME files as ours above: one equal-work ratio, nothing else
             sweep = {}
             forced = os.environ.get("MEGAGTA_E2E_REF_THREADS")          # (one-off runs at sizes where the sweep does not fit the call)
             best_t = int(forced) if forced else 0
@@ -325,12 +336,67 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                     note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
                 if sweep:
                     best_t = min(sweep, key=sweep.get)
-                    out["reference_thread_sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
+                    ref_box["sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
                 dtr, ncr = run(n_ours, f"ref_t{best_t}", ["--bin", REF, "-t", str(best_t)])
+                note(f"e2e reference, {best_t} threads: {n_ours} reads in {dtr:.1f} s")
+                ref_box.update(best_t=best_t, dtr=dtr, ncr=ncr)
             except TimeoutError as e:
-                out["reference"] = {"reads": n_ours, "threads": best_t, "cut_off": str(e)}
+                ref_box.update(best_t=best_t, cut_off=str(e))
+            except Exception as e:                                       # noqa: BLE001 -- reported in the line, never lost in a thread
+                ref_box.update(best_t=best_t, error=repr(e))
+
+        def large_leg():
+            # a point beyond the same-sample size, ours only (the reference needs ~60 s per million reads; profiles/r06 holds it at 10 M reads): skipped when the run is late
+            if time.time() > large_deadline:
+                out["ours_large"] = {"reads": n_large, "skipped": "the bench run was %.0f s old when this leg was due: not started" % (time.time() - _T0)}
+                return
+            try:
+                dtl, ncl = run(n_large, "ours_large", ["-t", str(min(cores, 16))])
+            except TimeoutError as e:
+                out["ours_large"] = {"reads": n_large, "cut_off": str(e)}
+                return
+            note(f"e2e ours: {n_large} reads in {dtl:.1f} s")
+            out["ours_large"] = {"reads": n_large, "seconds": dtl, "reads_per_s": n_large / dtl, "contigs": ncl,
+                                 "note": "megagta.py -k %s on %d reads, default mode, ours only in THIS run" % (klist, n_large)}
+            # the reference at this size is a quarter of an hour of host time: measured once by the builder on a box of the same pool, on the same
+            # generated read set (same seed, same files) -- quoted with its date and commit, never re-timed here
+            try:
+                rj = json.load(open(RECORDED_REFERENCE))
+                if rj["reference"]["reads"] == n_large and rj.get("k_list") == klist and rj.get("genes") == out["genes"] and "seconds" in rj["reference"]:
+                    out["ours_large"]["speedup_vs_recorded_reference"] = {
+                        "value": rj["reference"]["seconds"] / dtl, "reference_seconds": rj["reference"]["seconds"], "reference_threads": rj["reference"]["threads"],
+                        "ours_seconds_in_that_run": rj["ours"]["seconds"], "speedup_in_that_run": rj.get("speedup_same_sample"),
+                        "contigs_equal_fraction_in_that_run": rj.get("contigs_equal_fraction"), "recorded": rj.get("date"), "commit": rj.get("commit"),
+                        "file": os.path.relpath(RECORDED_REFERENCE, ROOT), "note": "the reference was timed on another box of the pool (same image, same generated reads)"}
+            except Exception:                                           # noqa: BLE001 -- no record: no ratio
+                pass
+
+        have_ref = n_ref > 0 and os.path.exists(REF)
+        side_by_side = have_ref and n_large > 0 and not os.environ.get("MEGAGTA_E2E_SERIAL") and cores >= 48
+        th = None
+        if have_ref:
+            if not os.environ.get("MEGAGTA_E2E_REF_THREADS"):
+                ensure_set(n_ref)                                        # (the read sets are made on the GPU: before the threads part)
+            if side_by_side:
+                ensure_set(n_large)
+                th = threading.Thread(target=reference_leg)
+                th.start()
+            else:
+                reference_leg()
+        if n_large > 0 and not ref_box.get("cut_off"):
+            large_leg()
+        if th is not None:
+            th.join()
+        if have_ref:
+            out["reference_ran"] = "beside the GPU's %d-read leg (host cores: %d; the reference's threads + ours' 16 fit)" % (n_large, cores) if side_by_side else "alone on the host"
+            if "sweep" in ref_box:
+                out["reference_thread_sweep"] = ref_box["sweep"]
+            if "error" in ref_box:
+                raise RuntimeError("the reference's run failed: " + ref_box["error"])
+            if "cut_off" in ref_box:
+                out["reference"] = {"reads": n_ours, "threads": ref_box.get("best_t"), "cut_off": ref_box["cut_off"]}
                 return out
-            note(f"e2e reference, {best_t} threads: {n_ours} reads in {dtr:.1f} s")
+            best_t, dtr, ncr = ref_box["best_t"], ref_box["dtr"], ref_box["ncr"]
             out["reference"] = {"reads": n_ours, "seconds": dtr, "threads": best_t, "reads_per_s": n_ours / dtr, "contigs": ncr,
                                 "note": "the reference binary behind the same driver on the SAME files as `ours`; thread count = the best of "
                                         "16 / 32 on the small set"}
@@ -344,19 +410,6 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                 out["contigs_equal_fraction_ours_ordered_vs_unordered"] = equal_fraction("ours_unordered", "ours")
             if "ours_unordered_cache" in out:
                 out["speedup_same_sample_unordered_cache"] = dtr / out["ours_unordered_cache"]["seconds"]
-        if n_large > 0:
-            # a point beyond the same-sample size, ours only (the reference needs ~70 s per million reads): skipped when the run is late
-            if time.time() > large_deadline:
-                out["ours_large"] = {"reads": n_large, "skipped": "the bench run was %.0f s old when this leg was due: not started" % (time.time() - _T0)}
-            else:
-                try:
-                    dtl, ncl = run(n_large, "ours_large", ["-t", str(min(cores, 16))])
-                except TimeoutError as e:
-                    out["ours_large"] = {"reads": n_large, "cut_off": str(e)}
-                    return out
-                note(f"e2e ours: {n_large} reads in {dtl:.1f} s")
-                out["ours_large"] = {"reads": n_large, "seconds": dtl, "reads_per_s": n_large / dtl, "contigs": ncl,
-                                     "note": "megagta.py -k %s on %d reads, default mode, ours only (the reference was not run at this size)" % (klist, n_large)}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -453,7 +506,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--seeds", type=int, default=60000, help="seed k-mers per gene of the A* leg (0 = skip the search leg)")
     ap.add_argument("--e2e-reads", type=int, default=2_000_000, help="reads of the reads->contigs leg through megagta.py (0 = skip)")
-    ap.add_argument("--e2e-large-reads", type=int, default=20_000_000, help="a larger reads->contigs run, ours only (0 = skip; skipped anyway when the bench run is already late)")
+    ap.add_argument("--e2e-large-reads", type=int, default=10_000_000, help="a larger reads->contigs run, ours only (0 = skip; skipped anyway when the bench run is already late)")
     ap.add_argument("--e2e-ref-reads", type=int, default=200_000, help="small set on which the reference's thread count is chosen before it runs on the e2e set (0 = no reference run)")
     ap.add_argument("--product-seeds", type=int, default=60_000, help="findstart seeds per gene of the product-mode search leg (0 = skip)")
     ap.add_argument("--denovo", action="store_true", help="also run the denovo leg above 20 M reads (half a minute at 100 M)")
