@@ -839,6 +839,11 @@ def main():
                             "rank_invariant_floor_ms": s["ms_count"] + s["ms_gen"],
                             "rank_invariant_floor_note": "count + key generation: every rank of a bucket-sharded build scans all reads; "
                                                          "sort + emit shrink with N, this part does not (SURVEY.md 8e)",
+                            # ... and in a `megagta.py --gpus N` run: `denovo` of the intermediate k (GPU 0 only; 26 + 23 s at 100 M reads,
+                            # profiles/r05/e2e_100M_reads_to_seeds_steps.log) and the host steps do not shrink either; `findstart` is
+                            # 0.17 s of kernel per gene at this size (`findstart` leg of this line): nothing to shard
+                            "driver_run_non_scaling_note": "megagta.py --gpus N shards buildgraph (buckets) and search (genes, then seeds); denovo of the intermediate k "
+                                                           "runs on GPU 0: 49 s of the 81 s reads -> seeds at 100 M reads (profiles/r05); findstart's kernel is 0.17 s per gene",
                             "pcie_inclusive_note": "inputs resident; uploading the packed reads (0.25 B/base + 8 B/read at ~55 GB/s) and returning "
                                                    "2 B/edge would add ~%.0f ms per build" % ((args.reads * (L * 0.25 + 8) + s["n_edges"] * 2) / 55e9 * 1e3)},
             "input_generation_s": t_gen,
