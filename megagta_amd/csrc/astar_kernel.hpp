@@ -841,7 +841,6 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     // ---- per-search state (uniform inside a group)
     int st = S_IDLE;
     bool need_scan = false;
-    uint32_t gate_tick = 0;
     uint32_t spins = 0;
     uint32_t last_lim = 0xFFFFFFFFu;                                  // (low word of) the start limit when this wave last looked (gate progress)
     long long seed = -1;
@@ -1005,11 +1004,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 prog_floor = 0;
                 if (a.gate) {
                     if (gl == 0) st_agent(&a.run_seed[slot], (long long)seed);
-#ifdef MGTA_ASTAR_LIGHT_GATE
-                    st = S_WAIT; need_scan = false; spins = 0;          // (the cached limit is looked at first: most seeds find it ahead of them)
-#else
                     st = S_WAIT; need_scan = true; spins = 0;
-#endif
                 } else {
                     st = S_START;
                 }
@@ -1027,14 +1022,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
         // running j, and i < q + B for the next seed q of the queue.  The lowest running search always passes.  The limit moves when a
         // search ends (its wave recomputes it) and, with a cost term, as the running searches progress: for that ONE waiting wave per
         // direction and ~50 us re-reads the table (ticket = time of the last refresh); the others poll one word.
-#ifdef MGTA_ASTAR_LIGHT_GATE
-        // (a wave that has searches RUNNING looks at the gate every fourth iteration only: its waiting seeds wait for the progress of searches
-        // that take milliseconds, and every look is a round trip to the coherence point in front of the running searches' next expansion)
-        const bool gate_now = __ballot(st == S_START || st == S_RUN) == 0ull || (++gate_tick & 3u) == 0u;
-        if (a.gate && gate_now) {
-#else
         if (a.gate) {
-#endif
             if (__ballot(st == S_WAIT) != 0ull) {
                 bool scan = __ballot(st == S_WAIT && need_scan) != 0ull;
                 if (!scan) {
@@ -1801,15 +1789,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
             }
             st = S_IDLE;
         }
-#ifdef MGTA_ASTAR_LIGHT_GATE
-        // whoever finishes a search lets the waiting ones move the limit: the ticket's time is set back, so the next WAITING wave that looks
-        // re-reads the slot table at once (it has nothing else to do), instead of this wave doing it -- 32 dependent rounds over 8 192 slots --
-        // in front of its own running searches
-        if (a.gate && __ballot(finishing) != 0ull && lane == 0)
-            __hip_atomic_store(&a.start_limit[2 + dir], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         if (a.gate && __ballot(finishing) != 0ull) (void)start_bound<G>(a, dir, lane);   // whoever finishes a search moves the limit for the waiting ones
-#endif
         PROF(9)
     }
     PROF_FLUSH
