@@ -435,6 +435,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // searches wait for the next page that comes back, and a third cost the 2 M-read run 4 of its 21 s.)
             a.pool.soft_limit = dyn / 2;
             if (const char *e = getenv("MGTA_ASTAR_SOFT_DIV")) a.pool.soft_limit = dyn / (uint64_t)std::max(1, atoi(e));   // (experiments)
+            if (const char *e = getenv("MGTA_ASTAR_SOFT_PCT")) a.pool.soft_limit = dyn / 100 * (uint64_t)std::min(100, std::max(1, atoi(e)));   // (experiments: per cent of the pool)
             a.gate = gated;
             a.free_share = free_share;
             a.active_slots = attempt == 3 ? 1u : (uint32_t)spb;
