@@ -433,7 +433,12 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // admission: no new search starts while half of the pool is in use.  (A third, while the arrays still doubled: what is in flight
             // goes on growing, the cold searches of a batch's first minute a hundredfold.  With pages an overcommitted pool only makes
             // searches wait for the next page that comes back, and a third cost the 2 M-read run 4 of its 21 s.)
-            a.pool.soft_limit = dyn / 2;
+            // No new search starts while more than this of the pool is in use: the searches that run keep room to grow.  Half of the pool since
+            // round 3; round 6 measured the ordered mode where admission is memory-bound (nirK on the multi-k graph of 50 M reads, 2.64 M seeds,
+            // the same contigs throughout: profiles/r06/soft_limit/): 50 % 166.0 s, 67 % 149.9 s, 80 % 142.5 / 142.8 s, 90 % 154.8 s (searches
+            // starve and wait), 100 % > 400 s (they take each other's room in turns); 2 M and 10 M reads: no difference.  Three quarters for the
+            // ordered mode; independent batches keep the half (a starved independent search is run again by the host).
+            a.pool.soft_limit = gated ? dyn / 4 * 3 : dyn / 2;
             if (const char *e = getenv("MGTA_ASTAR_SOFT_DIV")) a.pool.soft_limit = dyn / (uint64_t)std::max(1, atoi(e));   // (experiments)
             if (const char *e = getenv("MGTA_ASTAR_SOFT_PCT")) a.pool.soft_limit = dyn / 100 * (uint64_t)std::min(100, std::max(1, atoi(e)));   // (experiments: per cent of the pool)
             a.gate = gated;
