@@ -433,12 +433,14 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             // admission: no new search starts while half of the pool is in use.  (A third, while the arrays still doubled: what is in flight
             // goes on growing, the cold searches of a batch's first minute a hundredfold.  With pages an overcommitted pool only makes
             // searches wait for the next page that comes back, and a third cost the 2 M-read run 4 of its 21 s.)
-            // No new search starts while more than this of the pool is in use: the searches that run keep room to grow.  Half of the pool since
-            // round 3; round 6 measured the ordered mode where admission is memory-bound (nirK on the multi-k graph of 50 M reads, 2.64 M seeds,
-            // the same contigs throughout: profiles/r06/soft_limit/): 50 % 166.0 s, 67 % 149.9 s, 80 % 142.5 / 142.8 s, 90 % 154.8 s (searches
-            // starve and wait), 100 % > 400 s (they take each other's room in turns); 2 M and 10 M reads: no difference.  Three quarters for the
-            // ordered mode; independent batches keep the half (a starved independent search is run again by the host).
-            a.pool.soft_limit = gated ? dyn / 4 * 3 : dyn / 2;
+            // No new search starts while more than this of the pool is in use: the searches that run keep room to grow.  HALF of the pool, and it
+            // stays half: round 6 measured other values in the ordered mode where admission is memory-bound (profiles/r06/soft_limit/, the same
+            // contigs throughout).  nirK on the multi-k graph of 50 M reads (2.64 M seeds): 50 % 166.0 s, 67 % 149.9 s, 80 % 142.5 s, 90 % 154.8 s
+            // (searches starve and wait), 100 % > 400 s (they take each other's room in turns) -- but at 100 M reads (5.14 M seeds, the pool no
+            // larger) 75 % is already beyond the cliff: nirK had not ended after 900 s where it takes 391 s with half.  Where the cliff lies
+            // depends on how much the searches in flight still have to grow, which nothing knows when they are admitted.
+            // MGTA_ASTAR_SOFT_PCT / _DIV: experiments.
+            a.pool.soft_limit = dyn / 2;
             if (const char *e = getenv("MGTA_ASTAR_SOFT_DIV")) a.pool.soft_limit = dyn / (uint64_t)std::max(1, atoi(e));   // (experiments)
             if (const char *e = getenv("MGTA_ASTAR_SOFT_PCT")) a.pool.soft_limit = dyn / 100 * (uint64_t)std::min(100, std::max(1, atoi(e)));   // (experiments: per cent of the pool)
             a.gate = gated;
