@@ -592,34 +592,6 @@ __device__ __forceinline__ int cache_lookup(const AstarArgs &a, int dir, uint64_
     }
     return -1;                                                         // (an insert never goes further than this either)
 }
-// the same look-up in two halves: the first probe's two words are asked for early (their round trip to the coherence point runs under the
-// graph walk), the answer is taken when the codons are filtered
-struct CacheProbe { uint64_t i; unsigned long long k, v; };
-__device__ __forceinline__ CacheProbe cache_probe_issue(const AstarArgs &a, int dir, uint64_t key) {
-    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
-    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
-    CacheProbe p;
-    p.i = mix64(key) & cmask;
-    p.k = ld_agent(&tab[p.i].key);
-    p.v = ld_agent(&tab[p.i].val);
-    return p;
-}
-__device__ __forceinline__ int cache_probe_resolve(const AstarArgs &a, int dir, uint64_t key, int64_t seed, CacheProbe p) {
-    const CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
-    const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
-    for (uint32_t probes = 0; probes <= a.cache_probe_limit; ++probes) {
-        if (p.k == 0) return -1;
-        if (p.k == key) {
-            if (p.v == 0ull) return -1;
-            const unsigned long long v = ~p.v;
-            return (int64_t)(v >> 16) <= seed ? (int)(v & 0xFFFF) : -1;
-        }
-        p.i = (p.i + 1) & cmask;
-        p.k = ld_agent(&tab[p.i].key);
-        p.v = ld_agent(&tab[p.i].val);
-    }
-    return -1;
-}
 __device__ __forceinline__ void cache_insert(const AstarArgs &a, int dir, uint64_t key, int64_t visible_from, int em_state) {
     CacheEnt *tab = dir ? a.cache[1] : a.cache[0];
     const uint64_t cmask = dir ? a.cache_mask[1] : a.cache_mask[0];
