@@ -643,7 +643,7 @@ def main():
         last_contigs = {}
 
         def sstep(genes=None):
-            tot = {"n_expansions": 0, "ms_kernel": 0.0, "n_retries": 0, "n_grown": 0, "pool_used": 0}
+            tot = {"n_expansions": 0, "ms_kernel": 0.0, "n_retries": 0, "n_grown": 0, "pool_used": 0, "ms_queue_drained": 0.0, "per_gene": {}}
             mine_all = []
             for gi in (range(len(mg.genes)) if genes is None else genes):
                 mine = share[gi]
@@ -651,8 +651,10 @@ def main():
                 cont, offs, st = api.astar_search_packed(graph, hm[gi][0], hm[gi][1], kmers, states, 20, 0.5) if len(mine) else \
                     (np.zeros(0, np.uint8), np.zeros(1, np.int64), None)
                 if st:
-                    for key in ("n_expansions", "ms_kernel", "n_retries", "n_grown"):
+                    for key in ("n_expansions", "ms_kernel", "n_retries", "n_grown", "ms_queue_drained"):
                         tot[key] += st[key]
+                    tot["per_gene"][mg.genes[gi].name] = {"expansions": st["n_expansions"], "ms_kernel": st["ms_kernel"], "ms_queue_drained": st["ms_queue_drained"],
+                                                          "longest_search_expansions": st["max_search_expansions"]}
                     tot["pool_used"] = max(tot["pool_used"], st["pool_used"])
                 if world > 1:
                     mine_all.append((len(seeds[gi]), mine, cont, offs))
@@ -694,6 +696,10 @@ def main():
                   "lanes_per_search": 8 if max(len(x) for x in seeds) >= 32768 else 16, "searches_in_flight_per_gpu": 16384 if max(len(x) for x in seeds) >= 32768 else 8192,
                   "ms_kernel": sst[-1]["ms_kernel"], "retries": sst[-1]["n_retries"], "searches_grown_in_place": sst[-1]["n_grown"],
                   "warmup_expansions": w0["n_expansions"],
+                  # a batch cannot end before its longest search does: from the moment the last seed is TAKEN the launch only finishes what is in flight
+                  "tail": {"ms_kernel": sst[-1]["ms_kernel"], "ms_until_the_last_seed_was_taken": sst[-1]["ms_queue_drained"],
+                           "tail_fraction_of_kernel_time": 1.0 - sst[-1]["ms_queue_drained"] / max(1e-9, sst[-1]["ms_kernel"]), "per_gene": sst[-1]["per_gene"],
+                           "note": "mgta_astar_stats.ms_queue_drained; one search alone takes 14-17 us per expansion (DESIGN.md 5)"},
                   "pool_used_GB": sst[-1]["pool_used"] / 1e9}
         if rank == 0:
             # roofline of the leg.  Bound: random 128-byte lines (graph lines, heap blocks, hash lines, nodes) -- not the 8 TB/s stream rate and

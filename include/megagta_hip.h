@@ -283,6 +283,9 @@ typedef struct mgta_astar_stats {
                                                            * exceed the CU's 160 KB (models longer than ~400 columns): read from device memory */
     int64_t n_over_limit;                                 /* search sides that outgrew the library's page tables (2 GB per array, ~33 M nodes) and are
                                                            * reported as failed searches (ok = 0, no extension); named on stderr.  0 in every measured run */
+    double ms_queue_drained;                              /* first pass: milliseconds from the kernel's start to the moment the last seed of the batch was
+                                                           * TAKEN by a search slot; ms_kernel - ms_queue_drained = the tail in which the launch only finishes
+                                                           * the searches in flight (a batch cannot end before its longest search does) */
 } mgta_astar_stats;
 
 /* sink gets one call per seed, in seed order: left (already reverse-complemented) + right halves. */

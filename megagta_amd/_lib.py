@@ -52,7 +52,7 @@ class AstarStats(C.Structure):
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double), ("n_grown", C.c_int64), ("n_rehash", C.c_int64),
                 ("n_recycled", C.c_int64), ("pool_bytes", C.c_uint64), ("pool_used", C.c_uint64), ("n_resumes", C.c_int64),
                 ("reserve_bytes", C.c_uint64), ("reserve_used", C.c_uint64), ("max_search_nodes", C.c_int64),
-                ("max_search_expansions", C.c_int64), ("order_abandoned", C.c_int64), ("n_cache_drops", C.c_int64), ("hmm_in_lds", C.c_int64), ("n_over_limit", C.c_int64)]
+                ("max_search_expansions", C.c_int64), ("order_abandoned", C.c_int64), ("n_cache_drops", C.c_int64), ("hmm_in_lds", C.c_int64), ("n_over_limit", C.c_int64), ("ms_queue_drained", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -247,6 +247,9 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
         d_prof.alloc(128);
         MGTA_HIP_CHECK(hipMemsetAsync(d_prof.p, 0, 128, st));
         a.prof = d_prof.as<unsigned long long>();
+        DevBuf d_tmark;
+        d_tmark.alloc(32);
+        a.tmark = d_tmark.as<unsigned long long>();
         const size_t lds_fix = G == 8 ? lds_fixed<8>() : G == 16 ? lds_fixed<16>() : G == 32 ? lds_fixed<32>() : lds_fixed<64>();
         const bool use_lds = lds_fix + tab_bytes + 1024 <= 160 * 1024;             // heap tops + level tables + HMM tables
         const size_t lds_bytes = lds_fix + (use_lds ? tab_bytes : 0);
@@ -469,6 +472,7 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
                 a.todo[d] = d_todo[d].as<int64_t>(); a.n_todo[d] = (int64_t)todo[d].size();
             }
             MGTA_HIP_CHECK(hipEventRecord(ev.e[2], st));
+            MGTA_HIP_CHECK(hipMemsetAsync(d_tmark.p, 0xFF, 32, st));
             if (G == 8) launch_astar<8>(a, (int)blocks, lds_bytes, use_lds, st);
 #ifndef MGTA_ASTAR_G8_ONLY                                                     /* (experiment builds: one instantiation compiles in a quarter of the time) */
             else if (G == 16) launch_astar<16>(a, (int)blocks, lds_bytes, use_lds, st);
@@ -530,11 +534,19 @@ int astar_batch_impl(mgta_ctx *ctx, mgta_sdbg *g, const mgta_hmm *fwd, const mgt
             MGTA_HIP_CHECK(hipMemcpyAsync(h_pool, ar.meta.p, 64, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipMemcpyAsync(h_cnt, ar.meta.as<uint32_t>() + 16 + kNumClasses, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
             if (cache_mode > 0) MGTA_HIP_CHECK(hipMemcpyAsync(h_lim, d_start_limit.p, 128, hipMemcpyDeviceToHost, st));
+            unsigned long long h_tmark[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+            MGTA_HIP_CHECK(hipMemcpyAsync(h_tmark, d_tmark.p, 32, hipMemcpyDeviceToHost, st));
             MGTA_HIP_CHECK(hipStreamSynchronize(st));
             MGTA_HIP_CHECK(hipGetLastError());
             float ms = 0;
             MGTA_HIP_CHECK(hipEventElapsedTime(&ms, ev.e[2], ev.e[3]));
             ST.ms_kernel += ms;
+            if (attempt == 0 && h_tmark[0] != ~0ull) {                                // when the last seed of the batch was TAKEN: what follows is the tail
+                double drained = 0;
+                for (int d = 0; d < 2; ++d)
+                    if (h_tmark[1 + d] != ~0ull && h_tmark[1 + d] >= h_tmark[0]) drained = std::max(drained, (double)(h_tmark[1 + d] - h_tmark[0]) * 1e-5);
+                ST.ms_queue_drained = drained;
+            }
             ST.n_recycled += (int64_t)h_pool[1]; ST.n_rehash += (int64_t)h_pool[3]; ST.n_grown += (int64_t)h_pool[4];
             ST.n_retries += (int64_t)h_pool[7];                                      // searches that started again in place
             ST.pool_bytes = pool_bytes;

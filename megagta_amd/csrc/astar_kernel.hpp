@@ -174,6 +174,8 @@ struct AstarArgs {
     uint32_t blocks_dir0;         // workgroups [0, blocks_dir0) search direction 0 (the k-mer, forward model), the rest direction 1: split by the work the
                                   // seeds' model positions promise (a forward search covers M - s columns, a reverse one s), not in halves
     unsigned long long *prof;     // [16] per-phase cycle sums (MGTA_ASTAR_PROFILE builds only)
+    unsigned long long *tmark;    // s_memrealtime ticks (10 ns), kept by atomic minimum, all-ones = never: [0] the launch's first workgroup at work, [1 + dir] the
+                                  // first slot of the direction that found its queue empty (from then on the launch only finishes what is in flight: the tail)
     uint32_t ramp_base;           // ordered launches: searches in flight per direction before any has ended (slow start)
     int auto_unorder;             // ordered launches, OPT-IN (MEGAGTA_SEARCH_ALLOW_UNORDERED=1): when the searches in flight have outgrown the pool (thousands of refused requests) the
                                   // batch gives up the ORDER, not the searches: start_limit[14] is set, from then on every path is visible
@@ -769,6 +771,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
     double *const s_tab = reinterpret_cast<double *>(s_mem + (size_t)SPB * (kLdsHeapSlots * sizeof(HeapEnt) + kPtWords * sizeof(uint32_t) + kStage * sizeof(HeapEnt)));
 
     const int dir = blockIdx.x < a.blocks_dir0 ? 0 : 1;
+    if (threadIdx.x == 0) __hip_atomic_fetch_min(&a.tmark[0], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     HmmView hv;                                                       // select by value: no indexed access into the kernel arguments
     hv.tab = dir ? a.hm[1].tab : a.hm[0].tab; hv.M = dir ? a.hm[1].M : a.hm[0].M; hv.A = dir ? a.hm[1].A : a.hm[0].A;
     hv.col_fwd = dir ? a.hm[1].col_fwd : a.hm[0].col_fwd; hv.col_enum = dir ? a.hm[1].col_enum : a.hm[0].col_enum;
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(kAstarThreads) void astar_kernel(AstarArgs a) {
                 // (slow start: no seed taken this time)
             } else if (qi >= n_todo) {
                 st = S_EXIT;
+                if (gl == 0) __hip_atomic_fetch_min(&a.tmark[1 + dir], (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (a.gate && gl == 0) st_agent(&a.run_seed[slot], -1ll);
             } else {
                 seed = todo[qi];

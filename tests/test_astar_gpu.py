@@ -209,6 +209,9 @@ def test_longest_first_order_of_cold_batches_changes_no_result(ctx, meta20k, mon
     monkeypatch.delenv("MGTA_ASTAR_LPT")
     got, st1 = api.astar_search(meta20k.g, meta20k.fw, meta20k.rv, meta20k.kmers, meta20k.states, 20, 0.5)
     assert st0["n_expansions"] == st1["n_expansions"] > 10000
+    # the moment the last seed was taken lies inside the launch (what follows is the tail: mgta_astar_stats.ms_queue_drained)
+    for st in (st0, st1):
+        assert 0.0 <= st["ms_queue_drained"] <= st["ms_kernel"] * 1.05 + 1.0, st
     for a, b, km in zip(got, want, meta20k.kmers):
         assert a.contig(km) == b.contig(km) and a.right_side == b.right_side and a.left_side == b.left_side
 
