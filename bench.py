@@ -330,14 +330,37 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             forced = os.environ.get("MEGAGTA_E2E_REF_THREADS")          # (one-off runs at sizes where the sweep does not fit the call)
             best_t = int(forced) if forced else 0
             try:
+                crashed = {}
                 for threads in ([] if forced else sorted({min(cores, 16), min(cores, 32)})):     # (64 threads and every core were slower than 32 in every sweep of rounds 2-4)
-                    dtr, _ = run(n_ref, f"ref_small_t{threads}", ["--bin", REF, "-t", str(threads)])
+                    try:
+                        dtr, _ = run(n_ref, f"ref_small_t{threads}", ["--bin", REF, "-t", str(threads)])
+                    except RuntimeError as e:
+                        # the reference's multi-thread `search` reads term_nodes without a lock (search.cpp:182-189) and segfaults now and then: that
+                        # thread count is named and left out, the leg goes on
+                        crashed[threads] = str(e)[-200:]
+                        note(f"e2e reference, {threads} threads: the run on {n_ref} reads FAILED (left out of the sweep)")
+                        continue
                     sweep[threads] = dtr
                     note(f"e2e reference, {threads} threads: {n_ref} reads in {dtr:.1f} s")
+                if sweep or crashed:
+                    ref_box["sweep"] = {"reads": n_ref, "seconds_by_threads": sweep, "crashed": crashed}
                 if sweep:
                     best_t = min(sweep, key=sweep.get)
-                    ref_box["sweep"] = {"reads": n_ref, "seconds_by_threads": sweep}
-                dtr, ncr = run(n_ours, f"ref_t{best_t}", ["--bin", REF, "-t", str(best_t)])
+                elif not forced:
+                    best_t = min(cores, 16)
+                tries = [best_t] + [t for t in sorted(sweep, key=sweep.get) if t != best_t]
+                last = None
+                for t_ in tries:                                         # (a crash of the big run: once more with the next-best thread count)
+                    try:
+                        dtr, ncr = run(n_ours, f"ref_t{t_}", ["--bin", REF, "-t", str(t_)])
+                        best_t = t_
+                        last = None
+                        break
+                    except RuntimeError as e:
+                        last = e
+                        note(f"e2e reference, {t_} threads: the run on {n_ours} reads FAILED")
+                if last is not None:
+                    raise last
                 note(f"e2e reference, {best_t} threads: {n_ours} reads in {dtr:.1f} s")
                 ref_box.update(best_t=best_t, dtr=dtr, ncr=ncr)
             except TimeoutError as e:
@@ -391,8 +414,9 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
             out["reference_ran"] = "beside the GPU's %d-read leg (host cores: %d; the reference's threads + ours' 16 fit)" % (n_large, cores) if side_by_side else "alone on the host"
             if "sweep" in ref_box:
                 out["reference_thread_sweep"] = ref_box["sweep"]
-            if "error" in ref_box:
-                raise RuntimeError("the reference's run failed: " + ref_box["error"])
+            if "error" in ref_box:                                       # (ours' numbers stay in the line whatever the reference did)
+                out["reference"] = {"reads": n_ours, "threads": ref_box.get("best_t"), "error": ref_box["error"][-600:]}
+                return out
             if "cut_off" in ref_box:
                 out["reference"] = {"reads": n_ours, "threads": ref_box.get("best_t"), "cut_off": ref_box["cut_off"]}
                 return out
