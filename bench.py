@@ -406,10 +406,12 @@ def e2e_leg(gene_specs, n_ours: int, n_ref: int, device: str, klist: str = "30,3
                 th.start()
             else:
                 reference_leg()
-        if n_large > 0 and not ref_box.get("cut_off"):
-            large_leg()
-        if th is not None:
-            th.join()
+        try:
+            if n_large > 0 and not ref_box.get("cut_off"):
+                large_leg()
+        finally:
+            if th is not None:                                           # (never leave the leg -- and remove its files -- under a running reference)
+                th.join()
         if have_ref:
             out["reference_ran"] = "beside the GPU's %d-read leg (host cores: %d; the reference's threads + ours' 16 fit)" % (n_large, cores) if side_by_side else "alone on the host"
             if "sweep" in ref_box:
