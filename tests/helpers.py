@@ -158,8 +158,13 @@ def stagewise_vs_reference(out, work, gene_list: str, oracle, ref_bin: str, our_
     the contigs of the intermediate k (denovo -t 1), the seeds of every gene (findstart, sorted: the reference shuffles its lines),
     and the raw contigs of every gene: MEGAGTA_CACHE_WINDOW=1 byte-identical to the reference's `search ... 1` on the same graph and
     seed files, the driver's own run (whatever window it ran with) compared as a multiset.  -> {gene: (equal as a multiset, seeds)}"""
+    return stagewise_finish(stagewise_start(out, work, gene_list, ref_bin, our_bin), oracle, min_multiset)
+
+
+def stagewise_start(out, work, gene_list: str, ref_bin: str, our_bin: str):
+    """the reference's steps of stagewise_vs_reference, started (host threads; only `w1` uses the GPU) -- a caller with GPU work of its own to do
+    in the meantime (the two-rank run of the config-4 test) joins them later with stagewise_finish"""
     import subprocess
-    from collections import Counter
     from concurrent.futures import ThreadPoolExecutor
     run = lambda cmd, **kw: subprocess.run(cmd, check=True, capture_output=True, **kw)
     lib = str(out / "tmp" / "reads.lib")
@@ -169,24 +174,33 @@ def stagewise_vs_reference(out, work, gene_list: str, oracle, ref_bin: str, our_
     # every reference step takes its inputs from the FINISHED run under `out` (the previous k's contigs, the graph and seed files), so the
     # steps do not wait for each other: they run side by side on the host cores (one after the other they were most of the test's minute)
     jobs = {}
-    with ThreadPoolExecutor(max_workers=8) as ex:
-        prev = None
-        for k in (29, 35, 44):                                        # the three graphs
-            cmd = [ref_bin, "buildgraph", "-k", str(k), "--output_prefix", str(work / f"ref_{k}")] + common
-            if prev is not None:
-                cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
-            jobs[("graph", k)] = ex.submit(run, cmd)
-            prev = k
-        for k, nxt in ((29, 35), (35, 44)):                           # the contigs of the intermediate k
-            jobs[("denovo", k)] = ex.submit(run, [ref_bin, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(work / f"ref_{k}"), "-t", "1", "--min_standalone", "400",
-                                                  "--max_tip_len", "150", "--min_contig", str(nxt + 1)])
-        for gene, faa in genes.items():                               # the seeds of every gene
-            jobs[("seeds", gene)] = ex.submit(run, [ref_bin, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")])
-        # the reference's one-thread search on OUR graph files and seed files; window 1 == that run, byte for byte, all genes in one call
-        jobs["ref1"] = ex.submit(run, [ref_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ref1"), "20", "0.5", "1"])
-        jobs["w1"] = ex.submit(run, [our_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ours_w1"), "20", "0.5", "4"],
-                               env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
-        done = {key: f.result() for key, f in jobs.items()}
+    ex = ThreadPoolExecutor(max_workers=8)
+    prev = None
+    for k in (29, 35, 44):                                            # the three graphs
+        cmd = [ref_bin, "buildgraph", "-k", str(k), "--output_prefix", str(work / f"ref_{k}")] + common
+        if prev is not None:
+            cmd += ["--assist_seq", str(out / f"k{prev}" / f"{prev}.contigs.fa")]
+        jobs[("graph", k)] = ex.submit(run, cmd)
+        prev = k
+    for k, nxt in ((29, 35), (35, 44)):                               # the contigs of the intermediate k
+        jobs[("denovo", k)] = ex.submit(run, [ref_bin, "denovo", "-s", str(out / f"k{k}" / f"{k}"), "-o", str(work / f"ref_{k}"), "-t", "1", "--min_standalone", "400",
+                                              "--max_tip_len", "150", "--min_contig", str(nxt + 1)])
+    for gene, faa in genes.items():                                   # the seeds of every gene
+        jobs[("seeds", gene)] = ex.submit(run, [ref_bin, "findstart", faa, lib + ".bin", "45", "2", str(out / "k35" / "35.contigs.fa")])
+    # the reference's one-thread search on OUR graph files and seed files; window 1 == that run, byte for byte, all genes in one call
+    jobs["ref1"] = ex.submit(run, [ref_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ref1"), "20", "0.5", "1"])
+    jobs["w1"] = ex.submit(run, [our_bin, "search", str(out / "k44" / "44"), gene_list, str(out / "k44" / "44"), str(work / "ours_w1"), "20", "0.5", "4"],
+                           env={**os.environ, "MEGAGTA_CACHE_WINDOW": "1"})
+    return {"ex": ex, "jobs": jobs, "out": out, "work": work, "genes": genes}
+
+
+def stagewise_finish(started, oracle, min_multiset: float = 0.95):
+    from collections import Counter
+    out, work, genes = started["out"], started["work"], started["genes"]
+    try:
+        done = {key: f.result() for key, f in started["jobs"].items()}
+    finally:
+        started["ex"].shutdown(wait=True)
     for k in (29, 35, 44):
         assert oracle.Stream.read(str(out / f"k{k}" / f"{k}")).edges().md5() == oracle.Stream.read(str(work / f"ref_{k}")).edges().md5(), k
     for k in (29, 35):
